@@ -1,0 +1,211 @@
+/* ricadi.h -- C-ABI of libricadi_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the low-rank Newton-ADI hot path that optconpy reaches
+ * through `import sadptprj_riclyap_adi.{proj_ric_utils,lin_alg_utils}`
+ * (/root/reference/optcont_main.py:13-14, /root/reference/solve_dae_ric.py:3-4).
+ * Every entry point below names the reference-side call it stands behind.
+ *
+ * Conventions
+ *  - plain C types only; all matrices FP64, all indices int32;
+ *  - sparse matrices are CSR (rowptr[nrows+1], col[nnz], val[nnz]), sorted or not;
+ *  - dense panels are ROW-MAJOR, `ld` = number of columns unless stated
+ *    (a C-order numpy array of shape (n, m) is passed as is);
+ *  - the caller owns every host buffer; the library copies in / out and keeps
+ *    device state only inside the opaque context;
+ *  - every function returns 0 on success or a negative RICADI_E* code;
+ *    ricadi_last_error() gives the message.  Non-convergence of ADI/Newton is
+ *    not an error (the reference just stops at *_max_steps); iteration counts
+ *    and histories come back through the stats arrays;
+ *  - a context is bound to one GPU and one HIP stream and is NOT thread safe.
+ *
+ * The operator handled by a context is the saddle-point matrix
+ *
+ *      S(alpha, beta) = [ beta*A + alpha*E - U*Vt    Jt ]
+ *                       [ J                           0  ]
+ *
+ * with A ("cal A"), E ("cal E") NV x NV, J NP x NV, and an optional low-rank
+ * term U (NV x q), Vt (q x NV).  An ADI shift p is (alpha, beta) = (p, 1); the
+ * Leray projection uses (1, 0).
+ */
+#ifndef RICADI_H
+#define RICADI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RICADI_OK 0
+#define RICADI_EINVAL (-1)    /* bad argument                               */
+#define RICADI_EHIP (-2)      /* HIP / rocSOLVER runtime error              */
+#define RICADI_ENOCONV (-3)   /* inner Krylov solve missed its tolerance    */
+#define RICADI_EBREAKDOWN (-4)/* singular block / coarse matrix             */
+#define RICADI_ESTATE (-5)    /* call order violated (operator not set ...) */
+
+typedef struct ricadi_ctx ricadi_ctx;
+
+/* Options of the inner solver (block-Jacobi + coarse-level preconditioned
+ * GMRES).  Zero-initialise and call ricadi_default_opts() first.            */
+typedef struct ricadi_opts {
+  double gmres_tol;      /* relative residual per column (default 1e-11)    */
+  int gmres_restart;     /* Krylov vectors per cycle (default 60)           */
+  int gmres_maxit;       /* max iterations per solve (default 3000)         */
+  int bj_block;          /* block-Jacobi block size, <= 64 (default 32)     */
+  int agg_v;             /* velocity aggregate size of the coarse level     */
+  int agg_p;             /* pressure aggregate size of the coarse level     */
+  int coarse_max;        /* cap on coarse dimension (default 4096)          */
+  int use_coarse;        /* 0: one-level block-Jacobi only                  */
+  int verbose;
+} ricadi_opts;
+
+/* Parameters of the ADI / Newton loops; same meaning as the keys of the
+ * reference's `nwtn_adi_dict` (/root/reference/optcont_main.py:122-131).    */
+typedef struct ricadi_adi_params {
+  int adi_max_steps;
+  double adi_newZ_reltol;
+  int nwtn_max_steps;
+  double nwtn_upd_reltol;
+  double nwtn_upd_abstol;
+  int project_w;         /* project the rhs factor first (default 1)        */
+  int verbose;
+} ricadi_adi_params;
+
+const char* ricadi_last_error(void);
+int ricadi_version(void);
+void ricadi_default_opts(ricadi_opts* o);
+void ricadi_default_adi_params(ricadi_adi_params* p);
+
+/* ---- context ---------------------------------------------------------- */
+int ricadi_create(int device_id, ricadi_ctx** ctx);
+int ricadi_destroy(ricadi_ctx* ctx);
+int ricadi_set_opts(ricadi_ctx* ctx, const ricadi_opts* o);
+/* HIP stream all work of this context is enqueued on (as a void*).          */
+void* ricadi_stream(ricadi_ctx* ctx);
+int ricadi_synchronize(ricadi_ctx* ctx);
+
+/* ---- operator ---------------------------------------------------------
+ * Replaces the (amat, mmat, jmat) arguments of
+ * pru.solve_proj_lyap_stein / pru.proj_alg_ric_newtonadi
+ * (/root/reference/tests/test_units_compfacres_compress.py:62-64,
+ *  /root/reference/optcont_main.py:488-492, solve_dae_ric.py:152-159) and of
+ * lau.solve_sadpnt_smw (/root/reference/solve_dae_ric.py:192-194).
+ * A = cal A, E = cal E already in the orientation they are applied in
+ * (the Python shim resolves `transposed`).                                  */
+int ricadi_set_operator(ricadi_ctx* ctx, int nv, int np,
+                        const int32_t* a_rowptr, const int32_t* a_col, const double* a_val,
+                        const int32_t* e_rowptr, const int32_t* e_col, const double* e_val,
+                        const int32_t* j_rowptr, const int32_t* j_col, const double* j_val);
+
+/* Low-rank term  - U * Vt ;  U is NV x q row-major, V is NV x q row-major
+ * (i.e. Vt = V^T).  q = 0 removes it.  Stands behind the umat / vmat
+ * arguments of lau.solve_sadpnt_smw (/root/reference/solve_dae_ric.py:192-194,
+ * optcont_main.py:510-514).                                                 */
+int ricadi_set_lowrank(ricadi_ctx* ctx, const double* U, const double* V, int q);
+
+/* ---- K1: saddle-point SpMM (testable kernel) --------------------------
+ * Y = S(alpha, beta) * X for an n x m panel, n = NV + NP (host buffers).    */
+int ricadi_spmm(ricadi_ctx* ctx, double alpha, double beta,
+                const double* X, int m, double* Y);
+
+/* Preconditioner alone: Z = P(alpha,beta)^-1 * R  (n x m), for tests.       */
+int ricadi_precond_apply(ricadi_ctx* ctx, double alpha, double beta,
+                         const double* R, int m, double* Z);
+
+/* ---- one shift-solve ---------------------------------------------------
+ * Solve S(alpha,beta) [V; L] = [R; Rp] for an NV x m panel R (Rp may be
+ * NULL = 0).  X_out is n x m (velocity rows first).  iters_out[1],
+ * relres_out[m] may be NULL.  This is the unit of the `shift-solves/s`
+ * metric; stands behind lau.solve_sadpnt_smw.                              */
+int ricadi_shift_solve(ricadi_ctx* ctx, double alpha, double beta,
+                       const double* R, const double* Rp, int m,
+                       double* X_out, int* iters_out, double* relres_out);
+
+/* ---- a2: low-rank ADI for the projected Lyapunov equation -------------
+ * pru.solve_proj_lyap_stein (/root/reference/tests/test_units_compfacres_compress.py:62-64).
+ * W is NV x m.  Z_out must hold NV x (adi_max_steps*m) doubles, row-major
+ * with ld = *c_out on return (columns are packed).  Z_out may be NULL: the
+ * factor then stays on the device (see ricadi_factor_*).
+ * stats_out (may be NULL) receives [steps, rel_newZ, total_gmres_iters,
+ * shift_solves, ||W_end^T W_end||_F].                                       */
+int ricadi_lyap_adi(ricadi_ctx* ctx, const double* shifts, int nshifts,
+                    const double* W, int m, const ricadi_adi_params* prm,
+                    double* Z_out, int* c_out, double* stats_out);
+
+/* ---- a1: Newton-Kleinman ADI for the projected Riccati equation -------
+ * pru.proj_alg_ric_newtonadi (/root/reference/optcont_main.py:488-492,
+ * /root/reference/solve_dae_ric.py:152-159).  B is NV x nb dense, W NV x mw,
+ * Z0 NV x c0 (or NULL), oldB NV x nb (mtxoldb, or NULL).  Z_out capacity
+ * NV x zcap doubles (zcap >= adi_max_steps*(mw+nb)); may be NULL.
+ * stats_out: [newton_steps, last_upd_abs, last_upd_rel, total_adi_steps,
+ * total_gmres_iters, shift_solves].                                         */
+int ricadi_ric_newtonadi(ricadi_ctx* ctx, const double* shifts, int nshifts,
+                         const double* B, int nb, const double* W, int mw,
+                         const double* Z0, int c0, const double* oldB,
+                         const ricadi_adi_params* prm,
+                         double* Z_out, int zcap, int* c_out, double* stats_out);
+
+/* ---- a3: column compression -------------------------------------------
+ * pru.compress_Zsvd (/root/reference/optcont_main.py:498-499,
+ * solve_dae_ric.py:162-163).  Keeps singular values > thresh (thresh < 0:
+ * no threshold) and at most kmax (kmax <= 0: no cap).  Z == NULL compresses
+ * the factor left on the device by the last ADI / Newton call.  Zc_out is
+ * NV x *k_out row-major; sv_out (may be NULL) receives min(c, NV) singular
+ * values.                                                                  */
+int ricadi_compress(ricadi_ctx* ctx, const double* Z, int c, double thresh, int kmax,
+                    double* Zc_out, int* k_out, double* sv_out);
+
+/* ---- a4: factored product  E * (Z * (Z^T * B)) -------------------------
+ * pru.get_mTzzTtb(MT, Z, tb) (/root/reference/optcont_main.py:505-506,
+ * solve_dae_ric.py:101,183,189); the feedback gain is its negative.
+ * `mt_*` is the CSR of the matrix applied from the left (NV x NV); NULL uses
+ * cal E of the context.  Z == NULL uses the device-resident factor.         */
+int ricadi_gain(ricadi_ctx* ctx,
+                const int32_t* mt_rowptr, const int32_t* mt_col, const double* mt_val,
+                const double* Z, int c, const double* B, int nb, double* K_out);
+
+/* ---- a5: squared projected Lyapunov residual norm from factors ---------
+ * pru.comp_proj_lyap_res_norm(Z, F, M, W, J)
+ * (/root/reference/tests/test_units_compfacres_compress.py:82,104).
+ * Uses the context operator: cal A = F^T, cal E = M^T, low-rank term.      */
+int ricadi_lyap_res_norm(ricadi_ctx* ctx, const double* Z, int c,
+                         const double* W, int m, double* res2_out);
+
+/* ---- device-resident factor -------------------------------------------- */
+int ricadi_factor_cols(ricadi_ctx* ctx, int* c_out);
+int ricadi_factor_get(ricadi_ctx* ctx, double* Z_out, int c);
+int ricadi_factor_set(ricadi_ctx* ctx, const double* Z, int c);
+
+/* ---- device-pointer level (multi-GPU orchestration, benchmarks) --------
+ * Same operations on buffers that already live in HBM (e.g. torch tensors'
+ * data_ptr()); nothing is copied to or from the host.                      */
+int ricadi_spmm_dev(ricadi_ctx* ctx, double alpha, double beta,
+                    const double* dX, int m, double* dY);
+int ricadi_shift_solve_dev(ricadi_ctx* ctx, double alpha, double beta,
+                           const double* dR, int m, double* dX,
+                           int* iters_out, double* relres_out);
+/* dW (NV x m) += coef * E * dV (first NV rows of an n x m or NV x m panel) */
+int ricadi_apply_e_dev(ricadi_ctx* ctx, double coef, const double* dV, int m, double* dW);
+/* Frobenius norms of the m columns' Gram matrix: out = ||W^T W||_F, and the
+ * squared F-norm of the panel in nrm2 (both may be NULL).                  */
+int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,
+                           double* gram_fro, double* nrm2);
+/* Average duration (ms) of the last timed kernel class, measured with HIP
+ * events on the context stream: which = 0 SpMM.                            */
+int ricadi_time_spmm_dev(ricadi_ctx* ctx, double alpha, double beta, const double* dX,
+                         int m, double* dY, int reps, double* ms_per_launch);
+
+/* ---- host-side logic exported for CPU tests ---------------------------- */
+/* Greedy BFS aggregation of the graph of a CSR pattern into blocks of at
+ * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */
+int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col,
+                          int bsize, int32_t* blk_out);
+/* Cauchy recombination data for a sweep of g distinct real shifts
+ * (SURVEY.md section 8e):  C_ij = -1/(p_i+p_j) = R^T R (upper R);
+ * rinv_out = R^-1 (g x g row-major), cinv1_out = C^-1 * ones (g).          */
+int ricadi_host_cauchy(const double* shifts, int g, double* rinv_out, double* cinv1_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RICADI_H */

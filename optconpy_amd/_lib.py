@@ -1,0 +1,422 @@
+"""ctypes binding of ``libricadi_hip.so`` (the C-ABI in ``include/ricadi.h``).
+
+The shared library is the product; there is no CPU fallback.  Importing this
+module only loads the library; creating a :class:`Context` needs a visible
+MI355X and raises ``RuntimeError`` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sps
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libricadi_hip.so")
+
+RICADI_OK = 0
+RICADI_ENOCONV = -3
+MAX_M = 128
+
+
+class RicadiOpts(C.Structure):
+    _fields_ = [("gmres_tol", C.c_double), ("gmres_restart", C.c_int),
+                ("gmres_maxit", C.c_int), ("bj_block", C.c_int), ("agg_v", C.c_int),
+                ("agg_p", C.c_int), ("coarse_max", C.c_int), ("use_coarse", C.c_int),
+                ("verbose", C.c_int)]
+
+
+class RicadiAdiParams(C.Structure):
+    _fields_ = [("adi_max_steps", C.c_int), ("adi_newZ_reltol", C.c_double),
+                ("nwtn_max_steps", C.c_int), ("nwtn_upd_reltol", C.c_double),
+                ("nwtn_upd_abstol", C.c_double), ("project_w", C.c_int),
+                ("verbose", C.c_int)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/ricadi.h
+SIGNATURES = {
+    "ricadi_last_error": (C.c_char_p, []),
+    "ricadi_version": (C.c_int, []),
+    "ricadi_default_opts": (None, [C.POINTER(RicadiOpts)]),
+    "ricadi_default_adi_params": (None, [C.POINTER(RicadiAdiParams)]),
+    "ricadi_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "ricadi_destroy": (C.c_int, [_vp]),
+    "ricadi_set_opts": (C.c_int, [_vp, C.POINTER(RicadiOpts)]),
+    "ricadi_stream": (_vp, [_vp]),
+    "ricadi_synchronize": (C.c_int, [_vp]),
+    "ricadi_set_operator": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp,
+                                      _ip, _ip, _dp]),
+    "ricadi_set_lowrank": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "ricadi_spmm": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
+    "ricadi_precond_apply": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
+    "ricadi_shift_solve": (C.c_int, [_vp, C.c_double, C.c_double, _dp, _dp, C.c_int, _dp,
+                                     C.POINTER(C.c_int), _dp]),
+    "ricadi_lyap_adi": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, C.POINTER(RicadiAdiParams),
+                                  _dp, C.POINTER(C.c_int), _dp]),
+    "ricadi_ric_newtonadi": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp,
+                                       C.c_int, _dp, C.POINTER(RicadiAdiParams), _dp, C.c_int,
+                                       C.POINTER(C.c_int), _dp]),
+    "ricadi_compress": (C.c_int, [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp,
+                                  C.POINTER(C.c_int), _dp]),
+    "ricadi_gain": (C.c_int, [_vp, _ip, _ip, _dp, _dp, C.c_int, _dp, C.c_int, _dp]),
+    "ricadi_lyap_res_norm": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp]),
+    "ricadi_factor_cols": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ricadi_factor_get": (C.c_int, [_vp, _dp, C.c_int]),
+    "ricadi_factor_set": (C.c_int, [_vp, _dp, C.c_int]),
+    "ricadi_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp]),
+    "ricadi_shift_solve_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp,
+                                         C.POINTER(C.c_int), _dp]),
+    "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
+    "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
+    "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
+                                       _dp]),
+    "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
+    "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libricadi_hip.so is missing ({0}); build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` -- there is no "
+            "CPU fallback for the HIP path".format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _chk(rc, allow_noconv=False):
+    if rc == RICADI_OK or (allow_noconv and rc == RICADI_ENOCONV):
+        return rc
+    msg = load().ricadi_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError("ricadi: " + msg)
+    raise RuntimeError("ricadi error {0}: {1}".format(rc, msg))
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def as_panel(a, nrows=None):
+    """C-contiguous float64 2-D array (column vectors become n x 1)."""
+    if sps.issparse(a):
+        a = a.toarray()
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    a = np.ascontiguousarray(a)
+    if nrows is not None and a.shape[0] != nrows:
+        raise ValueError("panel has {0} rows, expected {1}".format(a.shape[0], nrows))
+    return a
+
+
+def as_csr(a):
+    """Sorted CSR with int32 indices and float64 values (input csr / csc / dense)."""
+    m = sps.csr_matrix(a, dtype=np.float64)
+    m.sum_duplicates()
+    m.sort_indices()
+    if m.nnz >= 2 ** 31:
+        raise ValueError("matrix too large for int32 indices")
+    return (np.ascontiguousarray(m.indptr, dtype=np.int32),
+            np.ascontiguousarray(m.indices, dtype=np.int32),
+            np.ascontiguousarray(m.data, dtype=np.float64), m.shape)
+
+
+def default_opts(**kw):
+    o = RicadiOpts()
+    load().ricadi_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError("unknown ricadi option " + k)
+        setattr(o, k, v)
+    return o
+
+
+def adi_params(d=None, project_w=True):
+    """Translate the reference's ``nwtn_adi_dict`` (optcont_main.py:122-131).
+
+    Unknown keys are ignored, missing ones take the reference defaults.
+    """
+    p = RicadiAdiParams()
+    load().ricadi_default_adi_params(C.byref(p))
+    d = {} if d is None else d
+    for k in ("adi_max_steps", "nwtn_max_steps"):
+        if k in d:
+            setattr(p, k, int(d[k]))
+    for k in ("adi_newZ_reltol", "nwtn_upd_reltol", "nwtn_upd_abstol"):
+        if k in d:
+            setattr(p, k, float(d[k]))
+    p.verbose = 1 if d.get("verbose", False) else 0
+    p.project_w = 1 if d.get("project_w", project_w) else 0
+    return p
+
+
+class Context:
+    """One GPU, one stream, one saddle-point operator."""
+
+    def __init__(self, device=0, **opts):
+        self._lib = load()
+        self._h = _vp()
+        _chk(self._lib.ricadi_create(int(device), C.byref(self._h)))
+        self.nv = self.np_ = 0
+        if opts:
+            self.set_opts(**opts)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ricadi_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self):
+        return self._lib.ricadi_stream(self._h)
+
+    def synchronize(self):
+        _chk(self._lib.ricadi_synchronize(self._h))
+
+    def set_opts(self, **kw):
+        o = default_opts(**kw)
+        self._opts = o
+        _chk(self._lib.ricadi_set_opts(self._h, C.byref(o)))
+
+    # -- operator ---------------------------------------------------------
+    def set_operator(self, calA, calE, J=None):
+        """``calA``, ``calE`` NV x NV, ``J`` NP x NV (or None), any scipy format."""
+        arp, aci, av, ash = as_csr(calA)
+        erp, eci, ev, esh = as_csr(calE)
+        nv = ash[0]
+        if ash != (nv, nv) or esh != (nv, nv):
+            raise ValueError("calA / calE must be square and of equal size")
+        if J is not None and J.shape[0] > 0:
+            jrp, jci, jv, jsh = as_csr(J)
+            if jsh[1] != nv:
+                raise ValueError("J has the wrong number of columns")
+            np_ = jsh[0]
+            _chk(self._lib.ricadi_set_operator(self._h, nv, np_, _i(arp), _i(aci), _d(av),
+                                               _i(erp), _i(eci), _d(ev), _i(jrp), _i(jci),
+                                               _d(jv)))
+        else:
+            np_ = 0
+            _chk(self._lib.ricadi_set_operator(self._h, nv, 0, _i(arp), _i(aci), _d(av),
+                                               _i(erp), _i(eci), _d(ev), None, None, None))
+        self.nv, self.np_ = nv, np_
+        self.n = nv + np_
+
+    def set_lowrank(self, U=None, V=None):
+        """Operator becomes ``beta*A + alpha*E - U V^T`` (both NV x q)."""
+        if U is None or V is None:
+            _chk(self._lib.ricadi_set_lowrank(self._h, None, None, 0))
+            return
+        U = as_panel(U, self.nv)
+        V = as_panel(V, self.nv)
+        if U.shape != V.shape:
+            raise ValueError("U and V must have the same shape")
+        _chk(self._lib.ricadi_set_lowrank(self._h, _d(U), _d(V), U.shape[1]))
+
+    # -- kernels ----------------------------------------------------------
+    def spmm(self, alpha, beta, X):
+        X = as_panel(X, self.n)
+        Y = np.empty_like(X)
+        _chk(self._lib.ricadi_spmm(self._h, alpha, beta, _d(X), X.shape[1], _d(Y)))
+        return Y
+
+    def precond_apply(self, alpha, beta, R):
+        R = as_panel(R, self.n)
+        Z = np.empty_like(R)
+        _chk(self._lib.ricadi_precond_apply(self._h, alpha, beta, _d(R), R.shape[1], _d(Z)))
+        return Z
+
+    def shift_solve(self, alpha, beta, R, Rp=None, strict=True):
+        """Solve ``S(alpha,beta) [V;L] = [R;Rp]``; wide panels go in chunks."""
+        R = as_panel(R, self.nv)
+        m = R.shape[1]
+        Rp = None if Rp is None else as_panel(Rp, self.np_)
+        X = np.empty((self.n, m))
+        iters, relres = 0, np.zeros(m)
+        for c0 in range(0, m, MAX_M):
+            c1 = min(m, c0 + MAX_M)
+            Rc = np.ascontiguousarray(R[:, c0:c1])
+            Rpc = None if Rp is None else np.ascontiguousarray(Rp[:, c0:c1])
+            Xc = np.empty((self.n, c1 - c0))
+            it = C.c_int(0)
+            rr = np.zeros(c1 - c0)
+            rc = self._lib.ricadi_shift_solve(self._h, alpha, beta, _d(Rc),
+                                              None if Rpc is None else _d(Rpc), c1 - c0,
+                                              _d(Xc), C.byref(it), _d(rr))
+            _chk(rc, allow_noconv=not strict)
+            X[:, c0:c1] = Xc
+            iters += it.value
+            relres[c0:c1] = rr
+        return X, iters, relres
+
+    # -- solvers ----------------------------------------------------------
+    def lyap_adi(self, shifts, W, prm, fetch=True):
+        W = as_panel(W, self.nv)
+        m = W.shape[1]
+        sh = np.ascontiguousarray(shifts, dtype=np.float64)
+        cap = prm.adi_max_steps * m
+        Z = np.empty((self.nv, cap)) if fetch else None
+        cc = C.c_int(0)
+        stats = np.zeros(8)
+        _chk(self._lib.ricadi_lyap_adi(self._h, _d(sh), sh.size, _d(W), m, C.byref(prm),
+                                       None if Z is None else _d(Z), C.byref(cc), _d(stats)))
+        c = cc.value
+        if fetch:
+            Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
+        info = dict(adi_steps=int(stats[0]), adi_rel_newZ=stats[1], gmres_iters=int(stats[2]),
+                    shift_solves=int(stats[3]), res_fro=stats[4], cols=c)
+        return Z, info
+
+    def ric_newtonadi(self, shifts, B, W, prm, Z0=None, oldB=None, fetch=True):
+        B = as_panel(B, self.nv)
+        W = as_panel(W, self.nv)
+        sh = np.ascontiguousarray(shifts, dtype=np.float64)
+        nb, mw = B.shape[1], W.shape[1]
+        Z0 = None if Z0 is None else as_panel(Z0, self.nv)
+        oldB = None if oldB is None else as_panel(oldB, self.nv)
+        cap = prm.adi_max_steps * (mw + nb)
+        Z = np.empty((self.nv, cap)) if fetch else None
+        cc = C.c_int(0)
+        stats = np.zeros(8)
+        _chk(self._lib.ricadi_ric_newtonadi(
+            self._h, _d(sh), sh.size, _d(B), nb, _d(W), mw,
+            None if Z0 is None else _d(Z0), 0 if Z0 is None else Z0.shape[1],
+            None if oldB is None else _d(oldB), C.byref(prm),
+            None if Z is None else _d(Z), cap, C.byref(cc), _d(stats)))
+        c = cc.value
+        if fetch:
+            Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
+        info = dict(nwtn_steps=int(stats[0]), upd_abs=stats[1], upd_rel=stats[2],
+                    adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
+                    shift_solves=int(stats[5]), cols=c)
+        return Z, info
+
+    def compress(self, Z=None, thresh=None, k=None):
+        """``Z=None`` compresses the factor left on the device."""
+        if Z is not None:
+            Z = as_panel(Z, self.nv)
+            c = Z.shape[1]
+        else:
+            cc = C.c_int(0)
+            _chk(self._lib.ricadi_factor_cols(self._h, C.byref(cc)))
+            c = cc.value
+        out = np.empty((self.nv, max(c, 1)))
+        kk = C.c_int(0)
+        sv = np.zeros(max(c, 1))
+        _chk(self._lib.ricadi_compress(self._h, None if Z is None else _d(Z), c,
+                                       -1.0 if thresh is None else float(thresh),
+                                       0 if k is None else int(k), _d(out), C.byref(kk), _d(sv)))
+        kk = kk.value
+        return out.ravel()[:self.nv * kk].reshape(self.nv, kk).copy(), sv[:min(c, self.nv)]
+
+    def gain(self, B, Z=None, MT=None):
+        """``MT (Z (Z^T B))`` with ``MT`` = calE of the context when None."""
+        B = as_panel(B, self.nv)
+        K = np.empty_like(B)
+        if Z is not None:
+            Z = as_panel(Z, self.nv)
+        c = 0 if Z is None else Z.shape[1]
+        if MT is not None:
+            rp, ci, v, sh = as_csr(MT)
+            _chk(self._lib.ricadi_gain(self._h, _i(rp), _i(ci), _d(v),
+                                       None if Z is None else _d(Z), c, _d(B), B.shape[1], _d(K)))
+        else:
+            _chk(self._lib.ricadi_gain(self._h, None, None, None,
+                                       None if Z is None else _d(Z), c, _d(B), B.shape[1], _d(K)))
+        return K
+
+    def lyap_res_norm(self, Z, W):
+        Z = as_panel(Z, self.nv)
+        W = as_panel(W, self.nv)
+        out = C.c_double(0.0)
+        _chk(self._lib.ricadi_lyap_res_norm(self._h, _d(Z), Z.shape[1], _d(W), W.shape[1],
+                                            C.byref(out)))
+        return out.value
+
+    def factor_get(self):
+        cc = C.c_int(0)
+        _chk(self._lib.ricadi_factor_cols(self._h, C.byref(cc)))
+        Z = np.empty((self.nv, cc.value))
+        _chk(self._lib.ricadi_factor_get(self._h, _d(Z), cc.value))
+        return Z
+
+    # -- device-pointer level (torch tensors' data_ptr()) ------------------
+    def spmm_dev(self, alpha, beta, x_ptr, m, y_ptr):
+        _chk(self._lib.ricadi_spmm_dev(self._h, alpha, beta, x_ptr, m, y_ptr))
+
+    def shift_solve_dev(self, alpha, beta, r_ptr, m, x_ptr, strict=True):
+        it = C.c_int(0)
+        rr = np.zeros(m)
+        rc = self._lib.ricadi_shift_solve_dev(self._h, alpha, beta, r_ptr, m, x_ptr,
+                                              C.byref(it), _d(rr))
+        _chk(rc, allow_noconv=not strict)
+        return it.value, rr
+
+    def apply_e_dev(self, coef, v_ptr, m, w_ptr):
+        _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))
+
+    def panel_norms_dev(self, w_ptr, nrows, m):
+        g = C.c_double(0.0)
+        t = C.c_double(0.0)
+        _chk(self._lib.ricadi_panel_norms_dev(self._h, w_ptr, nrows, m, C.byref(g), C.byref(t)))
+        return g.value, t.value
+
+    def time_spmm_dev(self, alpha, beta, x_ptr, m, y_ptr, reps):
+        ms = C.c_double(0.0)
+        _chk(self._lib.ricadi_time_spmm_dev(self._h, alpha, beta, x_ptr, m, y_ptr, reps,
+                                            C.byref(ms)))
+        return ms.value
+
+
+def host_aggregate(pattern, bsize):
+    """Greedy BFS aggregation (host logic of the preconditioner setup)."""
+    rp, ci, _, sh = as_csr(pattern)
+    blk = np.empty(sh[0], dtype=np.int32)
+    nb = load().ricadi_host_aggregate(sh[0], _i(rp), _i(ci), int(bsize), _i(blk))
+    if nb < 0:
+        _chk(nb)
+    return blk, nb
+
+
+def host_cauchy(shifts):
+    """``(R^-1, C^-1 1)`` of the Cauchy matrix of a shift sweep."""
+    sh = np.ascontiguousarray(shifts, dtype=np.float64)
+    g = sh.size
+    rinv = np.empty((g, g))
+    c1 = np.empty(g)
+    _chk(load().ricadi_host_cauchy(_d(sh), g, _d(rinv), _d(c1)))
+    return rinv, c1

@@ -1,0 +1,321 @@
+// ricadi_host.cpp -- host-side setup logic of libricadi_hip.so (no device code).
+//
+// Builds, once per operator, everything of the two-level preconditioner that
+// does not depend on the ADI shift: the unified saddle-point sparsity pattern,
+// the block-Jacobi partitions (greedy graph aggregation), the dense diagonal
+// blocks of cal A and cal E, the aggregation coarse space and its Galerkin
+// matrices.  The per-shift parts are linear combinations formed on the device.
+// Nothing here follows reference code: the reference solves these systems with
+// SuperLU.
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "ricadi_internal.h"
+
+namespace ricadi {
+
+HostCsr make_csr(int nrows, int ncols, const int32_t* rp, const int32_t* ci, const double* v) {
+  HostCsr a;
+  a.nrows = nrows;
+  a.ncols = ncols;
+  a.rp.assign(rp, rp + nrows + 1);
+  const int nnz = rp[nrows];
+  a.ci.assign(ci, ci + nnz);
+  a.v.assign(v, v + nnz);
+  sort_rows(a);
+  return a;
+}
+
+void sort_rows(HostCsr& a) {
+  std::vector<std::pair<int, double>> tmp;
+  for (int i = 0; i < a.nrows; ++i) {
+    const int b = a.rp[i], e = a.rp[i + 1];
+    bool sorted = true;
+    for (int k = b + 1; k < e; ++k)
+      if (a.ci[k] < a.ci[k - 1]) { sorted = false; break; }
+    if (sorted) continue;
+    tmp.clear();
+    for (int k = b; k < e; ++k) tmp.emplace_back(a.ci[k], a.v[k]);
+    std::sort(tmp.begin(), tmp.end(),
+              [](const std::pair<int, double>& x, const std::pair<int, double>& y) {
+                return x.first < y.first;
+              });
+    for (int k = b; k < e; ++k) {
+      a.ci[k] = tmp[k - b].first;
+      a.v[k] = tmp[k - b].second;
+    }
+  }
+}
+
+HostCsr transpose(const HostCsr& a) {
+  HostCsr t;
+  t.nrows = a.ncols;
+  t.ncols = a.nrows;
+  t.rp.assign(t.nrows + 1, 0);
+  for (size_t k = 0; k < a.nnz(); ++k) t.rp[a.ci[k] + 1]++;
+  for (int i = 0; i < t.nrows; ++i) t.rp[i + 1] += t.rp[i];
+  t.ci.resize(a.nnz());
+  t.v.resize(a.nnz());
+  std::vector<int> pos(t.rp.begin(), t.rp.end() - 1);
+  for (int i = 0; i < a.nrows; ++i)
+    for (int k = a.rp[i]; k < a.rp[i + 1]; ++k) {
+      const int d = pos[a.ci[k]]++;
+      t.ci[d] = i;
+      t.v[d] = a.v[k];
+    }
+  return t;
+}
+
+// Greedy BFS aggregation: grow a block from each still-free seed until it holds
+// bsize rows.  Deterministic (seeds in index order, neighbours in CSR order).
+int aggregate(int n, const int* rp, const int* ci, int bsize, int* blk) {
+  if (bsize < 1) bsize = 1;
+  std::fill(blk, blk + n, -1);
+  std::vector<int> members;
+  members.reserve(bsize);
+  int nb = 0;
+  for (int seed = 0; seed < n; ++seed) {
+    if (blk[seed] >= 0) continue;
+    members.clear();
+    members.push_back(seed);
+    blk[seed] = nb;
+    size_t head = 0;
+    while (head < members.size() && (int)members.size() < bsize) {
+      const int u = members[head++];
+      for (int k = rp[u]; k < rp[u + 1] && (int)members.size() < bsize; ++k) {
+        const int v = ci[k];
+        if (v >= 0 && v < n && blk[v] < 0) {
+          blk[v] = nb;
+          members.push_back(v);
+        }
+      }
+    }
+    ++nb;
+  }
+  return nb;
+}
+
+static void lists_from_blocks(int n, const int* blk, int nb, std::vector<int>& ptr,
+                              std::vector<int>& rows) {
+  ptr.assign(nb + 1, 0);
+  for (int i = 0; i < n; ++i) ptr[blk[i] + 1]++;
+  for (int b = 0; b < nb; ++b) ptr[b + 1] += ptr[b];
+  rows.resize(n);
+  std::vector<int> pos(ptr.begin(), ptr.end() - 1);
+  for (int i = 0; i < n; ++i) rows[pos[blk[i]]++] = i;
+}
+
+void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
+                 HostSetup& hs) {
+  const int nv = A.nrows, np = J.nrows, n = nv + np;
+  hs.nv = nv;
+  hs.np = np;
+  hs.n = n;
+  HostCsr JT = transpose(J);
+
+  // ---- unified saddle pattern -------------------------------------------
+  hs.s_rp.assign(n + 1, 0);
+  hs.s_ci.clear();
+  hs.s_srcA.clear();
+  hs.s_srcE.clear();
+  hs.s_srcJ.clear();
+  hs.dA.assign(nv, 0.0);
+  hs.dE.assign(nv, 0.0);
+  // velocity-velocity pattern kept aside for the graph work
+  std::vector<int> vv_rp(nv + 1, 0), vv_ci;
+  for (int i = 0; i < nv; ++i) {
+    int a = A.rp[i], ae = A.rp[i + 1], e = E.rp[i], ee = E.rp[i + 1];
+    while (a < ae || e < ee) {
+      const int ca = a < ae ? A.ci[a] : INT32_MAX;
+      const int ce = e < ee ? E.ci[e] : INT32_MAX;
+      const int c = std::min(ca, ce);
+      double va = 0.0, ve = 0.0;
+      if (ca == c) va = A.v[a++];
+      if (ce == c) ve = E.v[e++];
+      hs.s_ci.push_back(c);
+      hs.s_srcA.push_back(va);
+      hs.s_srcE.push_back(ve);
+      hs.s_srcJ.push_back(0.0);
+      vv_ci.push_back(c);
+      if (c == i) {
+        hs.dA[i] = va;
+        hs.dE[i] = ve;
+      }
+    }
+    vv_rp[i + 1] = (int)vv_ci.size();
+    for (int k = JT.rp[i]; k < JT.rp[i + 1]; ++k) {
+      hs.s_ci.push_back(nv + JT.ci[k]);
+      hs.s_srcA.push_back(0.0);
+      hs.s_srcE.push_back(0.0);
+      hs.s_srcJ.push_back(JT.v[k]);
+    }
+    hs.s_rp[i + 1] = (int)hs.s_ci.size();
+  }
+  for (int k = 0; k < np; ++k) {
+    for (int q = J.rp[k]; q < J.rp[k + 1]; ++q) {
+      hs.s_ci.push_back(J.ci[q]);
+      hs.s_srcA.push_back(0.0);
+      hs.s_srcE.push_back(0.0);
+      hs.s_srcJ.push_back(J.v[q]);
+    }
+    hs.s_rp[nv + k + 1] = (int)hs.s_ci.size();
+  }
+
+  // ---- block-Jacobi partition of the velocity block -----------------------
+  const int bs = (o.bj_block <= 16) ? 16 : (o.bj_block <= 32 ? 32 : 64);
+  hs.bs = bs;
+  std::vector<int> blk(nv);
+  hs.nbv = aggregate(nv, vv_rp.data(), vv_ci.data(), bs, blk.data());
+  lists_from_blocks(nv, blk.data(), hs.nbv, hs.bv_ptr, hs.bv_rows);
+  std::vector<int> local(nv);
+  for (int b = 0; b < hs.nbv; ++b)
+    for (int k = hs.bv_ptr[b]; k < hs.bv_ptr[b + 1]; ++k) local[hs.bv_rows[k]] = k - hs.bv_ptr[b];
+  hs.bv_A.assign((size_t)hs.nbv * bs * bs, 0.0);
+  hs.bv_E.assign((size_t)hs.nbv * bs * bs, 0.0);
+  for (int i = 0; i < nv; ++i) {
+    const int b = blk[i];
+    double* Ba = hs.bv_A.data() + (size_t)b * bs * bs + (size_t)local[i] * bs;
+    double* Be = hs.bv_E.data() + (size_t)b * bs * bs + (size_t)local[i] * bs;
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+      if (blk[A.ci[k]] == b) Ba[local[A.ci[k]]] += A.v[k];
+    for (int k = E.rp[i]; k < E.rp[i + 1]; ++k)
+      if (blk[E.ci[k]] == b) Be[local[E.ci[k]]] += E.v[k];
+  }
+
+  // ---- pressure graph (pattern of J J^T) and its block partition ----------
+  std::vector<int> pp_rp(np + 1, 0), pp_ci;
+  {
+    std::vector<int> mark(np, -1);
+    for (int k = 0; k < np; ++k) {
+      for (int q = J.rp[k]; q < J.rp[k + 1]; ++q) {
+        const int j = J.ci[q];
+        for (int t = JT.rp[j]; t < JT.rp[j + 1]; ++t) {
+          const int k2 = JT.ci[t];
+          if (mark[k2] != k) {
+            mark[k2] = k;
+            pp_ci.push_back(k2);
+          }
+        }
+      }
+      std::sort(pp_ci.begin() + pp_rp[k], pp_ci.end());
+      pp_rp[k + 1] = (int)pp_ci.size();
+    }
+  }
+  std::vector<int> pblk(std::max(np, 1));
+  hs.nbp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), bs, pblk.data()) : 0;
+  lists_from_blocks(np, pblk.data(), hs.nbp, hs.bp_ptr, hs.bp_rows);
+
+  // ---- aggregation coarse space -------------------------------------------
+  hs.kc = hs.kcv = hs.kcp = 0;
+  hs.agg_ptr.assign(1, 0);
+  hs.agg_rows.clear();
+  hs.aggof.assign(n, 0);
+  hs.E0.clear();
+  hs.EM.clear();
+  hs.EJ.clear();
+  if (!o.use_coarse) return;
+  // graph for velocity aggregates: pattern of cal E if it is a genuine
+  // (mass-like) matrix -- keeps the components apart -- else the union pattern
+  const bool e_graph = E.nnz() > (size_t)(2 * nv);
+  const int* g_rp = e_graph ? E.rp.data() : vv_rp.data();
+  const int* g_ci = e_graph ? E.ci.data() : vv_ci.data();
+  int av = std::max(1, o.agg_v), ap = std::max(1, o.agg_p);
+  std::vector<int> va(nv), pa(std::max(np, 1));
+  int kv = 0, kp = 0;
+  for (int attempt = 0; attempt < 16; ++attempt) {
+    kv = aggregate(nv, g_rp, g_ci, av, va.data());
+    kp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), ap, pa.data()) : 0;
+    if (kv + kp <= std::max(16, o.coarse_max)) break;
+    av *= 2;
+    ap *= 2;
+  }
+  hs.kcv = kv;
+  hs.kcp = kp;
+  hs.kc = kv + kp;
+  const int kc = hs.kc;
+  for (int i = 0; i < nv; ++i) hs.aggof[i] = va[i];
+  for (int k = 0; k < np; ++k) hs.aggof[nv + k] = kv + pa[k];
+  lists_from_blocks(n, hs.aggof.data(), kc, hs.agg_ptr, hs.agg_rows);
+  hs.E0.assign((size_t)kc * kc, 0.0);
+  hs.EM.assign((size_t)kc * kc, 0.0);
+  hs.EJ.assign((size_t)kc * kc, 0.0);
+  for (int i = 0; i < nv; ++i) {
+    const size_t ra = (size_t)va[i] * kc;
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) hs.E0[ra + va[A.ci[k]]] += A.v[k];
+    for (int k = E.rp[i]; k < E.rp[i + 1]; ++k) hs.EM[ra + va[E.ci[k]]] += E.v[k];
+  }
+  for (int k = 0; k < np; ++k)
+    for (int q = J.rp[k]; q < J.rp[k + 1]; ++q) {
+      const int cp = kv + pa[k], cv = va[J.ci[q]];
+      hs.EJ[(size_t)cp * kc + cv] += J.v[q];
+      hs.EJ[(size_t)cv * kc + cp] += J.v[q];
+    }
+}
+
+// Cauchy data of one shift-parallel ADI sweep:
+//   C_ij = -1/(p_i + p_j)  (s.p.d. for distinct negative real shifts),
+//   C = R^T R;  rinv = R^-1 (upper, row-major);  cinv1 = C^-1 * ones.
+int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1) {
+  if (g < 1) return RICADI_EINVAL;
+  std::vector<double> L((size_t)g * g, 0.0);  // lower Cholesky factor, C = L L^T
+  for (int i = 0; i < g; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = -1.0 / (shifts[i] + shifts[j]);
+      for (int k = 0; k < j; ++k) s -= L[(size_t)i * g + k] * L[(size_t)j * g + k];
+      if (i == j) {
+        if (!(s > 0.0)) return RICADI_EBREAKDOWN;
+        L[(size_t)i * g + i] = std::sqrt(s);
+      } else {
+        L[(size_t)i * g + j] = s / L[(size_t)j * g + j];
+      }
+    }
+  // Linv (lower): solve L * Linv = I
+  std::vector<double> Li((size_t)g * g, 0.0);
+  for (int c = 0; c < g; ++c)
+    for (int i = c; i < g; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[(size_t)i * g + k] * Li[(size_t)k * g + c];
+      Li[(size_t)i * g + c] = s / L[(size_t)i * g + i];
+    }
+  // R = L^T  =>  R^-1 = Linv^T
+  for (int i = 0; i < g; ++i)
+    for (int j = 0; j < g; ++j) rinv[(size_t)i * g + j] = Li[(size_t)j * g + i];
+  // C^-1 1 = Linv^T (Linv 1)
+  std::vector<double> t(g, 0.0);
+  for (int i = 0; i < g; ++i)
+    for (int j = 0; j <= i; ++j) t[i] += Li[(size_t)i * g + j];
+  for (int i = 0; i < g; ++i) {
+    double s = 0.0;
+    for (int k = i; k < g; ++k) s += Li[(size_t)k * g + i] * t[k];
+    cinv1[i] = s;
+  }
+  return RICADI_OK;
+}
+
+}  // namespace ricadi
+
+extern "C" {
+
+int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col, int bsize,
+                          int32_t* blk_out) {
+  if (n < 0 || !rowptr || !col || !blk_out) {
+    ricadi::set_error("ricadi_host_aggregate: bad argument");
+    return RICADI_EINVAL;
+  }
+  return ricadi::aggregate(n, rowptr, col, bsize, blk_out);
+}
+
+int ricadi_host_cauchy(const double* shifts, int g, double* rinv_out, double* cinv1_out) {
+  if (!shifts || !rinv_out || !cinv1_out) {
+    ricadi::set_error("ricadi_host_cauchy: bad argument");
+    return RICADI_EINVAL;
+  }
+  int rc = ricadi::cauchy_data(shifts, g, rinv_out, cinv1_out);
+  if (rc == RICADI_EBREAKDOWN)
+    ricadi::set_error("ricadi_host_cauchy: Cauchy matrix not positive definite "
+                      "(shifts must be distinct, negative and few)");
+  return rc;
+}
+
+}  // extern "C"

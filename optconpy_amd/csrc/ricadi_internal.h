@@ -1,0 +1,111 @@
+// ricadi_internal.h -- shared declarations of libricadi_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ricadi.h"
+
+#define RICADI_MAX_M 128
+
+namespace ricadi {
+
+// ---- host-side CSR helper --------------------------------------------------
+struct HostCsr {
+  int nrows = 0, ncols = 0;
+  std::vector<int> rp, ci;
+  std::vector<double> v;
+  size_t nnz() const { return ci.size(); }
+};
+HostCsr make_csr(int nrows, int ncols, const int32_t* rp, const int32_t* ci, const double* v);
+HostCsr transpose(const HostCsr& a);
+void sort_rows(HostCsr& a);
+
+int aggregate(int n, const int* rp, const int* ci, int bsize, int* blk);
+
+// Host-built description of the saddle operator and the two-level
+// preconditioner's fixed (shift independent) parts.
+struct HostSetup {
+  int nv = 0, np = 0, n = 0;
+  // unified saddle pattern, three value sources
+  std::vector<int> s_rp, s_ci;
+  std::vector<double> s_srcA, s_srcE, s_srcJ;
+  // diagonals of A and E
+  std::vector<double> dA, dE;
+  // block-Jacobi, velocity block
+  int bs = 32;
+  int nbv = 0;
+  std::vector<int> bv_ptr, bv_rows;
+  std::vector<double> bv_A, bv_E;  // nbv x bs x bs
+  // block-Jacobi, Schur complement
+  int nbp = 0;
+  std::vector<int> bp_ptr, bp_rows;  // rows are pressure-local (0..np)
+  // coarse level
+  int kc = 0, kcv = 0, kcp = 0;
+  std::vector<int> agg_ptr, agg_rows;  // aggregates over all n dofs
+  std::vector<int> aggof;              // n -> coarse index
+  std::vector<double> E0, EM, EJ;      // kc x kc dense
+};
+void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
+                 HostSetup& hs);
+int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
+
+// ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
+void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
+                 const double* x, int ldx, const int* xmap, double* y, int ldy, const double* r,
+                 int ldr, double alpha, double beta_r, const double* rowscale, int m);
+void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const double* srcE,
+                           const double* srcJ, double alpha, double beta, double* out);
+void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, double alpha,
+                     double beta, double* out);
+void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y);
+void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
+                     double b, double* y);
+void launch_copy_cols(hipStream_t st, int nrows, int w, const double* src, int lds_, int sc0,
+                      double* dst, int ldd, int dc0, double scale);
+int dots_num_blocks(int nrows);
+void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                      size_t vstride, const double* w, int want_self, double* partial,
+                      double* out);
+void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                        size_t vstride, const double* h, double sign, const double* w,
+                        const double* scale, double* out);
+void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
+                       const double* h2, double* H, double* cs, double* sn, double* g,
+                       double* scale, double* resid, const double* bnorm, double tol);
+void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
+                            const double* g, double* y);
+void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
+                        double* scale, double* resid);
+void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
+                        const double* inv, const double* in, int ldi, double* out, int ldo, int m);
+void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const double* Be,
+                          double alpha, double beta, double* out);
+void launch_schur_blocks(hipStream_t st, int nblocks, int bs, const int* bptr, const int* rows,
+                         const int* jrp, const int* jci, const double* jv, const double* dinv,
+                         double* blocks);
+void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
+                         int* flag);
+void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows, const double* in,
+                     int ldi, double* rc, int m);
+void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
+                        double* ec);
+void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, const double* ec,
+                        double* z);
+void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
+                    int ldb, double* C, int ldc);
+void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
+                    int ldc, double* Y, int ldy, double alpha, double beta);
+void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
+                     const double* a2, double alpha, double beta, double* out);
+void launch_set_identity(hipStream_t st, int k, double* out);
+
+void set_error(const std::string& msg);
+
+}  // namespace ricadi

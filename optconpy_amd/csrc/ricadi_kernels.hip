@@ -1,0 +1,793 @@
+// ricadi_kernels.hip -- CDNA4 (gfx950) kernels of the Newton-ADI hot path.
+//
+// Everything here is new code: the reference (/root/reference) has no native or
+// GPU source at all; the kernels implement the list
+// K1..K6 of SURVEY.md section 8(a).
+//
+// Layout rules shared by all kernels
+//   * dense panels are row-major n x m, one row = m contiguous doubles
+//     (m = 16 -> one 128-B line per row: an indexed row gather is a full line);
+//   * a wavefront (64 lanes) is split into 16-lane groups; a group owns one
+//     matrix row and its lanes own the panel columns g, g+16, ...;
+//   * reductions over rows are two-stage (per-workgroup partials, then a small
+//     reduce kernel), so results are bitwise reproducible run to run.
+#include "ricadi_internal.h"
+
+namespace ricadi {
+
+// ---------------------------------------------------------------------------
+// K1: CSR SpMM on row-major panels.
+//   y[i,:] = beta_r * r[i,:] + alpha * rowscale[i] * sum_k val[k] * x[xrow(col[k]),:]
+// xmap (optional) redirects the gathered row (used to apply S to a prolongated
+// coarse vector without materialising it).  One 16-lane group per row; the
+// (col,val) loads are group-uniform (one request), the x-row load is one
+// coalesced 128-B line per 16 columns.
+// ---------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(256) void spmm_kernel(
+    int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
+    const double* __restrict__ val, const double* __restrict__ x, int ldx,
+    const int* __restrict__ xmap, double* __restrict__ y, int ldy,
+    const double* __restrict__ r, int ldr, double alpha, double beta_r,
+    const double* __restrict__ rowscale, int m) {
+  const int g = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= nrows) return;
+  double acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
+  const int k0 = rp[row], k1 = rp[row + 1];
+  int k = k0;
+  for (; k + 1 < k1; k += 2) {
+    int c0 = ci[k], c1 = ci[k + 1];
+    const double v0 = val[k], v1 = val[k + 1];
+    if (xmap) { c0 = xmap[c0]; c1 = xmap[c1]; }
+    const double* x0 = x + (size_t)c0 * ldx;
+    const double* x1 = x + (size_t)c1 * ldx;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = g + 16 * c;
+      if (col < m) {
+        acc[c] = fma(v0, x0[col], acc[c]);
+        acc[c] = fma(v1, x1[col], acc[c]);
+      }
+    }
+  }
+  if (k < k1) {
+    int c0 = ci[k];
+    const double v0 = val[k];
+    if (xmap) c0 = xmap[c0];
+    const double* x0 = x + (size_t)c0 * ldx;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const int col = g + 16 * c;
+      if (col < m) acc[c] = fma(v0, x0[col], acc[c]);
+    }
+  }
+  const double sc = alpha * (rowscale ? rowscale[row] : 1.0);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = g + 16 * c;
+    if (col < m) {
+      double out = sc * acc[c];
+      if (r) out += beta_r * r[(size_t)row * ldr + col];
+      y[(size_t)row * ldy + col] = out;
+    }
+  }
+}
+
+void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
+                 const double* x, int ldx, const int* xmap, double* y, int ldy,
+                 const double* r, int ldr, double alpha, double beta_r,
+                 const double* rowscale, int m) {
+  if (nrows <= 0 || m <= 0) return;
+  dim3 grid((nrows + 15) / 16), block(256);
+  const int cpl = (m + 15) / 16;
+#define RICADI_SPMM_CASE(C)                                                              \
+  case C:                                                                                \
+    hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, nrows, rp, ci, val, x, ldx,   \
+                       xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);                \
+    break;
+  switch (cpl) {
+    RICADI_SPMM_CASE(1)
+    RICADI_SPMM_CASE(2)
+    RICADI_SPMM_CASE(3)
+    RICADI_SPMM_CASE(4)
+    RICADI_SPMM_CASE(5)
+    RICADI_SPMM_CASE(6)
+    RICADI_SPMM_CASE(7)
+    RICADI_SPMM_CASE(8)
+    default:
+      break;  // m <= RICADI_MAX_M = 128 is enforced by the callers
+  }
+#undef RICADI_SPMM_CASE
+}
+
+// S_val = alpha * srcE + beta * srcA + srcJ on the unified saddle pattern.
+__global__ void assemble_shift_kernel(int nnz, const double* __restrict__ srcA,
+                                      const double* __restrict__ srcE,
+                                      const double* __restrict__ srcJ, double alpha,
+                                      double beta, double* __restrict__ out) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x)
+    out[k] = alpha * srcE[k] + beta * srcA[k] + srcJ[k];
+}
+void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const double* srcE,
+                           const double* srcJ, double alpha, double beta, double* out) {
+  int grid = std::min((nnz + 255) / 256, 2048);
+  hipLaunchKernelGGL(assemble_shift_kernel, dim3(grid), dim3(256), 0, st, nnz, srcA, srcE, srcJ,
+                     alpha, beta, out);
+}
+
+// out[i] = 1 / (alpha*dE[i] + beta*dA[i])
+__global__ void diag_inv_kernel(int n, const double* dA, const double* dE, double alpha,
+                                double beta, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0 / (alpha * dE[i] + beta * dA[i]);
+}
+void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, double alpha,
+                     double beta, double* out) {
+  hipLaunchKernelGGL(diag_inv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dA, dE, alpha,
+                     beta, out);
+}
+
+// ---------------------------------------------------------------------------
+// elementwise panel helpers (K4)
+// ---------------------------------------------------------------------------
+__global__ void axpby_kernel(size_t n, double a, const double* __restrict__ x, double b,
+                             double* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y) {
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, st, n, a, x, b, y);
+}
+
+// y[r, c] = a[c] * x[r, c] + b * y[r, c]   (per-column scale, contiguous panel)
+__global__ void colscale_kernel(size_t n, int m, const double* __restrict__ a,
+                                const double* __restrict__ x, double b, double* __restrict__ y) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    y[i] = a[i % m] * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+}
+void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
+                     double b, double* y) {
+  size_t n = nrows * m;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(colscale_kernel, dim3(grid), dim3(256), 0, st, n, m, a, x, b, y);
+}
+
+// copy a strided block of columns: dst[r, dc0 + c] = scale * src[r, sc0 + c], c < w
+__global__ void copy_cols_kernel(int nrows, int w, const double* __restrict__ src, int lds_,
+                                 int sc0, double* __restrict__ dst, int ldd, int dc0,
+                                 double scale) {
+  size_t n = (size_t)nrows * w;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i / w;
+    int c = (int)(i % w);
+    dst[r * ldd + dc0 + c] = scale * src[r * lds_ + sc0 + c];
+  }
+}
+void launch_copy_cols(hipStream_t st, int nrows, int w, const double* src, int lds_, int sc0,
+                      double* dst, int ldd, int dc0, double scale) {
+  size_t n = (size_t)nrows * w;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid), dim3(256), 0, st, nrows, w, src, lds_, sc0, dst,
+                     ldd, dc0, scale);
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-column Krylov orthogonalisation.
+//
+// cols_dots: partial[blk][i][c] = sum_{r in chunk} V_i[r,c] * w[r,c]  for
+// i < nvec (vector nvec, if want_self, is w itself -> ||w||^2 per column).
+// The w chunk is staged in LDS once and re-used against every basis panel
+// (the "LDS-staged Krylov panel"); a thread owns one (i, c) output, the 16
+// lanes of a group read one contiguous row of V_i, so no cross-lane reduction
+// is needed at all.  A second kernel sums the partials over workgroups.
+// ---------------------------------------------------------------------------
+constexpr int DOT_ROWS = 64;
+
+__global__ __launch_bounds__(256) void cols_dots_kernel(
+    int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    const double* __restrict__ w, int want_self, double* __restrict__ partial) {
+  extern __shared__ double wl[];  // DOT_ROWS x m
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  for (int e = threadIdx.x; e < nr * m; e += blockDim.x) wl[e] = w[(size_t)r0 * m + e];
+  __syncthreads();
+  const int ntot = nvec + (want_self ? 1 : 0);
+  const int nout = ntot * m;
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    const int i = o / m, c = o - i * m;
+    const double* v = (i < nvec) ? basis + (size_t)i * vstride + (size_t)r0 * m + c
+                                 : w + (size_t)r0 * m + c;
+    double s0 = 0.0, s1 = 0.0;
+    int r = 0;
+    for (; r + 1 < nr; r += 2) {
+      s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
+      s1 = fma(v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+    }
+    if (r < nr) s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
+    partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
+  }
+}
+
+// out[o] (+)= sum_b partial[b][o]
+__global__ void reduce_partials_kernel(int nblk, int nout, const double* __restrict__ partial,
+                                       double* __restrict__ out, int accumulate) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nout) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * nout + o];
+  out[o] = accumulate ? out[o] + s : s;
+}
+
+int dots_num_blocks(int nrows) { return (nrows + DOT_ROWS - 1) / DOT_ROWS; }
+
+void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                      size_t vstride, const double* w, int want_self, double* partial,
+                      double* out) {
+  const int nblk = dots_num_blocks(nrows);
+  const int nout = (nvec + (want_self ? 1 : 0)) * m;
+  if (nout == 0) return;
+  hipLaunchKernelGGL(cols_dots_kernel, dim3(nblk), dim3(256), DOT_ROWS * m * sizeof(double), st,
+                     nrows, m, nvec, basis, vstride, w, want_self, partial);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 127) / 128), dim3(128), 0, st, nblk,
+                     nout, partial, out, 0);
+}
+
+// out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
+// (scale may be NULL = 1; w may be NULL = 0).  Streams nvec panels once.
+__global__ __launch_bounds__(256) void cols_update_kernel(
+    size_t nelem, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    const double* __restrict__ h, double sign, const double* __restrict__ w,
+    const double* __restrict__ scale, double* __restrict__ out) {
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nelem;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % m);
+    double s0 = 0.0, s1 = 0.0;
+    int i = 0;
+    for (; i + 1 < nvec; i += 2) {
+      s0 = fma(h[i * m + c], basis[(size_t)i * vstride + e], s0);
+      s1 = fma(h[(i + 1) * m + c], basis[(size_t)(i + 1) * vstride + e], s1);
+    }
+    if (i < nvec) s0 = fma(h[i * m + c], basis[(size_t)i * vstride + e], s0);
+    double v = (w ? w[e] : 0.0) + sign * (s0 + s1);
+    if (scale) v *= scale[c];
+    out[e] = v;
+  }
+}
+void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                        size_t vstride, const double* h, double sign, const double* w,
+                        const double* scale, double* out) {
+  size_t nelem = (size_t)nrows * m;
+  if (!nelem) return;
+  int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
+  hipLaunchKernelGGL(cols_update_kernel, dim3(grid), dim3(256), 0, st, nelem, m, nvec, basis,
+                     vstride, h, sign, w, scale, out);
+}
+
+// ---------------------------------------------------------------------------
+// GMRES small per-column kernels (one thread per panel column).
+//   state layout (all device, per column c):
+//     H   [c][j][i]   (restart+1) x restart upper Hessenberg -> R after rotations
+//     cs,sn [c][i],  g [c][i]
+// hess_update: consumes h1 (pass 1), h2 (pass 2 incl. ||w'||^2 as last row),
+// applies the stored rotations, creates the new one, writes scale = 1/h_{j+1,j}
+// (0 on breakdown / frozen column) and the residual estimate |g_{j+1}|.
+// ---------------------------------------------------------------------------
+__global__ void gmres_hess_kernel(int m, int j, int restart, const double* __restrict__ h1,
+                                  const double* __restrict__ h2, double* __restrict__ H,
+                                  double* __restrict__ cs, double* __restrict__ sn,
+                                  double* __restrict__ g, double* __restrict__ scale,
+                                  double* __restrict__ resid, const double* __restrict__ bnorm,
+                                  double tol) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  double* Hc = H + (size_t)c * (restart + 1) * restart + (size_t)j * (restart + 1);
+  double* csc = cs + (size_t)c * restart;
+  double* snc = sn + (size_t)c * restart;
+  double* gc = g + (size_t)c * (restart + 1);
+  const int nv = j + 1;
+  double h2sq = 0.0;
+  for (int i = 0; i < nv; ++i) {
+    const double b = h2[i * m + c];
+    h2sq += b * b;
+    Hc[i] = h1[i * m + c] + b;
+  }
+  const double ww = h2[nv * m + c];  // ||w'||^2 before the second projection
+  double hn2 = ww - h2sq;
+  double hnext = hn2 > 0.0 ? sqrt(hn2) : 0.0;
+  // frozen column (already converged, or exact breakdown): keep it inert
+  const double tiny = 1e-300;
+  const bool dead = !(hnext > tiny) || (fabs(gc[j]) <= 0.01 * tol * bnorm[c]);
+  if (dead) hnext = 0.0;
+  for (int i = 0; i < j; ++i) {
+    const double t = csc[i] * Hc[i] + snc[i] * Hc[i + 1];
+    Hc[i + 1] = -snc[i] * Hc[i] + csc[i] * Hc[i + 1];
+    Hc[i] = t;
+  }
+  const double d = hypot(Hc[j], hnext);
+  double cj = 1.0, sj = 0.0;
+  if (d > tiny) { cj = Hc[j] / d; sj = hnext / d; }
+  csc[j] = cj;
+  snc[j] = sj;
+  Hc[j] = (d > tiny) ? d : 1.0;  // keep R non-singular for frozen columns
+  Hc[j + 1] = 0.0;
+  if (d > tiny) {
+    gc[j + 1] = -sj * gc[j];
+    gc[j] = cj * gc[j];
+  } else {
+    gc[j + 1] = 0.0;
+    gc[j] = 0.0;
+  }
+  scale[c] = (hnext > tiny) ? 1.0 / hnext : 0.0;
+  resid[c] = fabs(gc[j + 1]);
+}
+void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
+                       const double* h2, double* H, double* cs, double* sn, double* g,
+                       double* scale, double* resid, const double* bnorm, double tol) {
+  hipLaunchKernelGGL(gmres_hess_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, j, restart, h1,
+                     h2, H, cs, sn, g, scale, resid, bnorm, tol);
+}
+
+// y[i*m + c] solves R y = g for the k x k triangle of column c.
+__global__ void gmres_backsolve_kernel(int m, int k, int restart, const double* __restrict__ H,
+                                       const double* __restrict__ g, double* __restrict__ y) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  const double* Hc = H + (size_t)c * (restart + 1) * restart;
+  const double* gc = g + (size_t)c * (restart + 1);
+  for (int i = k - 1; i >= 0; --i) {
+    double s = gc[i];
+    for (int l = i + 1; l < k; ++l) s -= Hc[(size_t)l * (restart + 1) + i] * y[l * m + c];
+    y[i * m + c] = s / Hc[(size_t)i * (restart + 1) + i];
+  }
+}
+void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
+                            const double* g, double* y) {
+  hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, k, restart,
+                     H, g, y);
+}
+
+// start of a cycle: beta[c] = sqrt(nrm2[c]); g = [beta, 0...]; scale = 1/beta
+__global__ void gmres_start_kernel(int m, int restart, const double* __restrict__ nrm2,
+                                   double* __restrict__ g, double* __restrict__ scale,
+                                   double* __restrict__ resid) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  const double b = sqrt(fmax(nrm2[c], 0.0));
+  double* gc = g + (size_t)c * (restart + 1);
+  for (int i = 0; i <= restart; ++i) gc[i] = 0.0;
+  gc[0] = b;
+  scale[c] = b > 1e-300 ? 1.0 / b : 0.0;
+  resid[c] = b;
+}
+void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
+                        double* scale, double* resid) {
+  hipLaunchKernelGGL(gmres_start_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, restart, nrm2, g,
+                     scale, resid);
+}
+
+// ---------------------------------------------------------------------------
+// K2: block-Jacobi.  Blocks are BS x BS dense inverses (padded with identity),
+// members listed in `rows`.  One wave per block: lane (s, c) = (lane>>4,
+// lane&15) holds the block's input column c in registers and produces the
+// output rows s, s+4, ...
+//   out[rows[il], :] = sum_jl inv[b][il][jl] * in[rows[jl], :]
+// ---------------------------------------------------------------------------
+template <int BS>
+__global__ __launch_bounds__(256) void block_apply_kernel(
+    int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
+    const double* __restrict__ inv, const double* __restrict__ in, int ldi,
+    double* __restrict__ out, int ldo, int m) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= nblocks) return;
+  const int lane = threadIdx.x & 63;
+  const int s = lane >> 4, g = lane & 15;
+  const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
+  const double* Bi = inv + (size_t)wave * BS * BS;
+  for (int cc = g; cc < m; cc += 16) {
+    double xin[BS];
+#pragma unroll
+    for (int jl = 0; jl < BS; ++jl)
+      xin[jl] = (jl < nb) ? in[(size_t)rows[b0 + jl] * ldi + cc] : 0.0;
+    for (int il = s; il < nb; il += 4) {
+      const double* bi = Bi + il * BS;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int jl = 0; jl < BS; jl += 2) {
+        a0 = fma(bi[jl], xin[jl], a0);
+        a1 = fma(bi[jl + 1], xin[jl + 1], a1);
+      }
+      out[(size_t)rows[b0 + il] * ldo + cc] = a0 + a1;
+    }
+  }
+}
+void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
+                        const double* inv, const double* in, int ldi, double* out, int ldo,
+                        int m) {
+  if (nblocks <= 0) return;
+  dim3 grid((nblocks + 3) / 4), block(256);
+  switch (bs) {
+    case 16:
+      hipLaunchKernelGGL(block_apply_kernel<16>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
+                         ldi, out, ldo, m);
+      break;
+    case 32:
+      hipLaunchKernelGGL(block_apply_kernel<32>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
+                         ldi, out, ldo, m);
+      break;
+    default:
+      hipLaunchKernelGGL(block_apply_kernel<64>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
+                         ldi, out, ldo, m);
+      break;
+  }
+}
+
+// blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)
+__global__ void block_combine_kernel(size_t n, const double* Ba, const double* Be, double alpha,
+                                     double beta, double* out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = alpha * Be[i] + beta * Ba[i];
+}
+void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const double* Be,
+                          double alpha, double beta, double* out) {
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(block_combine_kernel, dim3(grid), dim3(256), 0, st, n, Ba, Be, alpha, beta,
+                     out);
+}
+
+// Diagonal blocks of the SIMPLE Schur complement  J * Dinv * J^T : entry (il,kl)
+// of block b = sparse dot of J rows (sorted columns) weighted by Dinv.
+__global__ void schur_blocks_kernel(int nblocks, int bs, const int* __restrict__ bptr,
+                                    const int* __restrict__ rows, const int* __restrict__ jrp,
+                                    const int* __restrict__ jci, const double* __restrict__ jv,
+                                    const double* __restrict__ dinv, double* __restrict__ blocks) {
+  const int b = blockIdx.x;
+  const int b0 = bptr[b], nb = bptr[b + 1] - b0;
+  double* Bb = blocks + (size_t)b * bs * bs;
+  for (int e = threadIdx.x; e < bs * bs; e += blockDim.x) {
+    const int il = e / bs, kl = e - il * bs;
+    double s = 0.0;
+    if (il < nb && kl < nb) {
+      const int ri = rows[b0 + il], rk = rows[b0 + kl];
+      int a = jrp[ri], ae = jrp[ri + 1], c = jrp[rk], ce = jrp[rk + 1];
+      while (a < ae && c < ce) {
+        const int ca = jci[a], cc = jci[c];
+        if (ca == cc) {
+          s = fma(jv[a] * dinv[ca], jv[c], s);
+          ++a;
+          ++c;
+        } else if (ca < cc) {
+          ++a;
+        } else {
+          ++c;
+        }
+      }
+    } else if (il == kl) {
+      s = 1.0;
+    }
+    Bb[e] = s;
+  }
+}
+void launch_schur_blocks(hipStream_t st, int nblocks, int bs, const int* bptr, const int* rows,
+                         const int* jrp, const int* jci, const double* jv, const double* dinv,
+                         double* blocks) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(schur_blocks_kernel, dim3(nblocks), dim3(256), 0, st, nblocks, bs, bptr, rows,
+                     jrp, jci, jv, dinv, blocks);
+}
+
+// In-place inverse of dense bs x bs blocks by Gauss-Jordan with partial
+// pivoting in LDS; one workgroup per block.  flag[0] is set to 1 on a zero pivot.
+__global__ __launch_bounds__(256) void block_invert_kernel(int bs, const int* __restrict__ bptr,
+                                                           double* __restrict__ blocks,
+                                                           int* __restrict__ flag) {
+  extern __shared__ double sm[];  // bs x (2*bs) augmented matrix
+  __shared__ int piv;
+  __shared__ double pivval;
+  const int W = 2 * bs;
+  double* Bb = blocks + (size_t)blockIdx.x * bs * bs;
+  // rows / columns beyond the block's true size are identity padding
+  const int nb = bptr ? bptr[blockIdx.x + 1] - bptr[blockIdx.x] : bs;
+  for (int e = threadIdx.x; e < bs * W; e += blockDim.x) {
+    const int i = e / W, j = e - i * W;
+    double v;
+    if (j < bs)
+      v = (i < nb && j < nb) ? Bb[i * bs + j] : (i == j ? 1.0 : 0.0);
+    else
+      v = ((j - bs) == i) ? 1.0 : 0.0;
+    sm[e] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < bs; ++k) {
+    if (threadIdx.x == 0) {
+      int p = k;
+      double best = fabs(sm[k * W + k]);
+      for (int i = k + 1; i < bs; ++i) {
+        const double v = fabs(sm[i * W + k]);
+        if (v > best) { best = v; p = i; }
+      }
+      piv = p;
+      pivval = sm[p * W + k];
+      if (!(best > 0.0)) { flag[0] = 1; pivval = 1.0; }
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k) {
+      for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        const double t = sm[k * W + j];
+        sm[k * W + j] = sm[p * W + j];
+        sm[p * W + j] = t;
+      }
+    }
+    __syncthreads();
+    const double ipv = 1.0 / pivval;
+    for (int j = threadIdx.x; j < W; j += blockDim.x) sm[k * W + j] *= ipv;
+    __syncthreads();
+    for (int e = threadIdx.x; e < bs * W; e += blockDim.x) {
+      const int i = e / W, j = e - i * W;
+      if (i != k && j != k) sm[e] -= sm[i * W + k] * sm[k * W + j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bs; i += blockDim.x)
+      if (i != k) sm[i * W + k] = 0.0;
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < bs * bs; e += blockDim.x) {
+    const int i = e / bs, j = e - i * bs;
+    Bb[e] = sm[i * W + bs + j];
+  }
+}
+void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
+                         int* flag) {
+  if (nblocks <= 0) return;
+  hipLaunchKernelGGL(block_invert_kernel, dim3(nblocks), dim3(256),
+                     (size_t)bs * 2 * bs * sizeof(double), st, bs, bptr, blocks, flag);
+}
+
+// ---------------------------------------------------------------------------
+// coarse level: restriction (aggregate sums), dense apply, prolongation-add
+// ---------------------------------------------------------------------------
+// rc[a, :] = sum_{r in aggregate a} in[r, :]   (one 16-lane group per aggregate)
+__global__ __launch_bounds__(256) void restrict_kernel(int nagg, const int* __restrict__ aptr,
+                                                       const int* __restrict__ arows,
+                                                       const double* __restrict__ in, int ldi,
+                                                       double* __restrict__ rc, int m) {
+  const int a = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (a >= nagg) return;
+  const int g = threadIdx.x & 15;
+  const int r0 = aptr[a], r1 = aptr[a + 1];
+  for (int c = g; c < m; c += 16) {
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) s += in[(size_t)arows[r] * ldi + c];
+    rc[(size_t)a * m + c] = s;
+  }
+}
+void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows, const double* in,
+                     int ldi, double* rc, int m) {
+  if (nagg <= 0) return;
+  hipLaunchKernelGGL(restrict_kernel, dim3((nagg + 15) / 16), dim3(256), 0, st, nagg, aptr, arows,
+                     in, ldi, rc, m);
+}
+
+// ec = Einv (k x k, row-major) * rc (k x m).  One wave per output row and
+// 16-column chunk; lanes run along the row of Einv (coalesced), 16 register
+// accumulators, butterfly reduction at the end.
+__global__ __launch_bounds__(256) void dense_apply_kernel(int k, int m,
+                                                          const double* __restrict__ Einv,
+                                                          const double* __restrict__ rc,
+                                                          double* __restrict__ ec) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nchunk = (m + 15) / 16;
+  if (wave >= k * nchunk) return;
+  const int i = wave / nchunk, c0 = (wave - i * nchunk) * 16;
+  const int mc = min(16, m - c0);
+  double acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.0;
+  const double* Ei = Einv + (size_t)i * k;
+  for (int j = lane; j < k; j += 64) {
+    const double e = Ei[j];
+    const double* rj = rc + (size_t)j * m + c0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (t < mc) acc[t] = fma(e, rj[t], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    double v = acc[t];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[t] = v;
+  }
+  if (lane == 0)
+    for (int t = 0; t < mc; ++t) ec[(size_t)i * m + c0 + t] = acc[t];
+}
+void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
+                        double* ec) {
+  if (k <= 0) return;
+  const int nwaves = k * ((m + 15) / 16);
+  hipLaunchKernelGGL(dense_apply_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, st, k, m, Einv, rc,
+                     ec);
+}
+
+// z[r, :] += ec[aggof[r], :]
+__global__ void prolong_add_kernel(int nrows, int m, const int* __restrict__ aggof,
+                                   const double* __restrict__ ec, double* __restrict__ z) {
+  size_t n = (size_t)nrows * m;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = e / m;
+    const int c = (int)(e - r * m);
+    z[e] += ec[(size_t)aggof[r] * m + c];
+  }
+}
+void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, const double* ec,
+                        double* z) {
+  size_t n = (size_t)nrows * m;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(prolong_add_kernel, dim3(grid), dim3(256), 0, st, nrows, m, aggof, ec, z);
+}
+
+// ---------------------------------------------------------------------------
+// K5/K6: dense tall-skinny products on the FP64 matrix cores.
+//   v_mfma_f64_16x16x4_f64: lane l holds A[i = l&15][k = l>>4] and
+//   B[k = l>>4][j = l&15]; D[row = (l>>4) + 4*reg][col = l&15].
+//
+// gemm_tn:  C (p x q) += A^T B, A n x p, B n x q (row-major).  Both operands
+// are read as 4-row x 16-column slabs -> each 16-lane group reads one 128-B
+// line.  A wave owns TI x TJ tiles of C over a row range; partial results are
+// added with FP64 atomics (C must be zeroed by the caller).
+// ---------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
+                                                      const double* __restrict__ A, int lda,
+                                                      const double* __restrict__ B, int ldb,
+                                                      double* __restrict__ C, int ldc,
+                                                      int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_blk = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 16 * TI;
+  const int j0 = blockIdx.z * 16 * TJ;
+  const int rbeg = (blockIdx.x * 4 + wave_in_blk) * rows_per_wave;
+  const int rend = min(n, rbeg + rows_per_wave);
+  if (rbeg >= n) return;
+  const int lc = lane & 15, lk = lane >> 4;
+  d4 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int r = rbeg; r < rend; r += 4) {
+    const int rr = r + lk;
+    const bool rok = rr < rend;
+    double af[TI], bf[TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a) {
+      const int col = i0 + 16 * a + lc;
+      af[a] = (rok && col < p) ? A[(size_t)rr * lda + col] : 0.0;
+    }
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int col = j0 + 16 * b + lc;
+      bf[b] = (rok && col < q) ? B[(size_t)rr * ldb + col] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < TI; ++a)
+#pragma unroll
+    for (int b = 0; b < TJ; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i0 + 16 * a + lk + 4 * e;
+        const int col = j0 + 16 * b + lc;
+        if (row < p && col < q) atomicAdd(&C[(size_t)row * ldc + col], acc[a][b][e]);
+      }
+}
+void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
+                    int ldb, double* C, int ldc) {
+  if (n <= 0 || p <= 0 || q <= 0) return;
+  // enough row slices to fill the chip, at least 64 rows each
+  const int tiles = ((p + 31) / 32) * ((q + 31) / 32);
+  int slices = std::max(1, std::min((n + 63) / 64, std::max(1, 4096 / std::max(1, tiles))));
+  int rows_per_wave = (n + slices - 1) / slices;
+  rows_per_wave = (rows_per_wave + 3) & ~3;
+  slices = (n + rows_per_wave - 1) / rows_per_wave;
+  dim3 grid((slices + 3) / 4, (p + 31) / 32, (q + 31) / 32), block(256);
+  hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
+                     rows_per_wave);
+}
+
+// gemm_nn:  Y (n x q) = alpha * A (n x p) * C (p x q) + beta * Y.
+// A wave owns 16 rows x (16*TJ) columns.  A-operand: A[r0 + (l&15)][k + (l>>4)].
+template <int TJ>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(int n, int p, int q,
+                                                      const double* __restrict__ A, int lda,
+                                                      const double* __restrict__ C, int ldc,
+                                                      double* __restrict__ Y, int ldy,
+                                                      double alpha, double beta) {
+  const int lane = threadIdx.x & 63;
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int j0 = blockIdx.y * 16 * TJ;
+  if (r0 >= n) return;
+  const int lc = lane & 15, lk = lane >> 4;
+  d4 acc[TJ];
+#pragma unroll
+  for (int b = 0; b < TJ; ++b) acc[b] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int arow = r0 + lc;
+  const bool aok = arow < n;
+  for (int k = 0; k < p; k += 4) {
+    const int kk = k + lk;
+    const double af = (aok && kk < p) ? A[(size_t)arow * lda + kk] : 0.0;
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) {
+      const int col = j0 + 16 * b + lc;
+      const double bf = (kk < p && col < q) ? C[(size_t)kk * ldc + col] : 0.0;
+      acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc[b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < TJ; ++b)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = r0 + lk + 4 * e;
+      const int col = j0 + 16 * b + lc;
+      if (row < n && col < q) {
+        double* y = &Y[(size_t)row * ldy + col];
+        *y = alpha * acc[b][e] + (beta == 0.0 ? 0.0 : beta * (*y));
+      }
+    }
+}
+void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
+                    int ldc, double* Y, int ldy, double alpha, double beta) {
+  if (n <= 0 || q <= 0) return;
+  dim3 grid((n + 63) / 64, (q + 31) / 32), block(256);
+  hipLaunchKernelGGL((gemm_nn_kernel<2>), grid, block, 0, st, n, p, q, A, lda, C, ldc, Y, ldy,
+                     alpha, beta);
+}
+
+// coarse matrix combine: out = beta*E0 + alpha*EM + EJ  (dense k x k)
+__global__ void combine3_kernel(size_t n, const double* a0, const double* a1, const double* a2,
+                                double alpha, double beta, double* out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = beta * a0[i] + alpha * a1[i] + a2[i];
+}
+void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
+                     const double* a2, double alpha, double beta, double* out) {
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(combine3_kernel, dim3(grid), dim3(256), 0, st, n, a0, a1, a2, alpha, beta,
+                     out);
+}
+
+// identity matrix (for getrs against I)
+__global__ void set_identity_kernel(int k, double* out) {
+  size_t n = (size_t)k * k;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (i / k == i % k) ? 1.0 : 0.0;
+}
+void launch_set_identity(hipStream_t st, int k, double* out) {
+  size_t n = (size_t)k * k;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(set_identity_kernel, dim3(grid), dim3(256), 0, st, k, out);
+}
+
+}  // namespace ricadi

@@ -1,0 +1,1175 @@
+// ricadi_solver.hip -- context, two-level preconditioner, panel GMRES, low-rank
+// ADI, Newton-Kleinman, compression, gain; and the C-ABI of include/ricadi.h.
+//
+// New code (the reference has no native source).  The
+// algorithms restate what the reference *calls* -- see include/ricadi.h for the
+// reference call site behind each entry point.
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "ricadi_internal.h"
+
+namespace ricadi {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+struct HipError {
+  std::string msg;
+};
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      throw HipError{std::string(#expr) + " : " + hipGetErrorString(e_)};                 \
+  } while (0)
+#define RBCHK(expr)                                                                       \
+  do {                                                                                    \
+    rocblas_status s_ = (expr);                                                           \
+    if (s_ != rocblas_status_success)                                                     \
+      throw HipError{std::string(#expr) + " : rocblas status " + std::to_string((int)s_)}; \
+  } while (0)
+
+template <class T>
+struct DArr {
+  T* p = nullptr;
+  size_t n = 0;
+  DArr() = default;
+  DArr(const DArr&) = delete;
+  DArr& operator=(const DArr&) = delete;
+  ~DArr() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count) HIPCHK(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void ensure(size_t count) {
+    if (count > n) alloc(count);
+  }
+  void upload(const std::vector<T>& h, hipStream_t st) {
+    alloc(h.size());
+    if (!h.empty()) {
+      HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+};
+
+struct ShiftData {
+  double alpha = 0, beta = 0;
+  DArr<double> sval, dinv, bvinv, bpinv, einv;
+};
+
+struct DevCsr {
+  int nrows = 0;
+  DArr<int> rp, ci;
+  DArr<double> v;
+  void upload(const HostCsr& h, hipStream_t st) {
+    nrows = h.nrows;
+    rp.upload(h.rp, st);
+    ci.upload(h.ci, st);
+    v.upload(h.v, st);
+  }
+};
+
+}  // namespace ricadi
+
+using namespace ricadi;
+
+struct ricadi_ctx {
+  int dev = 0;
+  hipStream_t st = nullptr;
+  rocblas_handle rb = nullptr;
+  ricadi_opts opts;
+  bool has_op = false;
+  int nv = 0, np = 0, n = 0;
+  int bs = 32, nbv = 0, nbp = 0, kc = 0;
+  size_t snnz = 0;
+  // operator
+  DArr<int> s_rp, s_ci;
+  DArr<double> srcA, srcE, srcJ;
+  DevCsr A, E, J, JT;
+  DArr<double> dA, dE;
+  DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows;
+  DArr<double> bvA, bvE;
+  DArr<int> agg_ptr, agg_rows, aggof;
+  DArr<double> E0, EM, EJ;
+  // low rank
+  int q = 0;
+  DArr<double> U, V, lrc;
+  // per-shift data
+  std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
+  // workspaces
+  int wm = 0, wrestart = 0;
+  DArr<double> basis, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
+  DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
+  DArr<int> flag, ipiv, info;
+  double* h_resid = nullptr;  // pinned
+  // factor
+  DArr<double> Z;
+  int zc = 0, zld = 0;
+  // stats
+  long total_iters = 0, total_solves = 0;
+
+  ~ricadi_ctx() {
+    if (h_resid) (void)hipHostFree(h_resid);
+    if (rb) rocblas_destroy_handle(rb);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+namespace ricadi {
+
+static void ensure_work(ricadi_ctx* c, int m) {
+  const int restart = c->opts.gmres_restart;
+  if (m <= c->wm && restart == c->wrestart) return;
+  const int mm = std::max(m, c->wm);
+  const size_t nm = (size_t)c->n * mm;
+  c->basis.alloc((size_t)(restart + 1) * nm);
+  c->wv.alloc(nm);
+  c->zv.alloc(nm);
+  c->r2.alloc(nm);
+  c->xs.alloc(nm);
+  c->bvec.alloc(nm);
+  c->pw1.alloc(nm);
+  c->pw2.alloc(nm);
+  c->tp.alloc((size_t)std::max(c->np, 1) * mm);
+  c->rc.alloc((size_t)std::max(c->kc, 1) * mm);
+  c->ec.alloc((size_t)std::max(c->kc, 1) * mm);
+  c->partial.alloc((size_t)dots_num_blocks(c->n) * (restart + 2) * mm);
+  c->h1.alloc((size_t)(restart + 2) * mm);
+  c->h2.alloc((size_t)(restart + 2) * mm);
+  c->H.alloc((size_t)mm * (restart + 1) * restart);
+  c->cs.alloc((size_t)mm * restart);
+  c->sn.alloc((size_t)mm * restart);
+  c->g.alloc((size_t)mm * (restart + 1));
+  c->scale.alloc(mm);
+  c->resid.alloc(mm);
+  c->yv.alloc((size_t)restart * mm);
+  c->bnorm2.alloc(mm);
+  c->nrm2.alloc(mm);
+  c->lrc.alloc((size_t)64 * mm + 64);
+  if (!c->h_resid) HIPCHK(hipHostMalloc((void**)&c->h_resid, sizeof(double) * 2 * RICADI_MAX_M));
+  c->wm = mm;
+  c->wrestart = restart;
+}
+
+// ---- per-shift setup ---------------------------------------------------------
+static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
+  auto key = std::make_pair(alpha, beta);
+  auto it = c->cache.find(key);
+  if (it != c->cache.end()) return it->second.get();
+  std::unique_ptr<ShiftData> sd(new ShiftData);
+  sd->alpha = alpha;
+  sd->beta = beta;
+  hipStream_t st = c->st;
+  sd->sval.alloc(c->snnz);
+  launch_assemble_shift(st, (int)c->snnz, c->srcA.p, c->srcE.p, c->srcJ.p, alpha, beta,
+                        sd->sval.p);
+  sd->dinv.alloc(c->nv);
+  launch_diag_inv(st, c->nv, c->dA.p, c->dE.p, alpha, beta, sd->dinv.p);
+  HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
+  const size_t bsz = (size_t)c->bs * c->bs;
+  sd->bvinv.alloc((size_t)c->nbv * bsz);
+  launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
+  launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
+  if (c->nbp > 0) {
+    sd->bpinv.alloc((size_t)c->nbp * bsz);
+    launch_schur_blocks(st, c->nbp, c->bs, c->bp_ptr.p, c->bp_rows.p, c->J.rp.p, c->J.ci.p,
+                        c->J.v.p, sd->dinv.p, sd->bpinv.p);
+    launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
+  }
+  if (c->kc > 0) {
+    const int k = c->kc;
+    sd->einv.alloc((size_t)k * k);
+    launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
+    c->ipiv.ensure(k);
+    // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
+    RBCHK(rocsolver_dgetrf(c->rb, k, k, sd->einv.p, k, c->ipiv.p, c->info.p));
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (info != 0) throw HipError{"coarse matrix singular (dgetrf info " + std::to_string(info) + ")"};
+    RBCHK(rocsolver_dgetri(c->rb, k, sd->einv.p, k, c->ipiv.p, c->info.p));
+  }
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (flag) throw HipError{"singular block-Jacobi block"};
+  ShiftData* out = sd.get();
+  c->cache[key] = std::move(sd);
+  return out;
+}
+
+// ---- operator and preconditioner on device panels ---------------------------------
+// y = S(alpha,beta) x   (n x m panels, ld = m); optional low-rank  - U V^T x_v
+static void op_apply(ricadi_ctx* c, const ShiftData* sd, const double* x, double* y, int m,
+                     bool lowrank) {
+  hipStream_t st = c->st;
+  launch_spmm(st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, x, m, nullptr, y, m, nullptr, 0, 1.0,
+              0.0, nullptr, m);
+  if (lowrank && c->q > 0) {
+    HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * c->q * m, st));
+    launch_gemm_tn(st, c->nv, c->q, m, c->V.p, c->q, x, m, c->lrc.p, m);
+    launch_gemm_nn(st, c->nv, c->q, m, c->U.p, c->q, c->lrc.p, m, y, m, -1.0, 1.0);
+  }
+}
+
+// z = P^-1 r : multiplicative two-level, coarse correction first, then one
+// SIMPLE-type block-Jacobi sweep on the updated residual.
+static void precond_apply(ricadi_ctx* c, const ShiftData* sd, const double* r, double* z, int m) {
+  hipStream_t st = c->st;
+  const int nv = c->nv, np = c->np;
+  const double* rr = r;
+  if (c->kc > 0) {
+    launch_restrict(st, c->kc, c->agg_ptr.p, c->agg_rows.p, r, m, c->rc.p, m);
+    launch_dense_apply(st, c->kc, m, sd->einv.p, c->rc.p, c->ec.p);
+    // r2 = r - S * (Y ec), prolongation folded into the gather
+    launch_spmm(st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, c->ec.p, m, c->aggof.p, c->r2.p, m, r,
+                m, -1.0, 1.0, nullptr, m);
+    rr = c->r2.p;
+  }
+  launch_block_apply(st, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, sd->bvinv.p, rr, m, z, m, m);
+  if (np > 0) {
+    // t = J z_v - r_p
+    launch_spmm(st, np, c->J.rp.p, c->J.ci.p, c->J.v.p, z, m, nullptr, c->tp.p, m,
+                rr + (size_t)nv * m, m, 1.0, -1.0, nullptr, m);
+    double* zp = z + (size_t)nv * m;
+    launch_block_apply(st, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, sd->bpinv.p, c->tp.p, m, zp,
+                       m, m);
+    // z_v -= Dinv * J^T z_p
+    launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, z, m, z, m, -1.0, 1.0,
+                sd->dinv.p, m);
+  }
+  if (c->kc > 0) launch_prolong_add(st, c->n, m, c->aggof.p, c->ec.p, z);
+}
+
+static void col_norms2(ricadi_ctx* c, const double* w, int nrows, int m, double* out) {
+  launch_cols_dots(c->st, nrows, m, 0, nullptr, 0, w, 1, c->partial.p, out);
+}
+
+// ---- panel GMRES ------------------------------------------------------------------
+// Solves S x = b for the m columns of the n x m panel b (device), x (device) is
+// overwritten.  Right preconditioning, CGS2, per-column Givens QR.
+struct GmresResult {
+  int iters = 0;
+  bool converged = false;
+  double max_relres = 0.0;
+};
+
+static GmresResult gmres_solve(ricadi_ctx* c, const ShiftData* sd, const double* b, double* x,
+                               int m, bool lowrank, double* relres_host) {
+  ensure_work(c, m);
+  hipStream_t st = c->st;
+  const int n = c->n, restart = c->opts.gmres_restart, maxit = c->opts.gmres_maxit;
+  const double tol = c->opts.gmres_tol;
+  const size_t nm = (size_t)n * m;
+  double* V = c->basis.p;
+  double* hb = c->h_resid;            // [0..m) resid, [m..2m) bnorm
+  GmresResult res;
+
+  col_norms2(c, b, n, m, c->bnorm2.p);
+  HIPCHK(hipMemcpyAsync(hb + m, c->bnorm2.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<double> bn(m);
+  for (int j = 0; j < m; ++j) bn[j] = std::sqrt(std::max(hb[m + j], 0.0));
+  // device copy of the norms (not squared) for the hess kernel
+  HIPCHK(hipMemcpyAsync(c->bnorm2.p, bn.data(), sizeof(double) * m, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * nm, st));
+
+  auto all_converged = [&](const double* r) {
+    double worst = 0.0;
+    bool ok = true;
+    for (int j = 0; j < m; ++j) {
+      const double rel = bn[j] > 0.0 ? r[j] / bn[j] : 0.0;
+      worst = std::max(worst, rel);
+      if (!(r[j] <= tol * bn[j])) ok = false;
+    }
+    res.max_relres = worst;
+    return ok;
+  };
+
+  bool first = true;
+  while (true) {
+    // residual of the current iterate
+    if (first) {
+      HIPCHK(hipMemcpyAsync(c->wv.p, b, sizeof(double) * nm, hipMemcpyDeviceToDevice, st));
+    } else {
+      op_apply(c, sd, x, c->wv.p, m, lowrank);
+      launch_axpby(st, nm, 1.0, b, -1.0, c->wv.p);
+    }
+    first = false;
+    col_norms2(c, c->wv.p, n, m, c->nrm2.p);
+    launch_gmres_start(st, m, restart, c->nrm2.p, c->g.p, c->scale.p, c->resid.p);
+    HIPCHK(hipMemcpyAsync(hb, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (all_converged(hb)) { res.converged = true; break; }
+    if (res.iters >= maxit) break;
+    launch_colscale(st, n, m, c->scale.p, c->wv.p, 0.0, V);
+    int k = 0;
+    for (int j = 0; j < restart; ++j) {
+      const double* vj = V + (size_t)j * nm;
+      precond_apply(c, sd, vj, c->zv.p, m);
+      op_apply(c, sd, c->zv.p, c->wv.p, m, lowrank);
+      launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 0, c->partial.p, c->h1.p);
+      launch_cols_update(st, n, m, j + 1, V, nm, c->h1.p, -1.0, c->wv.p, nullptr, c->wv.p);
+      launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 1, c->partial.p, c->h2.p);
+      launch_gmres_hess(st, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p, c->g.p,
+                        c->scale.p, c->resid.p, c->bnorm2.p, tol);
+      launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
+                         V + (size_t)(j + 1) * nm);
+      HIPCHK(hipMemcpyAsync(hb, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      ++res.iters;
+      k = j + 1;
+      if (all_converged(hb) || res.iters >= maxit) break;
+    }
+    launch_gmres_backsolve(st, m, k, restart, c->H.p, c->g.p, c->yv.p);
+    launch_cols_update(st, n, m, k, V, nm, c->yv.p, 1.0, nullptr, nullptr, c->wv.p);
+    precond_apply(c, sd, c->wv.p, c->zv.p, m);
+    launch_axpby(st, nm, 1.0, c->zv.p, 1.0, x);
+  }
+  if (relres_host) {
+    // true residual
+    op_apply(c, sd, x, c->wv.p, m, lowrank);
+    launch_axpby(st, nm, 1.0, b, -1.0, c->wv.p);
+    col_norms2(c, c->wv.p, n, m, c->nrm2.p);
+    HIPCHK(hipMemcpyAsync(hb, c->nrm2.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < m; ++j)
+      relres_host[j] = bn[j] > 0.0 ? std::sqrt(std::max(hb[j], 0.0)) / bn[j] : 0.0;
+  }
+  c->total_iters += res.iters;
+  c->total_solves += 1;
+  return res;
+}
+
+// rhs panel (n x m) from an NV x m device block (pressure rows zero)
+static void load_rhs(ricadi_ctx* c, const double* dR, int m, double* b) {
+  HIPCHK(hipMemcpyAsync(b, dR, sizeof(double) * (size_t)c->nv * m, hipMemcpyDeviceToDevice, c->st));
+  if (c->np > 0)
+    HIPCHK(hipMemsetAsync(b + (size_t)c->nv * m, 0, sizeof(double) * (size_t)c->np * m, c->st));
+}
+
+// W (NV x m, device, in place) <- P^T W  through one saddle solve with cal E
+static void project_panel(ricadi_ctx* c, double* dW, int m) {
+  if (c->np == 0) return;
+  ShiftData* sd = get_shift(c, 1.0, 0.0);
+  ensure_work(c, m);
+  load_rhs(c, dW, m, c->bvec.p);
+  GmresResult r = gmres_solve(c, sd, c->bvec.p, c->xs.p, m, false, nullptr);
+  if (!r.converged) throw HipError{"projection solve did not converge"};
+  launch_spmm(c->st, c->nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->xs.p, m, nullptr, dW, m, nullptr, 0,
+              1.0, 0.0, nullptr, m);
+}
+
+struct DScalar {
+  // tiny helper: Frobenius norm of W^T W and ||W||_F^2 of a device panel
+  static void gram_norms(ricadi_ctx* c, const double* dW, int nrows, int m, double* gram_fro,
+                         double* nrm2) {
+    DArr<double>& G = c->lrc;
+    G.ensure((size_t)m * m + 64);
+    HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * m * m, c->st));
+    launch_gemm_tn(c->st, nrows, m, m, dW, m, dW, m, G.p, m);
+    std::vector<double> h((size_t)m * m);
+    HIPCHK(hipMemcpyAsync(h.data(), G.p, sizeof(double) * m * m, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    double f = 0.0, t = 0.0;
+    for (int i = 0; i < m; ++i) {
+      t += h[(size_t)i * m + i];
+      for (int j = 0; j < m; ++j) f += h[(size_t)i * m + j] * h[(size_t)i * m + j];
+    }
+    if (gram_fro) *gram_fro = std::sqrt(f);
+    if (nrm2) *nrm2 = t;
+  }
+};
+
+// ---- low-rank ADI (device resident) -------------------------------------------------
+struct AdiStats {
+  int steps = 0;
+  double rel = 0.0;
+  long gmres_iters = 0;
+  long shift_solves = 0;
+  double res_fro = 0.0;
+};
+
+// dW: NV x m device panel (overwritten by the final residual factor).
+// Appends sqrt(-2p) V_i to c->Z (ld = c->zld) starting at column c->zc.
+static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
+                             const ricadi_adi_params& prm) {
+  AdiStats stt;
+  hipStream_t st = c->st;
+  ensure_work(c, m);
+  if (prm.project_w) project_panel(c, dW, m);
+  const long it0 = c->total_iters;
+  double znorm2 = 0.0;
+  for (int step = 1; step <= prm.adi_max_steps; ++step) {
+    const double p = shifts[(step - 1) % ns];
+    ShiftData* sd = get_shift(c, p, 1.0);
+    load_rhs(c, dW, m, c->bvec.p);
+    GmresResult r = gmres_solve(c, sd, c->bvec.p, c->xs.p, m, true, nullptr);
+    if (!r.converged && prm.verbose)
+      fprintf(stderr, "[ricadi] ADI step %d shift %g: GMRES stopped at relres %.2e after %d its\n",
+              step, p, r.max_relres, r.iters);
+    stt.shift_solves++;
+    // W <- W - 2 p E V
+    launch_spmm(st, c->nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->xs.p, m, nullptr, dW, m, dW, m,
+                -2.0 * p, 1.0, nullptr, m);
+    // Z <- [Z, sqrt(-2p) V]
+    launch_copy_cols(st, c->nv, m, c->xs.p, m, 0, c->Z.p, c->zld, c->zc, std::sqrt(-2.0 * p));
+    double n2 = 0.0;
+    col_norms2(c, c->xs.p, c->nv, m, c->nrm2.p);
+    HIPCHK(hipMemcpyAsync(c->h_resid, c->nrm2.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < m; ++j) n2 += c->h_resid[j];
+    n2 *= -2.0 * p;
+    znorm2 += n2;
+    c->zc += m;
+    stt.steps = step;
+    stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / znorm2) : 0.0;
+    if (prm.verbose)
+      fprintf(stderr, "[ricadi] ADI step %3d: shift %10.3e rel new Z %9.3e gmres its %d\n", step,
+              p, stt.rel, r.iters);
+    if (stt.rel < prm.adi_newZ_reltol) break;
+  }
+  stt.gmres_iters = c->total_iters - it0;
+  DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
+  return stt;
+}
+
+static void factor_reserve(ricadi_ctx* c, int ld) {
+  if ((size_t)c->nv * ld > c->Z.n) c->Z.alloc((size_t)c->nv * ld);
+  c->zld = ld;
+  c->zc = 0;
+}
+
+// ---- compression: Gram matrix on the matrix cores, eigendecomposition, Z * V_k -----
+// dZ: NV x cz (ld = ldz).  Returns k and writes Zc (NV x k, ld = k) into dOut
+// (which must hold NV*cz doubles).  Singular values (descending) to sv_host.
+static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
+                        bool thresh_relative, double* dOut, std::vector<double>* sv_host) {
+  hipStream_t st = c->st;
+  if (cz == 0) return 0;
+  DArr<double> G, ev, work, sel;
+  G.alloc((size_t)cz * cz);
+  ev.alloc(cz);
+  work.alloc(cz);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
+  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
+  RBCHK(rocsolver_dsyevd(c->rb, rocblas_evect_original, rocblas_fill_upper, cz, G.p, cz, ev.p,
+                         work.p, c->info.p));
+  std::vector<double> lam(cz);
+  HIPCHK(hipMemcpyAsync(lam.data(), ev.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // eigenvalues ascending; singular values descending
+  std::vector<double> sv(cz);
+  for (int i = 0; i < cz; ++i) sv[i] = std::sqrt(std::max(lam[cz - 1 - i], 0.0));
+  int k = std::min(cz, c->nv);
+  if (thresh >= 0.0) {
+    const double t = thresh_relative ? thresh * sv[0] : thresh;
+    int cnt = 0;
+    while (cnt < cz && sv[cnt] > t) ++cnt;
+    k = std::min(k, cnt);
+  }
+  if (kmax > 0) k = std::min(k, kmax);
+  if (sv_host) *sv_host = sv;
+  if (k == 0) return 0;
+  // row-major view of syevd output: row j = eigenvector j (ascending).  Build the
+  // cz x k selection  C[i][jj] = evec_{cz-1-jj}[i]  on the host (small).
+  std::vector<double> Gh((size_t)cz * cz), Ch((size_t)cz * k);
+  HIPCHK(hipMemcpyAsync(Gh.data(), G.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int jj = 0; jj < k; ++jj) {
+    const double* e = Gh.data() + (size_t)(cz - 1 - jj) * cz;
+    for (int i = 0; i < cz; ++i) Ch[(size_t)i * k + jj] = e[i];
+  }
+  sel.alloc((size_t)cz * k);
+  HIPCHK(hipMemcpyAsync(sel.p, Ch.data(), sizeof(double) * cz * k, hipMemcpyHostToDevice, st));
+  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
+  HIPCHK(hipStreamSynchronize(st));
+  return k;
+}
+
+// || Z1 Z1^T - Z0 Z0^T ||_F  via an LQ factorisation of [Z1, Z0]^T (Householder,
+// rocSOLVER) -- no squaring, so updates far below 1e-8 relative are resolved.
+static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const double* dZ0, int k0,
+                             double* x1norm) {
+  hipStream_t st = c->st;
+  const int kk = k1 + k0, nv = c->nv;
+  DArr<double> D, tau;
+  D.alloc((size_t)nv * kk);
+  tau.alloc(kk);
+  launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
+  if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
+  // row-major NV x kk  ==  column-major kk x NV :  D^T = L Q
+  RBCHK(rocsolver_dgelqf(c->rb, kk, nv, D.p, kk, tau.p));
+  std::vector<double> Lh((size_t)kk * kk);
+  // first kk columns of the column-major kk x NV array = first kk rows of the row-major one
+  HIPCHK(hipMemcpyAsync(Lh.data(), D.p, sizeof(double) * kk * kk, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // column-major L(i,j) = Lh[i + j*kk], lower triangular (i >= j)
+  auto Lat = [&](int i, int j) { return i >= j ? Lh[(size_t)i + (size_t)j * kk] : 0.0; };
+  // D S D^T = Q^T (L^T S L) Q  -> T = L^T S L (kk x kk), S = diag(I_k1, -I_k0)
+  // here D = (L Q)^T = Q^T L^T, so D S D^T needs S between D and D^T:
+  // D S D^T = Q^T L^T ... careful: D is NV x kk, D = Q^T L^T; D S D^T = Q^T (L^T S L) Q.
+  double f = 0.0, f1 = 0.0;
+  for (int a = 0; a < kk; ++a)
+    for (int b = 0; b < kk; ++b) {
+      double t = 0.0, t1 = 0.0;
+      for (int i = std::max(a, b); i < kk; ++i) {
+        const double pr = Lat(i, a) * Lat(i, b);
+        if (i < k1) { t += pr; t1 += pr; } else { t -= pr; }
+      }
+      f += t * t;
+      f1 += t1 * t1;
+    }
+  if (x1norm) *x1norm = std::sqrt(f1);
+  return std::sqrt(f);
+}
+
+// K = E * (Z * (Z^T B))  (device);  dK is NV x nb
+static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, int ldz,
+                     const double* dB, int nb, double* dK) {
+  hipStream_t st = c->st;
+  DArr<double> ZtB, T;
+  ZtB.alloc((size_t)std::max(cz, 1) * nb);
+  T.alloc((size_t)c->nv * nb);
+  HIPCHK(hipMemsetAsync(ZtB.p, 0, sizeof(double) * std::max(cz, 1) * nb, st));
+  launch_gemm_tn(st, c->nv, cz, nb, dZ, ldz, dB, nb, ZtB.p, nb);
+  launch_gemm_nn(st, c->nv, cz, nb, dZ, ldz, ZtB.p, nb, T.p, nb, 1.0, 0.0);
+  launch_spmm(st, c->nv, Mt.rp.p, Mt.ci.p, Mt.v.p, T.p, nb, nullptr, dK, nb, nullptr, 0, 1.0, 0.0,
+              nullptr, nb);
+  HIPCHK(hipStreamSynchronize(st));
+}
+
+}  // namespace ricadi
+
+// =====================================================================================
+//                                      C  A B I
+// =====================================================================================
+#define API_BEGIN try {
+#define API_END                                                   \
+  }                                                               \
+  catch (const ricadi::HipError& e) {                             \
+    ricadi::set_error(e.msg);                                     \
+    return RICADI_EHIP;                                           \
+  }                                                               \
+  catch (const std::exception& e) {                               \
+    ricadi::set_error(e.what());                                  \
+    return RICADI_EHIP;                                           \
+  }                                                               \
+  return RICADI_OK;
+
+#define REQUIRE(cond, code, msg)     \
+  do {                               \
+    if (!(cond)) {                   \
+      ricadi::set_error(msg);        \
+      return code;                   \
+    }                                \
+  } while (0)
+
+extern "C" {
+
+const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
+int ricadi_version(void) { return 100; }
+
+void ricadi_default_opts(ricadi_opts* o) {
+  if (!o) return;
+  o->gmres_tol = 1e-11;
+  o->gmres_restart = 60;
+  o->gmres_maxit = 3000;
+  o->bj_block = 32;
+  o->agg_v = 16;
+  o->agg_p = 32;
+  o->coarse_max = 4096;
+  o->use_coarse = 1;
+  o->verbose = 0;
+}
+
+void ricadi_default_adi_params(ricadi_adi_params* p) {
+  if (!p) return;
+  // /root/reference/optcont_main.py:122-131
+  p->adi_max_steps = 200;
+  p->adi_newZ_reltol = 1e-8;
+  p->nwtn_max_steps = 16;
+  p->nwtn_upd_reltol = 5e-8;
+  p->nwtn_upd_abstol = 1e-7;
+  p->project_w = 1;
+  p->verbose = 0;
+}
+
+int ricadi_create(int device_id, ricadi_ctx** out) {
+  REQUIRE(out, RICADI_EINVAL, "ricadi_create: ctx is NULL");
+  *out = nullptr;
+  API_BEGIN
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) throw ricadi::HipError{"no HIP device visible (this library has no CPU fallback)"};
+  if (device_id < 0 || device_id >= ndev) throw ricadi::HipError{"bad device id"};
+  HIPCHK(hipSetDevice(device_id));
+  std::unique_ptr<ricadi_ctx> c(new ricadi_ctx);
+  c->dev = device_id;
+  ricadi_default_opts(&c->opts);
+  HIPCHK(hipStreamCreate(&c->st));
+  RBCHK(rocblas_create_handle(&c->rb));
+  RBCHK(rocblas_set_stream(c->rb, c->st));
+  c->flag.alloc(4);
+  c->info.alloc(4);
+  *out = c.release();
+  API_END
+}
+
+int ricadi_destroy(ricadi_ctx* ctx) {
+  if (!ctx) return RICADI_OK;
+  API_BEGIN
+  (void)hipSetDevice(ctx->dev);
+  (void)hipStreamSynchronize(ctx->st);
+  delete ctx;
+  API_END
+}
+
+int ricadi_set_opts(ricadi_ctx* c, const ricadi_opts* o) {
+  REQUIRE(c && o, RICADI_EINVAL, "ricadi_set_opts: NULL argument");
+  REQUIRE(o->gmres_restart >= 2 && o->gmres_restart <= 400, RICADI_EINVAL, "gmres_restart out of range");
+  REQUIRE(o->gmres_tol > 0 && o->gmres_maxit > 0, RICADI_EINVAL, "bad gmres_tol / gmres_maxit");
+  const bool structural = c->has_op && (o->bj_block != c->opts.bj_block || o->agg_v != c->opts.agg_v ||
+                                        o->agg_p != c->opts.agg_p || o->coarse_max != c->opts.coarse_max ||
+                                        o->use_coarse != c->opts.use_coarse);
+  REQUIRE(!structural, RICADI_ESTATE, "preconditioner options must be set before ricadi_set_operator");
+  c->opts = *o;
+  return RICADI_OK;
+}
+
+void* ricadi_stream(ricadi_ctx* c) { return c ? (void*)c->st : nullptr; }
+
+int ricadi_synchronize(ricadi_ctx* c) {
+  REQUIRE(c, RICADI_EINVAL, "NULL ctx");
+  API_BEGIN
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, const int32_t* a_ci,
+                        const double* a_v, const int32_t* e_rp, const int32_t* e_ci,
+                        const double* e_v, const int32_t* j_rp, const int32_t* j_ci,
+                        const double* j_v) {
+  REQUIRE(c, RICADI_EINVAL, "NULL ctx");
+  REQUIRE(nv > 0 && np >= 0, RICADI_EINVAL, "bad sizes");
+  REQUIRE(a_rp && a_ci && a_v && e_rp && e_ci && e_v, RICADI_EINVAL, "NULL matrix");
+  REQUIRE(np == 0 || (j_rp && j_ci && j_v), RICADI_EINVAL, "NULL J");
+  API_BEGIN
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t st = c->st;
+  HostCsr A = make_csr(nv, nv, a_rp, a_ci, a_v);
+  HostCsr E = make_csr(nv, nv, e_rp, e_ci, e_v);
+  HostCsr J;
+  if (np > 0) {
+    J = make_csr(np, nv, j_rp, j_ci, j_v);
+  } else {
+    J.nrows = 0;
+    J.ncols = nv;
+    J.rp.assign(1, 0);
+  }
+  for (size_t k = 0; k < A.nnz(); ++k)
+    if (A.ci[k] < 0 || A.ci[k] >= nv) throw ricadi::HipError{"A: column index out of range"};
+  for (size_t k = 0; k < E.nnz(); ++k)
+    if (E.ci[k] < 0 || E.ci[k] >= nv) throw ricadi::HipError{"E: column index out of range"};
+  for (size_t k = 0; k < J.nnz(); ++k)
+    if (J.ci[k] < 0 || J.ci[k] >= nv) throw ricadi::HipError{"J: column index out of range"};
+  HostSetup hs;
+  build_setup(A, E, J, c->opts, hs);
+  c->cache.clear();
+  c->nv = nv;
+  c->np = np;
+  c->n = nv + np;
+  c->bs = hs.bs;
+  c->nbv = hs.nbv;
+  c->nbp = hs.nbp;
+  c->kc = hs.kc;
+  c->snnz = hs.s_ci.size();
+  c->s_rp.upload(hs.s_rp, st);
+  c->s_ci.upload(hs.s_ci, st);
+  c->srcA.upload(hs.s_srcA, st);
+  c->srcE.upload(hs.s_srcE, st);
+  c->srcJ.upload(hs.s_srcJ, st);
+  c->A.upload(A, st);
+  c->E.upload(E, st);
+  c->J.upload(J, st);
+  HostCsr JT = transpose(J);
+  c->JT.upload(JT, st);
+  c->dA.upload(hs.dA, st);
+  c->dE.upload(hs.dE, st);
+  c->bv_ptr.upload(hs.bv_ptr, st);
+  c->bv_rows.upload(hs.bv_rows, st);
+  c->bp_ptr.upload(hs.bp_ptr, st);
+  c->bp_rows.upload(hs.bp_rows, st);
+  c->bvA.upload(hs.bv_A, st);
+  c->bvE.upload(hs.bv_E, st);
+  c->agg_ptr.upload(hs.agg_ptr, st);
+  c->agg_rows.upload(hs.agg_rows, st);
+  c->aggof.upload(hs.aggof, st);
+  c->E0.upload(hs.E0, st);
+  c->EM.upload(hs.EM, st);
+  c->EJ.upload(hs.EJ, st);
+  c->q = 0;
+  c->wm = 0;  // workspaces depend on n
+  c->zc = 0;
+  c->has_op = true;
+  if (c->opts.verbose)
+    fprintf(stderr, "[ricadi] operator nv=%d np=%d nnz(S)=%zu | BJ blocks %d+%d (bs=%d) | coarse %d (%d+%d)\n",
+            nv, np, c->snnz, c->nbv, c->nbp, c->bs, c->kc, hs.kcv, hs.kcp);
+  API_END
+}
+
+int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(q >= 0 && q <= 64, RICADI_EINVAL, "low-rank width must be in [0, 64]");
+  REQUIRE(q == 0 || (U && V), RICADI_EINVAL, "NULL low-rank factor");
+  API_BEGIN
+  c->q = q;
+  if (q > 0) {
+    const size_t cnt = (size_t)c->nv * q;
+    c->U.ensure(cnt);
+    c->V.ensure(cnt);
+    HIPCHK(hipMemcpyAsync(c->U.p, U, cnt * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->V.p, V, cnt * sizeof(double), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
+  API_END
+}
+
+static int check_panel(ricadi_ctx* c, int m) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(m >= 1 && m <= RICADI_MAX_M, RICADI_EINVAL, "panel width must be in [1, 128]");
+  return RICADI_OK;
+}
+
+int ricadi_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double* dX, int m, double* dY) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dX && dY, RICADI_EINVAL, "NULL panel");
+  API_BEGIN
+  ShiftData* sd = get_shift(c, alpha, beta);
+  ensure_work(c, m);
+  op_apply(c, sd, dX, dY, m, true);
+  API_END
+}
+
+int ricadi_spmm(ricadi_ctx* c, double alpha, double beta, const double* X, int m, double* Y) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(X && Y, RICADI_EINVAL, "NULL panel");
+  API_BEGIN
+  const size_t nm = (size_t)c->n * m;
+  ShiftData* sd = get_shift(c, alpha, beta);
+  ensure_work(c, m);
+  HIPCHK(hipMemcpyAsync(c->pw1.p, X, nm * sizeof(double), hipMemcpyHostToDevice, c->st));
+  op_apply(c, sd, c->pw1.p, c->pw2.p, m, true);
+  HIPCHK(hipMemcpyAsync(Y, c->pw2.p, nm * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_precond_apply(ricadi_ctx* c, double alpha, double beta, const double* R, int m, double* Z) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(R && Z, RICADI_EINVAL, "NULL panel");
+  API_BEGIN
+  const size_t nm = (size_t)c->n * m;
+  ShiftData* sd = get_shift(c, alpha, beta);
+  ensure_work(c, m);
+  HIPCHK(hipMemcpyAsync(c->pw1.p, R, nm * sizeof(double), hipMemcpyHostToDevice, c->st));
+  precond_apply(c, sd, c->pw1.p, c->pw2.p, m);
+  HIPCHK(hipMemcpyAsync(Z, c->pw2.p, nm * sizeof(double), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_shift_solve_dev(ricadi_ctx* c, double alpha, double beta, const double* dR, int m,
+                           double* dX, int* iters_out, double* relres_out) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dR && dX, RICADI_EINVAL, "NULL panel");
+  int status = RICADI_OK;
+  try {
+    ShiftData* sd = get_shift(c, alpha, beta);
+    ensure_work(c, m);
+    load_rhs(c, dR, m, c->bvec.p);
+    GmresResult r = gmres_solve(c, sd, c->bvec.p, dX, m, true, relres_out);
+    if (iters_out) *iters_out = r.iters;
+    if (!r.converged) {
+      ricadi::set_error("GMRES did not reach the tolerance");
+      status = RICADI_ENOCONV;
+    }
+  } catch (const ricadi::HipError& e) {
+    ricadi::set_error(e.msg);
+    return RICADI_EHIP;
+  }
+  return status;
+}
+
+int ricadi_shift_solve(ricadi_ctx* c, double alpha, double beta, const double* R, const double* Rp,
+                       int m, double* X_out, int* iters_out, double* relres_out) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(R && X_out, RICADI_EINVAL, "NULL panel");
+  int status = RICADI_OK;
+  try {
+    const size_t nm = (size_t)c->n * m, nvm = (size_t)c->nv * m;
+    ShiftData* sd = get_shift(c, alpha, beta);
+    ensure_work(c, m);
+    HIPCHK(hipMemcpyAsync(c->bvec.p, R, nvm * sizeof(double), hipMemcpyHostToDevice, c->st));
+    if (c->np > 0) {
+      if (Rp)
+        HIPCHK(hipMemcpyAsync(c->bvec.p + nvm, Rp, (nm - nvm) * sizeof(double), hipMemcpyHostToDevice, c->st));
+      else
+        HIPCHK(hipMemsetAsync(c->bvec.p + nvm, 0, (nm - nvm) * sizeof(double), c->st));
+    }
+    GmresResult r = gmres_solve(c, sd, c->bvec.p, c->xs.p, m, true, relres_out);
+    HIPCHK(hipMemcpyAsync(X_out, c->xs.p, nm * sizeof(double), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (iters_out) *iters_out = r.iters;
+    if (!r.converged) {
+      ricadi::set_error("GMRES did not reach the tolerance");
+      status = RICADI_ENOCONV;
+    }
+  } catch (const ricadi::HipError& e) {
+    ricadi::set_error(e.msg);
+    return RICADI_EHIP;
+  }
+  return status;
+}
+
+int ricadi_apply_e_dev(ricadi_ctx* c, double coef, const double* dV, int m, double* dW) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dV && dW, RICADI_EINVAL, "NULL panel");
+  API_BEGIN
+  launch_spmm(c->st, c->nv, c->E.rp.p, c->E.ci.p, c->E.v.p, dV, m, nullptr, dW, m, dW, m, coef, 1.0,
+              nullptr, m);
+  API_END
+}
+
+int ricadi_panel_norms_dev(ricadi_ctx* c, const double* dW, int nrows, int m, double* gram_fro,
+                           double* nrm2) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dW && nrows > 0, RICADI_EINVAL, "bad panel");
+  API_BEGIN
+  DScalar::gram_norms(c, dW, nrows, m, gram_fro, nrm2);
+  API_END
+}
+
+int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double* dX, int m,
+                         double* dY, int reps, double* ms_per_launch) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dX && dY && reps > 0 && ms_per_launch, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  ShiftData* sd = get_shift(c, alpha, beta);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  // plain assembled-CSR saddle SpMM only (no low-rank term): the roofline kernel
+  HIPCHK(hipEventRecord(e0, c->st));
+  for (int i = 0; i < reps; ++i)
+    launch_spmm(c->st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, dX, m, nullptr, dY, m, nullptr, 0,
+                1.0, 0.0, nullptr, m);
+  HIPCHK(hipEventRecord(e1, c->st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  API_END
+}
+
+int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W, int m,
+                    const ricadi_adi_params* prm, double* Z_out, int* c_out, double* stats_out) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(shifts && ns > 0 && W && prm, RICADI_EINVAL, "bad argument");
+  for (int i = 0; i < ns; ++i) REQUIRE(shifts[i] < 0.0, RICADI_EINVAL, "ADI shifts must be negative");
+  REQUIRE(prm->adi_max_steps > 0, RICADI_EINVAL, "adi_max_steps must be positive");
+  API_BEGIN
+  ensure_work(c, m);
+  factor_reserve(c, prm->adi_max_steps * m);
+  DArr<double> dW;
+  dW.alloc((size_t)c->nv * m);
+  HIPCHK(hipMemcpyAsync(dW.p, W, sizeof(double) * c->nv * m, hipMemcpyHostToDevice, c->st));
+  AdiStats s = lyap_adi_dev(c, shifts, ns, dW.p, m, *prm);
+  if (c_out) *c_out = c->zc;
+  if (Z_out && c->zc > 0) {
+    HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * c->zc, c->Z.p, sizeof(double) * c->zld,
+                            sizeof(double) * c->zc, c->nv, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
+  if (stats_out) {
+    stats_out[0] = s.steps;
+    stats_out[1] = s.rel;
+    stats_out[2] = (double)s.gmres_iters;
+    stats_out[3] = (double)s.shift_solves;
+    stats_out[4] = s.res_fro;
+  }
+  API_END
+}
+
+int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const double* B, int nb,
+                         const double* W, int mw, const double* Z0, int c0, const double* oldB,
+                         const ricadi_adi_params* prm, double* Z_out, int zcap, int* c_out,
+                         double* stats_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(shifts && ns > 0 && B && W && prm, RICADI_EINVAL, "bad argument");
+  REQUIRE(nb >= 1 && nb <= 64 && mw >= 1 && mw + nb <= RICADI_MAX_M, RICADI_EINVAL, "bad widths");
+  REQUIRE(c0 == 0 || Z0, RICADI_EINVAL, "Z0 is NULL");
+  for (int i = 0; i < ns; ++i) REQUIRE(shifts[i] < 0.0, RICADI_EINVAL, "ADI shifts must be negative");
+  API_BEGIN
+  hipStream_t st = c->st;
+  const int nv = c->nv;
+  const int mfull = mw + nb;
+  ensure_work(c, mfull);
+  DArr<double> dB, dWm, dOld, dK, dKall, dRhs, Zk, Znew;
+  dB.alloc((size_t)nv * nb);
+  dWm.alloc((size_t)nv * mw);
+  dK.alloc((size_t)nv * nb);
+  dKall.alloc((size_t)nv * nb);
+  dRhs.alloc((size_t)nv * mfull);
+  HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dWm.p, W, sizeof(double) * nv * mw, hipMemcpyHostToDevice, st));
+  if (oldB) {
+    dOld.alloc((size_t)nv * nb);
+    HIPCHK(hipMemcpyAsync(dOld.p, oldB, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
+  }
+  int kk = 0;  // columns of the current (compressed) iterate Zk
+  if (c0 > 0) {
+    Zk.alloc((size_t)nv * c0);
+    HIPCHK(hipMemcpyAsync(Zk.p, Z0, sizeof(double) * nv * c0, hipMemcpyHostToDevice, st));
+    kk = c0;
+  }
+  // the rhs factor W is projected once here; the K_k part is in range(P^T) already
+  ricadi_adi_params p2 = *prm;
+  if (prm->project_w) project_panel(c, dWm.p, mw);
+  p2.project_w = 0;
+  double upd = 0, updrel = 0;
+  long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves;
+  int steps = 0;
+  for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
+    int m = mw;
+    if (kk > 0) {
+      gain_dev(c, c->E, Zk.p, kk, kk, dB.p, nb, dK.p);
+      m = mfull;
+    } else {
+      HIPCHK(hipMemsetAsync(dK.p, 0, sizeof(double) * nv * nb, st));
+    }
+    // closed loop  cal A - (K_k - old) B^T
+    HIPCHK(hipMemcpyAsync(dKall.p, dK.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
+    if (oldB) launch_axpby(st, (size_t)nv * nb, -1.0, dOld.p, 1.0, dKall.p);
+    const bool lr = (kk > 0) || oldB;
+    c->q = lr ? nb : 0;
+    if (lr) {
+      c->U.ensure((size_t)nv * nb);
+      c->V.ensure((size_t)nv * nb);
+      HIPCHK(hipMemcpyAsync(c->U.p, dKall.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->V.p, dB.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
+    }
+    // rhs = [W, K_k]
+    launch_copy_cols(st, nv, mw, dWm.p, mw, 0, dRhs.p, m, 0, 1.0);
+    if (m > mw) launch_copy_cols(st, nv, nb, dK.p, nb, 0, dRhs.p, m, mw, 1.0);
+    factor_reserve(c, prm->adi_max_steps * m);
+    AdiStats s = lyap_adi_dev(c, shifts, ns, dRhs.p, m, p2);
+    adi_total += s.steps;
+    // compressed copy of the new iterate (relative threshold at rounding level)
+    Znew.alloc((size_t)nv * c->zc);
+    int knew = compress_dev(c, c->Z.p, c->zc, c->zld, 1e-14, 0, true, Znew.p, nullptr);
+    double x1 = 0.0;
+    upd = diff_zzt_fnorm(c, Znew.p, knew, Zk.p, kk, &x1);
+    updrel = x1 > 0.0 ? upd / x1 : 0.0;
+    if (prm->verbose)
+      fprintf(stderr, "[ricadi] Newton step %2d: |upd| %9.3e rel %9.3e (%d ADI steps, %d -> %d columns)\n",
+              steps, upd, updrel, s.steps, c->zc, knew);
+    std::swap(Zk.p, Znew.p);
+    std::swap(Zk.n, Znew.n);
+    kk = knew;
+    if (upd < prm->nwtn_upd_abstol || updrel < prm->nwtn_upd_reltol) break;
+  }
+  if (steps > prm->nwtn_max_steps) steps = prm->nwtn_max_steps;
+  c->q = 0;
+  if (c_out) *c_out = c->zc;
+  if (Z_out && c->zc > 0) {
+    if (c->zc > zcap) throw ricadi::HipError{"Z_out capacity too small"};
+    HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * c->zc, c->Z.p, sizeof(double) * c->zld,
+                            sizeof(double) * c->zc, nv, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (stats_out) {
+    stats_out[0] = steps;
+    stats_out[1] = upd;
+    stats_out[2] = updrel;
+    stats_out[3] = (double)adi_total;
+    stats_out[4] = (double)(c->total_iters - it0);
+    stats_out[5] = (double)(c->total_solves - sol0);
+  }
+  API_END
+}
+
+int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int kmax, double* Zc_out,
+                    int* k_out, double* sv_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(Zc_out && k_out, RICADI_EINVAL, "NULL output");
+  API_BEGIN
+  const double* dZ;
+  int ld;
+  DArr<double> tmp, out;
+  if (Z) {
+    REQUIRE(cz > 0, RICADI_EINVAL, "bad column count");
+    tmp.alloc((size_t)c->nv * cz);
+    HIPCHK(hipMemcpyAsync(tmp.p, Z, sizeof(double) * c->nv * cz, hipMemcpyHostToDevice, c->st));
+    dZ = tmp.p;
+    ld = cz;
+  } else {
+    REQUIRE(c->zc > 0, RICADI_ESTATE, "no device-resident factor");
+    dZ = c->Z.p;
+    cz = c->zc;
+    ld = c->zld;
+  }
+  out.alloc((size_t)c->nv * cz);
+  std::vector<double> sv;
+  int k = compress_dev(c, dZ, cz, ld, thresh, kmax, false, out.p, &sv);
+  *k_out = k;
+  if (k > 0) {
+    HIPCHK(hipMemcpyAsync(Zc_out, out.p, sizeof(double) * c->nv * k, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
+  if (sv_out) std::memcpy(sv_out, sv.data(), sizeof(double) * std::min<size_t>(sv.size(), (size_t)std::min(cz, c->nv)));
+  API_END
+}
+
+int ricadi_gain(ricadi_ctx* c, const int32_t* mt_rp, const int32_t* mt_ci, const double* mt_v,
+                const double* Z, int cz, const double* B, int nb, double* K_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(B && K_out && nb >= 1 && nb <= RICADI_MAX_M, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  const int nv = c->nv;
+  DArr<double> dZ, dB, dK;
+  const double* z;
+  int ld;
+  if (Z) {
+    REQUIRE(cz > 0, RICADI_EINVAL, "bad column count");
+    dZ.alloc((size_t)nv * cz);
+    HIPCHK(hipMemcpyAsync(dZ.p, Z, sizeof(double) * nv * cz, hipMemcpyHostToDevice, c->st));
+    z = dZ.p;
+    ld = cz;
+  } else {
+    REQUIRE(c->zc > 0, RICADI_ESTATE, "no device-resident factor");
+    z = c->Z.p;
+    cz = c->zc;
+    ld = c->zld;
+  }
+  dB.alloc((size_t)nv * nb);
+  dK.alloc((size_t)nv * nb);
+  HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * nv * nb, hipMemcpyHostToDevice, c->st));
+  if (mt_rp) {
+    HostCsr Mt = make_csr(nv, nv, mt_rp, mt_ci, mt_v);
+    DevCsr dMt;
+    dMt.upload(Mt, c->st);
+    gain_dev(c, dMt, z, cz, ld, dB.p, nb, dK.p);
+  } else {
+    gain_dev(c, c->E, z, cz, ld, dB.p, nb, dK.p);
+  }
+  HIPCHK(hipMemcpyAsync(K_out, dK.p, sizeof(double) * nv * nb, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_lyap_res_norm(ricadi_ctx* c, const double* Z, int cz, const double* W, int m,
+                         double* res2_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(Z && W && res2_out && cz > 0 && m > 0, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  hipStream_t st = c->st;
+  const int nv = c->nv, wtot = 2 * cz + m;
+  DArr<double> dZ, S, chunk, G;
+  dZ.alloc((size_t)nv * cz);
+  S.alloc((size_t)nv * wtot);       // [cal A_eff Z, cal E Z, W], ld = wtot
+  HIPCHK(hipMemcpyAsync(dZ.p, Z, sizeof(double) * nv * cz, hipMemcpyHostToDevice, st));
+  {
+    DArr<double> dWh;
+    dWh.alloc((size_t)nv * m);
+    HIPCHK(hipMemcpyAsync(dWh.p, W, sizeof(double) * nv * m, hipMemcpyHostToDevice, st));
+    launch_copy_cols(st, nv, m, dWh.p, m, 0, S.p, wtot, 2 * cz, 1.0);
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  // cal A Z and cal E Z in column chunks of <= 64
+  const int CH = 64;
+  chunk.alloc((size_t)c->n * CH * 2);
+  double* in = chunk.p;
+  double* out = chunk.p + (size_t)c->n * CH;
+  for (int c0 = 0; c0 < cz; c0 += CH) {
+    const int w = std::min(CH, cz - c0);
+    launch_copy_cols(st, nv, w, dZ.p, cz, c0, in, w, 0, 1.0);
+    launch_spmm(st, nv, c->A.rp.p, c->A.ci.p, c->A.v.p, in, w, nullptr, out, w, nullptr, 0, 1.0, 0.0, nullptr, w);
+    if (c->q > 0) {
+      c->lrc.ensure((size_t)c->q * w + 64);
+      HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * c->q * w, st));
+      launch_gemm_tn(st, nv, c->q, w, c->V.p, c->q, in, w, c->lrc.p, w);
+      launch_gemm_nn(st, nv, c->q, w, c->U.p, c->q, c->lrc.p, w, out, w, -1.0, 1.0);
+    }
+    launch_copy_cols(st, nv, w, out, w, 0, S.p, wtot, c0, 1.0);
+    launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, in, w, nullptr, out, w, nullptr, 0, 1.0, 0.0, nullptr, w);
+    launch_copy_cols(st, nv, w, out, w, 0, S.p, wtot, cz + c0, 1.0);
+  }
+  // project every column: P^T s
+  const int saved_q = c->q;
+  for (int c0 = 0; c0 < wtot; c0 += CH) {
+    const int w = std::min(CH, wtot - c0);
+    launch_copy_cols(st, nv, w, S.p, wtot, c0, in, w, 0, 1.0);
+    project_panel(c, in, w);
+    launch_copy_cols(st, nv, w, in, w, 0, S.p, wtot, c0, 1.0);
+  }
+  c->q = saved_q;
+  G.alloc((size_t)wtot * wtot);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * wtot * wtot, st));
+  launch_gemm_tn(st, nv, wtot, wtot, S.p, wtot, S.p, wtot, G.p, wtot);
+  std::vector<double> Gh((size_t)wtot * wtot);
+  HIPCHK(hipMemcpyAsync(Gh.data(), G.p, sizeof(double) * wtot * wtot, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // residual = U S U^T with U = [G, H, Wp], S swaps the first two blocks;
+  // ||.||_F^2 = trace(S Gram S Gram)
+  auto perm = [&](int i) { return i < cz ? i + cz : (i < 2 * cz ? i - cz : i); };
+  double tr = 0.0;
+  for (int i = 0; i < wtot; ++i)
+    for (int j = 0; j < wtot; ++j)
+      tr += Gh[(size_t)perm(i) * wtot + j] * Gh[(size_t)perm(j) * wtot + i];
+  *res2_out = tr;
+  API_END
+}
+
+int ricadi_factor_cols(ricadi_ctx* c, int* c_out) {
+  REQUIRE(c && c_out, RICADI_EINVAL, "NULL argument");
+  *c_out = c->zc;
+  return RICADI_OK;
+}
+
+int ricadi_factor_get(ricadi_ctx* c, double* Z_out, int cz) {
+  REQUIRE(c && Z_out, RICADI_EINVAL, "NULL argument");
+  REQUIRE(cz == c->zc && cz > 0, RICADI_EINVAL, "column count does not match the device factor");
+  API_BEGIN
+  HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * cz, c->Z.p, sizeof(double) * c->zld,
+                          sizeof(double) * cz, c->nv, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_factor_set(ricadi_ctx* c, const double* Z, int cz) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(Z && cz > 0, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  factor_reserve(c, cz);
+  HIPCHK(hipMemcpyAsync(c->Z.p, Z, sizeof(double) * c->nv * cz, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  c->zc = cz;
+  API_END
+}
+
+}  // extern "C"
