@@ -97,6 +97,10 @@ int ricadi_set_operator(ricadi_ctx* ctx, int nv, int np,
                         const int32_t* e_rowptr, const int32_t* e_col, const double* e_val,
                         const int32_t* j_rowptr, const int32_t* j_col, const double* j_val);
 
+/* Dimension-only context (no operator): enough for ricadi_compress and for
+ * ricadi_gain with an explicit `mt_*` matrix, which need NV only.           */
+int ricadi_set_dims(ricadi_ctx* ctx, int nv);
+
 /* Low-rank term  - U * Vt ;  U is NV x q row-major, V is NV x q row-major
  * (i.e. Vt = V^T).  q = 0 removes it.  Stands behind the umat / vmat
  * arguments of lau.solve_sadpnt_smw (/root/reference/solve_dae_ric.py:192-194,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "ricadi_synchronize": (C.c_int, [_vp]),
     "ricadi_set_operator": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp,
                                       _ip, _ip, _dp]),
+    "ricadi_set_dims": (C.c_int, [_vp, C.c_int]),
     "ricadi_set_lowrank": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "ricadi_spmm": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
     "ricadi_precond_apply": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
@@ -235,6 +236,11 @@ class Context:
                                                _i(erp), _i(eci), _d(ev), None, None, None))
         self.nv, self.np_ = nv, np_
         self.n = nv + np_
+
+    def set_dims(self, nv):
+        """Dimension-only context: enough for compress() and gain(MT=...)."""
+        _chk(self._lib.ricadi_set_dims(self._h, int(nv)))
+        self.nv, self.np_, self.n = int(nv), 0, int(nv)
 
     def set_lowrank(self, U=None, V=None):
         """Operator becomes ``beta*A + alpha*E - U V^T`` (both NV x q)."""

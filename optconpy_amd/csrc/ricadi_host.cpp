@@ -224,6 +224,12 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   std::vector<int> va(nv), pa(std::max(np, 1));
   int kv = 0, kp = 0;
   for (int attempt = 0; attempt < 16; ++attempt) {
+    // The coarse pressure aggregates must not coincide with the Schur
+    // block-Jacobi blocks (same graph, same greedy rule, same size): with
+    // identical partitions the multiplicative two-level cycle stagnates
+    // (measured: N=40, ap == bs == 32 stalls at 1e-2, ap in {16,24,48,64}
+    // converges in 137-182 iterations).
+    if (ap == bs) ap = ap + ap / 2;
     kv = aggregate(nv, g_rp, g_ci, av, va.data());
     kp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), ap, pa.data()) : 0;
     if (kv + kp <= std::max(16, o.coarse_max)) break;

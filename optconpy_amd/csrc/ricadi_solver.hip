@@ -589,7 +589,7 @@ void ricadi_default_opts(ricadi_opts* o) {
   o->gmres_maxit = 3000;
   o->bj_block = 32;
   o->agg_v = 16;
-  o->agg_p = 32;
+  o->agg_p = 24;
   o->coarse_max = 4096;
   o->use_coarse = 1;
   o->verbose = 0;
@@ -728,6 +728,19 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
     fprintf(stderr, "[ricadi] operator nv=%d np=%d nnz(S)=%zu | BJ blocks %d+%d (bs=%d) | coarse %d (%d+%d)\n",
             nv, np, c->snnz, c->nbv, c->nbp, c->bs, c->kc, hs.kcv, hs.kcp);
   API_END
+}
+
+int ricadi_set_dims(ricadi_ctx* c, int nv) {
+  REQUIRE(c && nv > 0, RICADI_EINVAL, "bad argument");
+  c->cache.clear();
+  c->has_op = false;
+  c->nv = nv;
+  c->np = 0;
+  c->n = nv;
+  c->q = 0;
+  c->zc = 0;
+  c->wm = 0;
+  return RICADI_OK;
 }
 
 int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
@@ -1015,7 +1028,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
 
 int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int kmax, double* Zc_out,
                     int* k_out, double* sv_out) {
-  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(c && c->nv > 0, RICADI_ESTATE, "set the operator (or the dimensions) first");
   REQUIRE(Zc_out && k_out, RICADI_EINVAL, "NULL output");
   API_BEGIN
   const double* dZ;
@@ -1047,7 +1060,8 @@ int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int k
 
 int ricadi_gain(ricadi_ctx* c, const int32_t* mt_rp, const int32_t* mt_ci, const double* mt_v,
                 const double* Z, int cz, const double* B, int nb, double* K_out) {
-  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(c && c->nv > 0, RICADI_ESTATE, "set the operator (or the dimensions) first");
+  REQUIRE(mt_rp || c->has_op, RICADI_ESTATE, "no cal E in the context: pass mt_* explicitly");
   REQUIRE(B && K_out && nb >= 1 && nb <= RICADI_MAX_M, RICADI_EINVAL, "bad argument");
   API_BEGIN
   const int nv = c->nv;
