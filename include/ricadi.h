@@ -190,6 +190,11 @@ int ricadi_shift_solve_dev(ricadi_ctx* ctx, double alpha, double beta,
                            int* iters_out, double* relres_out);
 /* dW (NV x m) += coef * E * dV (first NV rows of an n x m or NV x m panel) */
 int ricadi_apply_e_dev(ricadi_ctx* ctx, double coef, const double* dV, int m, double* dW);
+/* dOut (nrows x m) = sum_i coef[i] * panel_i, panel_i = dBasis + i*stride
+ * (stride in doubles); coef is a host array.  Used by the shift-parallel
+ * Cauchy recombination.                              */
+int ricadi_lincomb_dev(ricadi_ctx* ctx, int nrows, int m, int nvec, const double* dBasis,
+                       int64_t stride, const double* coef, double* dOut);
 /* Frobenius norms of the m columns' Gram matrix: out = ||W^T W||_F, and the
  * squared F-norm of the panel in nrm2 (both may be NULL).                  */
 int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "ricadi_shift_solve_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp,
                                          C.POINTER(C.c_int), _dp]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
+    "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
     "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
                                        _dp]),
@@ -93,6 +94,14 @@ def load():
             "libricadi_hip.so is missing ({0}); build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` -- there is no "
             "CPU fallback for the HIP path".format(LIB_PATH))
+    # torch wheels bundle their own ROCm runtime (libamdhip64 / rocblas /
+    # rocsolver, same SONAMEs as /opt/rocm).  Two HIP runtimes in one process
+    # crash, so torch -- needed anyway for torch.distributed -- is imported
+    # first and our NEEDED entries then bind to the already loaded copies.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -394,6 +403,11 @@ class Context:
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):
         _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))
+
+    def lincomb_dev(self, nrows, m, coef, basis_ptr, stride, out_ptr):
+        cf = np.ascontiguousarray(coef, dtype=np.float64)
+        _chk(self._lib.ricadi_lincomb_dev(self._h, nrows, m, cf.size, basis_ptr, int(stride),
+                                          _d(cf), out_ptr))
 
     def panel_norms_dev(self, w_ptr, nrows, m):
         g = C.c_double(0.0)

@@ -1,0 +1,82 @@
+"""Process-wide HIP context management for the host-side mirror.
+
+The reference is single-threaded and re-passes its matrices with every call
+(``solve_dae_ric.py:152-159,192-194``); to keep that calling convention cheap
+one :class:`optconpy_amd._lib.Context` per process is kept alive and the
+operator is re-uploaded only when its fingerprint changes.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _lib
+
+_ctx = None
+_ctx_key = None
+_opts = {}
+
+
+def configure(**opts):
+    """Set inner-solver options (see ``ricadi_opts`` in include/ricadi.h).
+
+    Takes effect for the next operator; drops the cached context.
+    """
+    global _opts
+    _opts = dict(opts)
+    reset()
+
+
+def reset():
+    global _ctx, _ctx_key
+    if _ctx is not None:
+        _ctx.close()
+    _ctx = None
+    _ctx_key = None
+
+
+def device_id():
+    return int(os.environ.get("LOCAL_RANK", os.environ.get("RICADI_DEVICE", "0")))
+
+
+def _fingerprint(m):
+    if m is None:
+        return None
+    m = sps.csr_matrix(m)
+    d = m.data
+    return (m.shape, m.nnz, float(d.sum()) if d.size else 0.0,
+            float(np.abs(d).sum()) if d.size else 0.0,
+            int(m.indices[:64].sum()) if m.nnz else 0,
+            float(d[::max(1, d.size // 97)].dot(np.arange(d[::max(1, d.size // 97)].size)))
+            if d.size else 0.0)
+
+
+def context():
+    """The process-wide context (created on first use; needs a GPU)."""
+    global _ctx
+    if _ctx is None:
+        _ctx = _lib.Context(device_id(), **_opts)
+    return _ctx
+
+
+def context_for(calA, calE, J):
+    """Context with the operator ``[[beta*calA + alpha*calE, J^T],[J,0]]`` set."""
+    global _ctx_key
+    key = (_fingerprint(calA), _fingerprint(calE), _fingerprint(J))
+    ctx = context()
+    if key != _ctx_key:
+        ctx.set_operator(calA, calE, J)
+        _ctx_key = key
+    return ctx
+
+
+def context_dims(nv):
+    """Context that only knows NV (compression, explicit-matrix gain)."""
+    global _ctx_key
+    ctx = context()
+    if ctx.nv != nv:
+        ctx.set_dims(nv)
+        _ctx_key = ("dims", nv)
+    return ctx

@@ -270,7 +270,9 @@ int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1) {
       double s = -1.0 / (shifts[i] + shifts[j]);
       for (int k = 0; k < j; ++k) s -= L[(size_t)i * g + k] * L[(size_t)j * g + k];
       if (i == j) {
-        if (!(s > 0.0)) return RICADI_EBREAKDOWN;
+        // relative test: a numerically singular Cauchy matrix (repeated or
+        // too many shifts) must not slip through on a rounding-level pivot
+        if (!(s > 1e-13 * (-0.5 / shifts[i]))) return RICADI_EBREAKDOWN;
         L[(size_t)i * g + i] = std::sqrt(s);
       } else {
         L[(size_t)i * g + j] = s / L[(size_t)j * g + j];

@@ -664,7 +664,9 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
                         const double* j_v) {
   REQUIRE(c, RICADI_EINVAL, "NULL ctx");
   REQUIRE(nv > 0 && np >= 0, RICADI_EINVAL, "bad sizes");
-  REQUIRE(a_rp && a_ci && a_v && e_rp && e_ci && e_v, RICADI_EINVAL, "NULL matrix");
+  REQUIRE(a_rp && e_rp, RICADI_EINVAL, "NULL matrix");
+  REQUIRE((a_ci && a_v) || a_rp[nv] == 0, RICADI_EINVAL, "NULL matrix arrays");
+  REQUIRE((e_ci && e_v) || e_rp[nv] == 0, RICADI_EINVAL, "NULL matrix arrays");
   REQUIRE(np == 0 || (j_rp && j_ci && j_v), RICADI_EINVAL, "NULL J");
   API_BEGIN
   HIPCHK(hipSetDevice(c->dev));
@@ -863,6 +865,23 @@ int ricadi_apply_e_dev(ricadi_ctx* c, double coef, const double* dV, int m, doub
   API_BEGIN
   launch_spmm(c->st, c->nv, c->E.rp.p, c->E.ci.p, c->E.v.p, dV, m, nullptr, dW, m, dW, m, coef, 1.0,
               nullptr, m);
+  API_END
+}
+
+int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* dBasis,
+                       int64_t stride, const double* coef, double* dOut) {
+  REQUIRE(c && dBasis && coef && dOut, RICADI_EINVAL, "NULL argument");
+  REQUIRE(nrows > 0 && m >= 1 && m <= RICADI_MAX_M && nvec >= 1 && nvec <= 64, RICADI_EINVAL,
+          "bad sizes");
+  API_BEGIN
+  std::vector<double> h((size_t)nvec * m);
+  for (int i = 0; i < nvec; ++i)
+    for (int j = 0; j < m; ++j) h[(size_t)i * m + j] = coef[i];
+  c->lrc.ensure((size_t)nvec * m + 64);
+  HIPCHK(hipMemcpyAsync(c->lrc.p, h.data(), sizeof(double) * nvec * m, hipMemcpyHostToDevice, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  launch_cols_update(c->st, nrows, m, nvec, dBasis, (size_t)stride, c->lrc.p, 1.0, nullptr, nullptr,
+                     dOut);
   API_END
 }
 

@@ -1,0 +1,147 @@
+"""Host-side mirror of ``sadptprj_riclyap_adi.proj_ric_utils`` on the HIP path.
+
+Same names, keyword arguments and return conventions as the functions optconpy
+calls (``/root/reference/optcont_main.py:488-492,498-499,505-506``;
+``/root/reference/solve_dae_ric.py:101,152-159,162-163,183,189``;
+``/root/reference/tests/test_units_compfacres_compress.py:62-64,82,92,104``).
+The arithmetic runs in ``libricadi_hip.so`` on the GPU; this module only
+normalises the inputs (csr / csc / scaled / transposed sparse matrices, C-order
+float64 panels) and resolves the ``transposed`` flag into the orientation the
+C-ABI expects.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _lib, backend
+
+__all__ = [
+    "solve_proj_lyap_stein", "proj_alg_ric_newtonadi", "compress_Zsvd",
+    "get_mTzzTtb", "comp_proj_lyap_res_norm", "DEFAULT_MS",
+]
+
+# Built-in shift list for an ``adi_dict`` without ``'ms'``
+# (tests/test_units_compfacres_compress.py:54-64 relies on such a default; the
+# upstream values are not in the container) [INFERRED].
+DEFAULT_MS = [-30.0, -20.0, -10.0, -5.0, -3.0, -1.0]
+
+
+def _dense(a):
+    if sps.issparse(a):
+        return np.asarray(a.todense())
+    a = np.asarray(a, dtype=float)
+    return a.reshape(-1, 1) if a.ndim == 1 else a
+
+
+def _orient(amat, mmat, transposed):
+    amat = sps.csr_matrix(amat)
+    mmat = sps.csr_matrix(mmat)
+    if transposed:
+        return amat, mmat
+    return amat.T.tocsr(), mmat.T.tocsr()
+
+
+def _shifts(d):
+    ms = list(d.get("ms", DEFAULT_MS))
+    if any((not np.isreal(p)) or p >= 0 for p in ms):
+        raise ValueError("ADI shifts must be negative real numbers")
+    return [float(p) for p in ms]
+
+
+def solve_proj_lyap_stein(amat=None, mmat=None, jmat=None, wmat=None,
+                          umat=None, vmat=None, transposed=False,
+                          adi_dict=None, nwtn_adi_dict=None, **kw):
+    """Low-rank ADI for ``F^T X M + M^T X F + W W^T = 0`` on ker(J M^-1 ...).
+
+    ``F = amat - umat*vmat``; ``transposed=True`` swaps the roles
+    (``F X M^T + M X F^T``).  Signature and ``['zfac']`` return as at
+    ``tests/test_units_compfacres_compress.py:62-64``.
+    """
+    d = nwtn_adi_dict if adi_dict is None else adi_dict
+    d = {} if d is None else d
+    calA, calE = _orient(amat, mmat, transposed)
+    ctx = backend.context_for(calA, calE, jmat)
+    # low-rank term in cal A's orientation:  cal A - U V^T
+    if umat is not None and vmat is not None:
+        if transposed:
+            ctx.set_lowrank(_dense(umat), _dense(vmat).T)
+        else:                      # (amat - U V)^T = amat^T - V^T U^T
+            ctx.set_lowrank(_dense(vmat).T, _dense(umat))
+    else:
+        ctx.set_lowrank(None, None)
+    prm = _lib.adi_params(d)
+    W = _dense(wmat)
+    try:
+        if W.shape[1] > _lib.MAX_M:
+            raise ValueError("right-hand side factor wider than {0} columns".format(_lib.MAX_M))
+        Z, info = ctx.lyap_adi(_shifts(d), W, prm)
+    finally:
+        ctx.set_lowrank(None, None)
+    out = dict(zfac=Z)
+    out.update(info)
+    return out
+
+
+def proj_alg_ric_newtonadi(mmat=None, amat=None, jmat=None, bmat=None,
+                           wmat=None, z0=None, mtxoldb=None,
+                           transposed=False, nwtn_adi_dict=None, **kw):
+    """Newton-Kleinman ADI for the projected algebraic Riccati equation.
+
+    ``cal A X cal E^T + cal E X cal A^T - cal E X B B^T X cal E^T + W W^T = 0``
+    with ``cal A = amat^T``, ``cal E = mmat^T`` (as given if ``transposed``).
+    Call sites: ``optcont_main.py:488-492`` (steady state),
+    ``solve_dae_ric.py:152-159`` (one call per backward time step).  Returns a
+    dict whose ``'zfac'`` is the low-rank factor.
+    """
+    d = {} if nwtn_adi_dict is None else nwtn_adi_dict
+    calA, calE = _orient(amat, mmat, transposed)
+    ctx = backend.context_for(calA, calE, jmat)
+    ctx.set_lowrank(None, None)
+    prm = _lib.adi_params(d)
+    Z, info = ctx.ric_newtonadi(_shifts(d), _dense(bmat), _dense(wmat), prm,
+                                Z0=None if z0 is None else _dense(z0),
+                                oldB=None if mtxoldb is None else _dense(mtxoldb))
+    out = dict(zfac=Z)
+    out.update(info)
+    return out
+
+
+def compress_Zsvd(Z, thresh=None, k=None, shplot=False):
+    """Column compression ``Zc Zc^T ~ Z Z^T`` (``solve_dae_ric.py:162-163``).
+
+    Keeps the singular values above ``thresh`` (absolute) and at most ``k``.
+    On the GPU: Gram matrix ``Z^T Z`` on the FP64 matrix cores, symmetric
+    eigendecomposition, ``Zc = Z V_k``.  ``shplot`` is accepted and ignored.
+    """
+    Z = _dense(Z)
+    ctx = backend.context_dims(Z.shape[0])
+    Zc, _ = ctx.compress(Z, thresh=thresh, k=k)
+    return Zc
+
+
+def get_mTzzTtb(MT, Z, tb, output=None):
+    """``MT * (Z * (Z^T * tb))``; the feedback gain is its negative
+    (``optcont_main.py:505-506``; ``solve_dae_ric.py:101,183,189``)."""
+    Z = _dense(Z)
+    ctx = backend.context_dims(Z.shape[0])
+    return ctx.gain(_dense(tb), Z=Z, MT=sps.csr_matrix(MT))
+
+
+def comp_proj_lyap_res_norm(Z, amat=None, mmat=None, wmat=None, jmat=None,
+                            umat=None, vmat=None):
+    """Squared Frobenius norm of the projected Lyapunov residual from factors.
+
+    Positional use ``comp_proj_lyap_res_norm(Z, F, M, W, J)`` as at
+    ``tests/test_units_compfacres_compress.py:82,104``.
+    """
+    calA, calE = _orient(amat, mmat, False)
+    ctx = backend.context_for(calA, calE, jmat)
+    if umat is not None and vmat is not None:
+        ctx.set_lowrank(_dense(vmat).T, _dense(umat))
+    else:
+        ctx.set_lowrank(None, None)
+    try:
+        return ctx.lyap_res_norm(_dense(Z), _dense(wmat))
+    finally:
+        ctx.set_lowrank(None, None)

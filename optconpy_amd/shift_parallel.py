@@ -1,0 +1,161 @@
+"""Shift-parallel low-rank ADI: one ADI shift per GPU, one all-gather per sweep.
+
+The textbook LR-ADI recurrence is sequential in the shifts.  Its Cauchy form
+ is not: in a *sweep* of ``G`` distinct real
+shifts every rank ``g`` solves
+
+    S(p_g) [U_g; L] = [W_s; 0]
+
+against the **same** residual factor ``W_s`` (operator replicated, no data-path
+dependency), the ``U_g`` are all-gathered (RCCL over xGMI on the GPUs, gloo in
+the CPU tests), and every rank recombines them redundantly with the ``G x G``
+Cauchy matrix ``C_ij = -1/(p_i + p_j) = R^T R``:
+
+    Z-block  = U (R^-1 (x) I_m),        W_{s+1} = W_s + E U ((C^-1 1) (x) I_m)
+
+which reproduces ``G`` sequential ADI steps exactly (up to a rotation of the
+block's columns; ``Z Z^T`` and hence the gain ``K`` are identical).
+
+The reference has nothing distributed; this is new
+design.  The local operations are behind a small ``ops`` object so the same
+orchestration runs on ``torch.cuda`` tensors + ``libricadi_hip.so``
+(:class:`HipOps`) and, in the CPU test-suite, on CPU tensors with injected
+solves.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+class HipOps:
+    """Local panel operations on device tensors through the C-ABI."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.gmres_iters = 0
+        self.shift_solves = 0
+
+    def to_panel(self, W):
+        return torch.as_tensor(np.ascontiguousarray(W), dtype=torch.float64).to(self.device)
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float64, device=self.device)
+
+    def _sync_in(self):
+        # torch's stream -> ricadi's stream hand-off (both orders are rare: once per sweep)
+        torch.cuda.current_stream().synchronize()
+
+    def solve(self, p, W):
+        """First NV rows of ``S(p,1)^-1 [W; 0]`` as a new NV x m tensor."""
+        ctx = self.ctx
+        m = W.shape[1]
+        X = self.empty(ctx.n, m)
+        self._sync_in()
+        its, _ = ctx.shift_solve_dev(float(p), 1.0, W.data_ptr(), m, X.data_ptr(), strict=False)
+        ctx.synchronize()
+        self.gmres_iters += its
+        self.shift_solves += 1
+        return X[:ctx.nv].contiguous()
+
+    def lincomb(self, coef, U_all):
+        """``sum_i coef[i] * U_all[i]``; ``U_all`` is G x NV x m, contiguous."""
+        G, nv, m = U_all.shape
+        out = self.empty(nv, m)
+        self._sync_in()
+        self.ctx.lincomb_dev(nv, m, coef, U_all.data_ptr(), nv * m, out.data_ptr())
+        self.ctx.synchronize()
+        return out
+
+    def apply_E(self, coef, V, W):
+        """``W += coef * E * V`` in place."""
+        self._sync_in()
+        self.ctx.apply_e_dev(float(coef), V.data_ptr(), V.shape[1], W.data_ptr())
+        self.ctx.synchronize()
+
+    def fro2(self, T):
+        self._sync_in()
+        _, t = self.ctx.panel_norms_dev(T.data_ptr(), T.shape[0], T.shape[1])
+        return t
+
+    def gram_fro(self, T):
+        self._sync_in()
+        g, _ = self.ctx.panel_norms_dev(T.data_ptr(), T.shape[0], T.shape[1])
+        return g
+
+
+def sweep_shifts(ms, sweep, G):
+    """Shifts of sweep ``sweep``: ADI steps ``sweep*G+1 .. (sweep+1)*G`` of the cycle."""
+    ns = len(ms)
+    return [float(ms[(sweep * G + g) % ns]) for g in range(G)]
+
+
+def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
+                            group=None, width=None, max_width=8, verbose=False):
+    """Shift-parallel LR-ADI; returns ``(Z_blocks, info)``.
+
+    ``W`` is the (already projected) NV x m residual factor as a tensor on the
+    ops' device, replicated on every rank.  Each sweep handles ``G`` distinct
+    shifts, ``G = width`` or ``min(world_size, len(ms), max_width)`` (Cauchy
+    conditioning limits ``G``: SURVEY.md F8); shift ``g`` of the sweep is
+    solved by rank ``g % world_size``, so ``G`` may exceed the number of ranks.
+    Stops after the sweep in which the mean new-block norm falls below
+    ``adi_newZ_reltol`` (the sequential rule of ``optcont_main.py:123-124`` at
+    sweep granularity) or after ``adi_max_steps`` steps.
+    """
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    ns = len(ms)
+    G = int(width) if width else max(1, min(world, ns, max_width))
+    if G > ns:
+        raise ValueError("sweep width {0} exceeds the number of shifts {1}".format(G, ns))
+    per_rank = (G + world - 1) // world
+    nv, m = W.shape
+    W = W.clone()
+    blocks = []
+    znorm2 = 0.0
+    steps = 0
+    rel = float("inf")
+    nsweeps = 0
+    while steps + G <= adi_max_steps or steps == 0:
+        ps = sweep_shifts(ms, nsweeps, G)
+        if len(set(ps)) != G:
+            raise ValueError("shifts within one sweep must be distinct: {0}".format(ps))
+        mine = [g for g in range(G) if g % world == rank]
+        local = [ops.solve(ps[g], W) for g in mine]
+        while len(local) < per_rank:
+            local.append(torch.zeros_like(W))
+        U_loc = torch.stack(local, dim=0).contiguous()
+        if world > 1:
+            gathered = [torch.empty_like(U_loc) for _ in range(world)]
+            dist.all_gather(gathered, U_loc, group=group)
+            U_all = torch.stack([gathered[g % world][g // world] for g in range(G)],
+                                dim=0).contiguous()
+        else:
+            U_all = U_loc[:G].contiguous()
+        rinv, cinv1 = _lib.host_cauchy(ps)
+        n2 = 0.0
+        for j in range(G):
+            Zj = ops.lincomb(rinv[:, j], U_all)
+            n2 += ops.fro2(Zj)
+            blocks.append(Zj)
+        T = ops.lincomb(cinv1, U_all)
+        ops.apply_E(1.0, T, W)
+        znorm2 += n2
+        steps += G
+        nsweeps += 1
+        rel = float(np.sqrt(n2 / G / znorm2)) if znorm2 > 0 else 0.0
+        if verbose and rank == 0:
+            print("sweep {0:3d}: shifts {1} rel new Z {2:9.3e}".format(nsweeps, ps, rel))
+        if rel < adi_newZ_reltol:
+            break
+    info = dict(adi_steps=steps, sweeps=nsweeps, width=G, adi_rel_newZ=rel,
+                res_fro=ops.gram_fro(W), resfac=W)
+    return blocks, info

@@ -1,0 +1,97 @@
+"""C-ABI library: loads without a GPU, exports every declared symbol, host logic."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+from optconpy_amd import _lib, problems as pb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ricadi.h")).read()
+    declared = set(re.findall(r"\b(ricadi_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ricadi_ctx", "ricadi_opts", "ricadi_adi_params"}
+    assert len(declared) >= 25
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "symbol missing from libricadi_hip.so: " + name
+        assert name in _lib.SIGNATURES, "ctypes signature missing: " + name
+    assert set(_lib.SIGNATURES) <= declared
+
+
+def test_defaults_follow_reference():
+    p = _lib.adi_params(None)          # optcont_main.py:122-131
+    assert (p.adi_max_steps, p.nwtn_max_steps) == (200, 16)
+    assert (p.adi_newZ_reltol, p.nwtn_upd_reltol, p.nwtn_upd_abstol) == (1e-8, 5e-8, 1e-7)
+    p = _lib.adi_params(dict(adi_max_steps=7, unknown_key=1, verbose=True, ms=[-1.0]))
+    assert p.adi_max_steps == 7 and p.verbose == 1
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        _lib.Context(0)
+
+
+def test_host_aggregate_partition():
+    sm = pb.stokes_system(6, nu=1.0)
+    M = sm["M"]
+    blk, nb = _lib.host_aggregate(M, 16)
+    assert blk.min() == 0 and blk.max() == nb - 1
+    cnt = np.bincount(blk)
+    assert cnt.max() <= 16 and cnt.min() >= 1 and cnt.sum() == M.shape[0]
+    # aggregates are connected in the graph of M and never mix the two
+    # velocity components (M is block diagonal over components)
+    half = M.shape[0] // 2
+    for b in range(nb):
+        idx = np.flatnonzero(blk == b)
+        assert (idx < half).all() or (idx >= half).all()
+        sub = M[idx][:, idx]
+        ncomp, _ = sps.csgraph.connected_components(sub, directed=False)
+        assert ncomp == 1
+    # bsize 1 -> singletons; huge bsize -> one block per connected component
+    assert _lib.host_aggregate(M, 1)[1] == M.shape[0]
+    assert _lib.host_aggregate(M, 10 ** 6)[1] == 2
+
+
+def test_host_cauchy():
+    ps = np.array([-0.5, -2.0, -9.0, -40.0])
+    rinv, c1 = _lib.host_cauchy(ps)
+    C = -1.0 / (ps[:, None] + ps[None, :])
+    assert np.allclose(rinv, np.triu(rinv))
+    assert np.allclose(rinv @ rinv.T, np.linalg.inv(C), rtol=1e-9)
+    assert np.allclose(C @ c1, np.ones(4), rtol=1e-9)
+    with pytest.raises(RuntimeError):
+        _lib.host_cauchy([-1.0, -1.0])      # repeated shift: C singular
+
+
+def test_input_normalisation():
+    a = sps.csc_matrix(np.array([[1.0, 0, 2], [0, 3, 0], [4, 0, 5]]))
+    rp, ci, v, sh = _lib.as_csr(2.0 * a.T)      # csc, scaled, transposed (solve_dae_ric.py:85,156)
+    assert rp.dtype == np.int32 and ci.dtype == np.int32 and v.dtype == np.float64
+    assert np.allclose(sps.csr_matrix((v, ci, rp), shape=sh).toarray(), 2.0 * a.T.toarray())
+    p = _lib.as_panel(np.arange(3.0))
+    assert p.shape == (3, 1) and p.flags["C_CONTIGUOUS"]
+    with pytest.raises(ValueError):
+        _lib.as_panel(np.zeros((4, 2)), nrows=3)
+
+
+def test_dropin_package_names():
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    for name in ("proj_alg_ric_newtonadi", "solve_proj_lyap_stein", "compress_Zsvd",
+                 "get_mTzzTtb", "comp_proj_lyap_res_norm"):
+        assert callable(getattr(pru, name))
+    for name in ("solve_sadpnt_smw", "app_prj_via_sadpnt", "apply_massinv",
+                 "apply_invsqrt_fromright", "apply_sqrt_fromright", "app_luinv_to_spmat",
+                 "mm_dnssps"):
+        assert callable(getattr(lau, name))
+    # host-only helpers work without a GPU
+    Ms = sps.csr_matrix(np.diag([4.0, 9.0]))
+    assert np.allclose(lau.apply_invsqrt_fromright(Ms, np.eye(2)), np.diag([0.5, 1 / 3.0]))

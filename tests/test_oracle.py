@@ -1,0 +1,159 @@
+"""The CPU oracle against everything the reference pins for this path.
+
+Mirrors /root/reference/tests/test_units_compfacres_compress.py:15-106 (the
+five identities) on this repo's seeded matrices, adds convergence checks the
+reference test lacks, and compares with the committed golden vectors.
+"""
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spsla
+
+from optconpy_amd import problems as pb
+from oracle import lin_alg_utils as lau, proj_ric_utils as pru
+
+
+def _setup(N=8, NY=5, seed=0, pert=0.03):
+    sm = pb.stokes_system(N, nu=1.0)
+    M, A, J = sm["M"], sm["A"], sm["J"]
+    NV = sm["NV"]
+    rng = np.random.default_rng(seed)
+    R = sps.random(NV, NV, density=0.03, format="csr", random_state=rng)
+    F = (-M - 0.1 * A - pert * M.diagonal().mean() * R).tocsr()
+    W = rng.standard_normal((NV, NY))
+    return M, A, J, F, W, NV
+
+
+def _projector(M, J, NV):
+    Mlu = spsla.factorized(M.tocsc())
+    MinvJt = lau.app_luinv_to_spmat(Mlu, J.T)
+    Sinv = np.linalg.inv(J @ MinvJt)
+    return np.eye(NV) - MinvJt @ (Sinv @ J.toarray())
+
+
+def test_reference_identities():
+    M, A, J, F, W, NV = _setup()
+    # parameters of the reference test (:54-60) plus an explicit shift list that
+    # covers this pencil's spectrum, so that the iteration really converges
+    d = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, nwtn_max_steps=24,
+             nwtn_upd_reltol=4e-7, nwtn_upd_abstol=4e-7, full_upd_norm_check=True,
+             ms=pb.logshifts(2.0, 8e3, 12))
+    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    MtZ = M.T @ Z
+    MtXM = MtZ @ MtZ.T
+    FtXM = F.T @ (Z @ (Z.T @ M.toarray()))
+    P = _projector(M, J, NV)
+    PtW = P.T @ W
+    ProjRes = P.T @ FtXM @ P + P.T @ FtXM.T @ P + PtW @ PtW.T
+    resn = np.linalg.norm(ProjRes)
+    # converged: the squared norm is rounding noise around zero, may be negative
+    ownresn = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Z, F, M, W, J)))
+    # (1) smart fnorm  (reference test :85-86)
+    assert np.allclose(np.linalg.norm(MtXM), np.linalg.norm(MtZ.T @ MtZ))
+    # (2) factored residual == dense residual (:89); tolerance relative to ||W W^T||
+    assert abs(resn - ownresn) <= 1e-5 * np.linalg.norm(PtW @ PtW.T)
+    # ADI actually converged here (the reference test does not check this)
+    assert resn < 1e-6 * np.linalg.norm(PtW @ PtW.T)
+    Zred = pru.compress_Zsvd(Z, k=None, thresh=1e-6, shplot=True)
+    MtZr = M.T @ Zred
+    MtXMr = MtZr @ MtZr.T
+    # (3) reduction is 'projected' (:96-97)
+    assert np.allclose(MtXMr, P.T @ MtXMr @ P)
+    # (4) norm preserved (:100-101)
+    assert np.allclose(np.linalg.norm(MtZ.T @ MtZ), np.linalg.norm(MtZr.T @ MtZr))
+    # (5) residual preserved (:104-106), again relative to ||W W^T||
+    ownresr = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Zred, F, M, W, J)))
+    assert abs(ownresr - resn) <= 1e-5 * np.linalg.norm(PtW @ PtW.T)
+    assert Zred.shape[1] < Z.shape[1]
+
+
+def test_unconverged_residual_formula():
+    """The factored residual formula on a deliberately unconverged iterate."""
+    M, A, J, F, W, NV = _setup(N=6)
+    d = dict(adi_max_steps=3, adi_newZ_reltol=1e-30, ms=[-1.0, -4.0])
+    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    P = _projector(M, J, NV)
+    FtXM = F.T @ (Z @ (Z.T @ M.toarray()))
+    PtW = P.T @ W
+    dense = np.linalg.norm(P.T @ FtXM @ P + P.T @ FtXM.T @ P + PtW @ PtW.T)
+    own = np.sqrt(pru.comp_proj_lyap_res_norm(Z, F, M, W, J))
+    assert dense > 1e-3 * np.linalg.norm(PtW @ PtW.T)
+    assert np.allclose(dense, own, rtol=1e-9)
+    # the ADI residual factor carries the same norm: ||W_k W_k^T||_F
+    out = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)
+    assert np.allclose(out["res_hist"][-1], dense, rtol=1e-8)
+
+
+def test_projection_and_smw():
+    M, A, J, F, W, NV = _setup(N=6)
+    P = _projector(M, J, NV)
+    assert np.allclose(lau.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=W, transposedprj=True), P.T @ W)
+    assert np.allclose(lau.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=W), P @ W)
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((NV, 3))
+    V = rng.standard_normal((3, NV)) * 1e-2
+    Aop = (M + 0.1 * A).tocsr()
+    x = lau.solve_sadpnt_smw(amat=Aop, jmat=J, rhsv=W, umat=U, vmat=V)
+    NP = J.shape[0]
+    S = np.block([[Aop.toarray() - U @ V, J.T.toarray()], [J.toarray(), np.zeros((NP, NP))]])
+    assert np.allclose(S @ x, np.vstack([W, np.zeros((NP, W.shape[1]))]), atol=1e-9)
+
+
+def test_small_helpers():
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((5, 5))
+    Ms = sps.csr_matrix(B @ B.T + 5 * np.eye(5))
+    R = rng.standard_normal((7, 5))
+    X = lau.apply_invsqrt_fromright(Ms, R)
+    assert np.allclose(X @ Ms.toarray() @ X.T, R @ R.T)
+    Y = lau.apply_sqrt_fromright(Ms, R)
+    assert np.allclose(Y @ Y.T, R @ Ms.toarray() @ R.T)
+    assert np.allclose(lau.apply_massinv(Ms, R.T), np.linalg.solve(Ms.toarray(), R.T))
+    assert sps.issparse(lau.apply_massinv(Ms, sps.csr_matrix(R.T), output="sparse"))
+    assert np.allclose(lau.mm_dnssps(sps.csr_matrix(R), Ms), R @ Ms.toarray())
+
+
+def test_riccati_residual_small():
+    """Newton-ADI solves the projected ARE: dense residual check (N=4)."""
+    N = 4
+    pr = pb.ricc_problem(N, 0.2, NU=2, NY=2, alphau=1e-3)
+    M, A, J, Nc = pr.M, pr.A, pr.J, pr.Nc
+    NV = pr.NV
+    mct = lau.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+    trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    F = (-A - Nc).tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=pb.logshifts(1.0, 2e3, 10), adi_newZ_reltol=1e-12)
+    out = pru.proj_alg_ric_newtonadi(mmat=M, amat=F, jmat=J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
+    Z = out["zfac"]
+    X = Z @ Z.T
+    P = _projector(M, J, NV)
+    Md, Fd = M.toarray(), F.toarray()
+    res = Fd.T @ X @ Md + Md.T @ X @ Fd - Md.T @ X @ tb @ tb.T @ X @ Md + trct @ trct.T
+    res = P.T @ res @ P
+    assert np.linalg.norm(res) < 1e-7 * np.linalg.norm(trct @ trct.T)
+    assert out["nwtn_steps"] >= 2
+
+
+def test_transposed_flag_equivalence():
+    M, A, J, F, W, NV = _setup(N=5)
+    d = dict(adi_max_steps=12, adi_newZ_reltol=1e-30, ms=[-0.7, -3.0, -15.0])
+    Z1 = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    Z2 = pru.solve_proj_lyap_stein(amat=F.T.tocsr(), mmat=M.T.tocsr(), jmat=J, wmat=W,
+                                   transposed=True, adi_dict=d)["zfac"]
+    assert np.allclose(Z1, Z2, atol=1e-12)
+
+
+def test_golden_vectors(golden, cfg1):
+    pr, tb, trct, ms = cfg1
+    assert np.allclose(golden["shifts"], ms)
+    assert np.allclose(golden["tb"], tb.toarray(), atol=1e-14)
+    assert np.allclose(golden["trct"], trct, atol=1e-13)
+    chk = np.array([pr.M.data.sum(), pr.A.data.sum(), abs(pr.J.data).sum(), abs(pr.Nc.data).sum(),
+                    pr.M.nnz, pr.A.nnz, pr.J.nnz, pr.Nc.nnz])
+    assert np.allclose(golden["mat_checks"], chk, rtol=1e-12)
+    F = (-pr.A - pr.Nc).tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    lo = pru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=trct, adi_dict=d)
+    K = -pru.get_mTzzTtb(pr.M.T, lo["zfac"], tb)
+    assert lo["adi_steps"] == int(golden["lyap_steps"][0])
+    assert np.linalg.norm(K - golden["K_lyap"]) <= 1e-10 * np.linalg.norm(golden["K_lyap"])
