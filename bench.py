@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""Benchmark of the low-rank Newton-ADI hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): ADI shift-solves per second, next to the wall-clock to
+the feedback gain K.  One *step* = one Newton step of the projected Riccati
+solve on BASELINE config 2 (driven cavity, N=58 -> n = 29 930, nu = 0.05,
+16 log-spaced ADI shifts, right-hand-side panel m = NY' + NU = 16): a complete
+low-rank ADI solve of the closed-loop Lyapunov equation with the reference's
+default stopping rule (adi_newZ_reltol = 1e-8, optcont_main.py:124) followed by
+the gain K = -E Z Z^T B.  One *unit* = one shift-solve, i.e. one saddle-point
+solve S(p) [V;L] = [R;0] with an NV x 16 panel to relative residual 1e-11.
+
+N = 1 : the device-resident sequential ADI of libricadi_hip.so.
+N > 1 : one process per GPU (torch.distributed, RCCL); the same problem solved
+        with the shift-parallel Cauchy sweeps (one shift per GPU and sweep, one
+        all-gather per sweep) -> total work fixed, "scaling": "strong".
+
+The JSON line also carries the SpMM roofline figures (kernel time from HIP
+events on the library's stream) and the CPU baseline (oracle = scipy SuperLU on
+the same matrices, bounded sample, rank 0 / N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_inputs(N, nu, nshifts):
+    """cfg2 inputs, prepared with the product's own host-side mirror (GPU solves)."""
+    from optconpy_amd import lin_alg_utils as lau, problems as pb
+    pr = pb.ricc_problem(N, nu, NU=4, NY=4, alphau=1e-2)
+    mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+    trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    ms = pb.logshifts(1.0, 3e3, nshifts)
+    return pr, tb, trct, ms
+
+
+def spmm_roofline(ctx, nnz_s, n, m, reps=200):
+    """K1 roofline: algorithmic bytes (12 nnz + 4 (n+1) + 16 n m) over
+    the kernel's average duration measured with HIP events on the ctx stream."""
+    import torch
+    x = torch.randn(n, m, dtype=torch.float64, device="cuda")
+    y = torch.empty_like(x)
+    torch.cuda.synchronize()
+    ctx.time_spmm_dev(-3.0, 1.0, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
+    ms = ctx.time_spmm_dev(-3.0, 1.0, x.data_ptr(), m, y.data_ptr(), reps)
+    nbytes = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                kernel="spmm_kernel<1>", us_per_launch=round(ms * 1e3, 2),
+                algorithmic_bytes=int(nbytes), n=int(n), m=int(m), nnz=int(nnz_s))
+
+
+def cpu_baseline(pr, ms, m, adi_steps, nsample_shifts=3, solves_per_shift=4):
+    """Oracle (scipy SuperLU, as the reference's technology) on a bounded sample:
+    LU of `nsample_shifts` shifted saddle matrices + `solves_per_shift` panel solves
+    each; extrapolated to the step's work (16 LUs + adi_steps shift-solves)."""
+    from oracle import lin_alg_utils as olau
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(0)
+    R = rng.standard_normal((pr.NV, m))
+    t_lu, t_solve, nlu, nsol = 0.0, 0.0, 0, 0
+    pick = [ms[0], ms[len(ms) // 2], ms[-1]][:nsample_shifts]
+    for p in pick:
+        t0 = time.perf_counter()
+        lu = olau.SaddleLU(calA + p * pr.M, pr.J)
+        t_lu += time.perf_counter() - t0
+        nlu += 1
+        for _ in range(solves_per_shift):
+            t0 = time.perf_counter()
+            lu.solve(R)
+            t_solve += time.perf_counter() - t0
+            nsol += 1
+    lu_s, sol_s = t_lu / nlu, t_solve / nsol
+    step_time = len(ms) * lu_s + adi_steps * sol_s
+    return dict(value=round(adi_steps / step_time, 3), unit="shift-solves/s", cores=1,
+                kind="port",
+                sample="%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) "
+                       "of the cfg2 saddle matrix, scipy SuperLU single-threaded; "
+                       "extrapolated to one step = %d LUs + %d shift-solves"
+                       % (nlu, lu_s, nsol, m, sol_s, len(ms), adi_steps),
+                lu_seconds=round(lu_s, 3), solve_seconds=round(sol_s, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--N", type=int, default=58, help="mesh parameter (58 = BASELINE cfg2)")
+    ap.add_argument("--nu", type=float, default=0.05)
+    ap.add_argument("--shifts", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from optconpy_amd import _lib, backend, problems as pb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    os.environ["RICADI_DEVICE"] = str(local)
+
+    t0 = time.time()
+    pr, tb, trct, ms = build_inputs(args.N, args.nu, args.shifts)
+    backend.reset()
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    calE = pr.M.T.tocsr()
+    ctx = _lib.Context(local)
+    ctx.set_operator(calA, calE, pr.J)
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    prm_full = _lib.adi_params(d)
+    prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1))
+    nb, mw = tb.shape[1], trct.shape[1]
+    m = nb + mw
+    n = pr.NV + pr.NP
+    nnz_s = (calA + calE).nnz + 2 * pr.J.nnz
+
+    # untimed: converge the Newton iteration once; its compressed iterate is the
+    # linearisation point of the timed Newton step (so that the step sees the
+    # closed-loop low-rank term and the full m = 16 panel, like steps >= 2 do)
+    Zfull, info_full = ctx.ric_newtonadi(ms, tb, trct, prm_full, fetch=False)
+    Zk, _ = ctx.compress(None, thresh=1e-12, k=None)
+    K_ref = -ctx.gain(tb)
+    if rank == 0:
+        log("setup %.1fs: n=%d nnz(S)=%d m=%d; converged Newton: %s; |Z_k| cols %d"
+            % (time.time() - t0, n, nnz_s, m, info_full, Zk.shape[1]))
+
+    if world == 1:
+        def one_step():
+            ctx.clear_cache()                       # per-shift setup is part of the step
+            _, info = ctx.ric_newtonadi(ms, tb, trct, prm_one, Z0=Zk, fetch=False)
+            K = -ctx.gain(tb)
+            return info["shift_solves"], info["gmres_iters"], K
+    else:
+        from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel
+        ops = HipOps(ctx)
+        G = min(world, 8)
+        # closed-loop operator cal A - K_k B^T and rhs [W, K_k] of the Newton step
+        Kk = -K_ref                                  # K_k = E Z_k Z_k^T B
+        from optconpy_amd import lin_alg_utils as lau
+        Wp = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=trct, transposedprj=True)
+        backend.reset()
+        rhs = ops.to_panel(np.hstack([Wp, Kk]))
+        tbd = ops.to_panel(tb)
+
+        def one_step():
+            ctx.clear_cache()
+            ctx.set_lowrank(Kk, tb)
+            ops.gmres_iters = 0
+            ops.shift_solves = 0
+            blocks, info = lyap_adi_shift_parallel(ops, ms, rhs, adi_max_steps=200,
+                                                   adi_newZ_reltol=1e-8, width=G)
+            ctx.set_lowrank(None, None)
+            Z = torch.cat(blocks, dim=1).contiguous()
+            Kt = ops.gain(-1.0, Z, tbd)             # gain on the replicated factor
+            return info["adi_steps"], ops.gmres_iters, Kt.cpu().numpy()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    iters = 0
+    K = None
+    for _ in range(args.steps):
+        u, it, K = one_step()
+        units += u
+        iters += it
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k_err = float(np.linalg.norm(K - K_ref) / np.linalg.norm(K_ref))
+
+    if rank == 0:
+        out = {
+            "metric": "ADI shift-solves/sec (wall-clock to feedback K in ms_per_step)",
+            "value": round(units / elapsed, 3),
+            "unit": "shift-solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "driven cavity N=%d (cfg2: n=%d, nnz(S)=%d), nu=%g, %d log-spaced "
+                            "ADI shifts, 1 Newton step (closed-loop Lyapunov ADI to "
+                            "adi_newZ_reltol=1e-8) + gain K; panel m=%d; GMRES tol 1e-11"
+                            % (args.N, n, nnz_s, args.nu, len(ms), m),
+                "shift_solves_per_step": units // args.steps,
+                "gmres_iters_per_shift_solve": round(iters / max(units, 1), 1),
+                "parallelism": "sequential ADI, 1 GPU" if world == 1
+                else "shift-parallel ADI, %d shifts/sweep, 1 all-gather/sweep" % min(world, 8),
+                "K_rel_diff_vs_converged": k_err,
+            },
+        }
+        out["roofline"] = spmm_roofline(ctx, nnz_s, n, m)
+        if world == 1 and not args.no_large_roofline:
+            # the HBM-resident instance (BASELINE cfg5 pattern, n ~ 5e5)
+            try:
+                prl = pb.ricc_problem(236, 0.05, with_convection=True)
+                cl = _lib.Context(local, coarse_max=2048)
+                cl.set_operator((-prl.A - prl.Nc).T.tocsr(), prl.M.T.tocsr(), prl.J)
+                nl = prl.NV + prl.NP
+                nnzl = (prl.A + prl.Nc + prl.M).nnz + 2 * prl.J.nnz
+                out["roofline_cfg5"] = spmm_roofline(cl, nnzl, nl, 16, reps=100)
+                cl.close()
+            except Exception as e:                   # never lose the headline line
+                out["roofline_cfg5"] = {"error": str(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pr, ms, m, units // args.steps)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

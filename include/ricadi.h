@@ -97,6 +97,10 @@ int ricadi_set_operator(ricadi_ctx* ctx, int nv, int np,
                         const int32_t* e_rowptr, const int32_t* e_col, const double* e_val,
                         const int32_t* j_rowptr, const int32_t* j_col, const double* j_val);
 
+/* Drop the per-shift data (assembled values, block inverses, coarse inverse)
+ * cached for every (alpha, beta) used so far; they are rebuilt on demand.    */
+int ricadi_clear_cache(ricadi_ctx* ctx);
+
 /* Dimension-only context (no operator): enough for ricadi_compress and for
  * ricadi_gain with an explicit `mt_*` matrix, which need NV only.           */
 int ricadi_set_dims(ricadi_ctx* ctx, int nv);
@@ -195,6 +199,10 @@ int ricadi_apply_e_dev(ricadi_ctx* ctx, double coef, const double* dV, int m, do
  * Cauchy recombination.                              */
 int ricadi_lincomb_dev(ricadi_ctx* ctx, int nrows, int m, int nvec, const double* dBasis,
                        int64_t stride, const double* coef, double* dOut);
+/* dK (NV x nb) = coef * E * (Z * (Z^T B)) for a device-resident factor dZ
+ * (NV x c, row-major with leading dimension ldz) and dB (NV x nb).          */
+int ricadi_gain_dev(ricadi_ctx* ctx, double coef, const double* dZ, int c, int ldz,
+                    const double* dB, int nb, double* dK);
 /* Frobenius norms of the m columns' Gram matrix: out = ||W^T W||_F, and the
  * squared F-norm of the panel in nrm2 (both may be NULL).                  */
 int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,

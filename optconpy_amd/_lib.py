@@ -51,6 +51,7 @@ SIGNATURES = {
     "ricadi_synchronize": (C.c_int, [_vp]),
     "ricadi_set_operator": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp,
                                       _ip, _ip, _dp]),
+    "ricadi_clear_cache": (C.c_int, [_vp]),
     "ricadi_set_dims": (C.c_int, [_vp, C.c_int]),
     "ricadi_set_lowrank": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "ricadi_spmm": (C.c_int, [_vp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
@@ -74,6 +75,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int), _dp]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
+    "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
     "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
                                        _dp]),
@@ -189,7 +191,7 @@ class Context:
         self._lib = load()
         self._h = _vp()
         _chk(self._lib.ricadi_create(int(device), C.byref(self._h)))
-        self.nv = self.np_ = 0
+        self.nv = self.np_ = self.n = 0
         if opts:
             self.set_opts(**opts)
 
@@ -246,6 +248,9 @@ class Context:
         self.nv, self.np_ = nv, np_
         self.n = nv + np_
 
+    def clear_cache(self):
+        _chk(self._lib.ricadi_clear_cache(self._h))
+
     def set_dims(self, nv):
         """Dimension-only context: enough for compress() and gain(MT=...)."""
         _chk(self._lib.ricadi_set_dims(self._h, int(nv)))
@@ -263,13 +268,19 @@ class Context:
         _chk(self._lib.ricadi_set_lowrank(self._h, _d(U), _d(V), U.shape[1]))
 
     # -- kernels ----------------------------------------------------------
+    def _need_op(self):
+        if not self.n:
+            raise RuntimeError("ricadi: no operator set on this context")
+
     def spmm(self, alpha, beta, X):
+        self._need_op()
         X = as_panel(X, self.n)
         Y = np.empty_like(X)
         _chk(self._lib.ricadi_spmm(self._h, alpha, beta, _d(X), X.shape[1], _d(Y)))
         return Y
 
     def precond_apply(self, alpha, beta, R):
+        self._need_op()
         R = as_panel(R, self.n)
         Z = np.empty_like(R)
         _chk(self._lib.ricadi_precond_apply(self._h, alpha, beta, _d(R), R.shape[1], _d(Z)))
@@ -277,6 +288,7 @@ class Context:
 
     def shift_solve(self, alpha, beta, R, Rp=None, strict=True):
         """Solve ``S(alpha,beta) [V;L] = [R;Rp]``; wide panels go in chunks."""
+        self._need_op()
         R = as_panel(R, self.nv)
         m = R.shape[1]
         Rp = None if Rp is None else as_panel(Rp, self.np_)
@@ -408,6 +420,9 @@ class Context:
         cf = np.ascontiguousarray(coef, dtype=np.float64)
         _chk(self._lib.ricadi_lincomb_dev(self._h, nrows, m, cf.size, basis_ptr, int(stride),
                                           _d(cf), out_ptr))
+
+    def gain_dev(self, coef, z_ptr, c, ldz, b_ptr, nb, k_ptr):
+        _chk(self._lib.ricadi_gain_dev(self._h, coef, z_ptr, c, ldz, b_ptr, nb, k_ptr))
 
     def panel_norms_dev(self, w_ptr, nrows, m):
         g = C.c_double(0.0)

@@ -507,23 +507,22 @@ static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const dou
   const int kk = k1 + k0, nv = c->nv;
   DArr<double> D, tau;
   D.alloc((size_t)nv * kk);
-  tau.alloc(kk);
+  tau.alloc(std::max(kk, 1));
   launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
   if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
   // row-major NV x kk  ==  column-major kk x NV :  D^T = L Q
   RBCHK(rocsolver_dgelqf(c->rb, kk, nv, D.p, kk, tau.p));
-  std::vector<double> Lh((size_t)kk * kk);
-  // first kk columns of the column-major kk x NV array = first kk rows of the row-major one
-  HIPCHK(hipMemcpyAsync(Lh.data(), D.p, sizeof(double) * kk * kk, hipMemcpyDeviceToHost, st));
+  // L is kk x min(kk, NV), lower trapezoidal, in the first columns of the
+  // column-major kk x NV array (= the first rows of the row-major one)
+  const int nl = std::min(kk, nv);
+  std::vector<double> Lh((size_t)kk * nl);
+  HIPCHK(hipMemcpyAsync(Lh.data(), D.p, sizeof(double) * kk * nl, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  // column-major L(i,j) = Lh[i + j*kk], lower triangular (i >= j)
   auto Lat = [&](int i, int j) { return i >= j ? Lh[(size_t)i + (size_t)j * kk] : 0.0; };
-  // D S D^T = Q^T (L^T S L) Q  -> T = L^T S L (kk x kk), S = diag(I_k1, -I_k0)
-  // here D = (L Q)^T = Q^T L^T, so D S D^T needs S between D and D^T:
-  // D S D^T = Q^T L^T ... careful: D is NV x kk, D = Q^T L^T; D S D^T = Q^T (L^T S L) Q.
+  // D = Q^T L^T (NV x kk)  =>  D S D^T = Q^T (L^T S L) Q,  S = diag(I_k1, -I_k0)
   double f = 0.0, f1 = 0.0;
-  for (int a = 0; a < kk; ++a)
-    for (int b = 0; b < kk; ++b) {
+  for (int a = 0; a < nl; ++a)
+    for (int b = 0; b < nl; ++b) {
       double t = 0.0, t1 = 0.0;
       for (int i = std::max(a, b); i < kk; ++i) {
         const double pr = Lat(i, a) * Lat(i, b);
@@ -732,6 +731,14 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   API_END
 }
 
+int ricadi_clear_cache(ricadi_ctx* c) {
+  REQUIRE(c, RICADI_EINVAL, "NULL ctx");
+  API_BEGIN
+  HIPCHK(hipStreamSynchronize(c->st));
+  c->cache.clear();
+  API_END
+}
+
 int ricadi_set_dims(ricadi_ctx* c, int nv) {
   REQUIRE(c && nv > 0, RICADI_EINVAL, "bad argument");
   c->cache.clear();
@@ -882,6 +889,18 @@ int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* 
   HIPCHK(hipStreamSynchronize(c->st));
   launch_cols_update(c->st, nrows, m, nvec, dBasis, (size_t)stride, c->lrc.p, 1.0, nullptr, nullptr,
                      dOut);
+  API_END
+}
+
+int ricadi_gain_dev(ricadi_ctx* c, double coef, const double* dZ, int cz, int ldz, const double* dB,
+                    int nb, double* dK) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(dZ && dB && dK && cz > 0 && ldz >= cz && nb >= 1 && nb <= RICADI_MAX_M, RICADI_EINVAL,
+          "bad argument");
+  API_BEGIN
+  gain_dev(c, c->E, dZ, cz, ldz, dB, nb, dK);
+  if (coef != 1.0) launch_axpby(c->st, (size_t)c->nv * nb, coef, dK, 0.0, dK);
+  HIPCHK(hipStreamSynchronize(c->st));
   API_END
 }
 

@@ -77,6 +77,14 @@ class HipOps:
         self.ctx.apply_e_dev(float(coef), V.data_ptr(), V.shape[1], W.data_ptr())
         self.ctx.synchronize()
 
+    def gain(self, coef, Z, B):
+        """``coef * E * (Z * (Z^T B))`` for a contiguous NV x c factor ``Z``."""
+        K = self.empty(B.shape[0], B.shape[1])
+        self._sync_in()
+        self.ctx.gain_dev(float(coef), Z.data_ptr(), Z.shape[1], Z.shape[1], B.data_ptr(),
+                          B.shape[1], K.data_ptr())
+        return K
+
     def fro2(self, T):
         self._sync_in()
         _, t = self.ctx.panel_norms_dev(T.data_ptr(), T.shape[0], T.shape[1])

@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle.
+
+FP64 throughout.  Tolerances: kernels 1e-12 relative; solves at the GMRES
+tolerance; the feedback gain K within 1e-6 relative Frobenius norm -- the bar
+BASELINE.json's north_star states -- and in practice ~1e-11.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import scipy.sparse.linalg as spsla
+
+from optconpy_amd import _lib, backend, problems as pb
+from oracle import lin_alg_utils as olau, proj_ric_utils as opru
+
+pytestmark = pytest.mark.gpu
+K_TOL = 1e-6          # north_star parity bar
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope="module")
+def ctx1(cfg1):
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    ctx = _lib.Context(0)
+    ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    yield ctx
+    ctx.close()
+
+
+# --------------------------------------------------------------------------- K1
+@pytest.mark.parametrize("m", [1, 5, 16, 17, 48, 70, 128])
+def test_spmm_parity(ctx1, cfg1, m):
+    pr, tb, trct, ms = cfg1
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(m)
+    X = rng.standard_normal((pr.NV + pr.NP, m))
+    for (al, be) in ((-3.0, 1.0), (1.0, 0.0), (0.0, 1.0)):
+        S = sps.bmat([[be * calA + al * pr.M, pr.J.T], [pr.J, None]], format="csr")
+        assert rel(ctx1.spmm(al, be, X), S @ X) < 1e-13
+
+
+def test_spmm_lowrank_term(ctx1, cfg1):
+    pr, tb, trct, ms = cfg1
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(7)
+    U = rng.standard_normal((pr.NV, 8))
+    V = rng.standard_normal((pr.NV, 8))
+    X = rng.standard_normal((pr.NV + pr.NP, 16))
+    ctx1.set_lowrank(U, V)
+    try:
+        Y = ctx1.spmm(-2.0, 1.0, X)
+    finally:
+        ctx1.set_lowrank(None, None)
+    S = sps.bmat([[calA - 2.0 * pr.M, pr.J.T], [pr.J, None]], format="csr")
+    ref = S @ X
+    ref[:pr.NV] -= U @ (V.T @ X[:pr.NV])
+    assert rel(Y, ref) < 1e-12
+
+
+def test_linearity_of_spmm(ctx1, cfg1):
+    pr = cfg1[0]
+    rng = np.random.default_rng(11)
+    X1 = rng.standard_normal((pr.NV + pr.NP, 16))
+    X2 = rng.standard_normal((pr.NV + pr.NP, 16))
+    Y = ctx1.spmm(-5.0, 1.0, 2.0 * X1 - 3.0 * X2)
+    assert rel(Y, 2.0 * ctx1.spmm(-5.0, 1.0, X1) - 3.0 * ctx1.spmm(-5.0, 1.0, X2)) < 1e-13
+
+
+# ------------------------------------------------------------------ shift solves
+@pytest.mark.parametrize("p", [-1.0, -30.0, -1000.0])
+def test_shift_solve_vs_lu(ctx1, cfg1, p):
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(3)
+    R = rng.standard_normal((pr.NV, 16))
+    X, its, rr = ctx1.shift_solve(p, 1.0, R)
+    Xo = olau.SaddleLU(calA + p * pr.M, pr.J).solve(R)
+    assert rr.max() < 1e-10 and its > 0
+    assert rel(X[:pr.NV], Xo[:pr.NV]) < 1e-9
+    assert np.abs(pr.J @ X[:pr.NV]).max() < 1e-9 * np.abs(X[:pr.NV]).max()   # J V = 0
+
+
+def test_shift_solve_edge_panels(ctx1, cfg1):
+    """single column, zero columns, nonzero constraint rhs."""
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(4)
+    lu = olau.SaddleLU(calA - 10.0 * pr.M, pr.J)
+    r1 = rng.standard_normal((pr.NV, 1))
+    X, _, _ = ctx1.shift_solve(-10.0, 1.0, r1)
+    assert rel(X, lu.solve(r1)) < 1e-8
+    R = rng.standard_normal((pr.NV, 4))
+    R[:, 2] = 0.0                                   # a zero column must stay zero
+    X, _, rr = ctx1.shift_solve(-10.0, 1.0, R)
+    assert np.all(X[:, 2] == 0.0) and np.isfinite(X).all()
+    Rp = rng.standard_normal((pr.NP, 3))
+    Rv = rng.standard_normal((pr.NV, 3))
+    X, _, _ = ctx1.shift_solve(-10.0, 1.0, Rv, Rp)
+    assert rel(X, lu.solve(Rv, Rp)) < 1e-8
+
+
+def test_argument_errors(ctx1, cfg1):
+    pr = cfg1[0]
+    with pytest.raises(ValueError):
+        ctx1.spmm(-1.0, 1.0, np.zeros((pr.NV, 4)))              # wrong row count
+    with pytest.raises(ValueError):
+        ctx1.spmm(-1.0, 1.0, np.zeros((pr.NV + pr.NP, 129)))    # too wide for one panel
+    prm = _lib.adi_params(dict(adi_max_steps=3))
+    with pytest.raises(ValueError):
+        ctx1.lyap_adi([1.0], np.ones((pr.NV, 2)), prm)          # positive shift
+    fresh = _lib.Context(0)
+    with pytest.raises(RuntimeError):
+        fresh.spmm(-1.0, 1.0, np.zeros((3, 1)))                 # operator not set
+    fresh.close()
+
+
+# --------------------------------------------------------------------- a2, a1
+def test_lyap_adi_gain_vs_golden(ctx1, cfg1, golden):
+    pr, tb, trct, ms = cfg1
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    Z, info = ctx1.lyap_adi(ms, trct, _lib.adi_params(d))
+    assert info["adi_steps"] == int(golden["lyap_steps"][0])
+    K = -(pr.M.T @ (Z @ (Z.T @ tb.toarray())))
+    assert rel(K, golden["K_lyap"]) < K_TOL
+    # device gain kernel on the device-resident factor
+    assert rel(-ctx1.gain(tb.toarray()), golden["K_lyap"]) < K_TOL
+
+
+def test_newton_adi_gain_vs_golden_and_oracle(ctx1, cfg1, golden):
+    pr, tb, trct, ms = cfg1
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    Z, info = ctx1.ric_newtonadi(ms, tb.toarray(), trct, _lib.adi_params(d))
+    assert info["nwtn_steps"] == int(golden["nwtn_steps"][0])
+    # same Newton update norms as the oracle (same stopping decisions)
+    assert np.isclose(info["upd_rel"], golden["upd_hist"][-1, 1], rtol=1e-3)
+    K = -ctx1.gain(tb.toarray())
+    assert rel(K, golden["K_ric"]) < K_TOL
+    Kh = -opru.get_mTzzTtb(pr.M.T, Z, tb)      # from the factor copied to the host
+    assert rel(Kh, golden["K_ric"]) < K_TOL
+    # compression of the device-resident factor (solve_dae_ric.py:162-163 parameters)
+    Zc, sv = ctx1.compress(None, thresh=5e-5, k=50)
+    assert Zc.shape[1] == int(golden["kcomp"][0])
+    assert np.allclose(sv[:20], golden["sv"][:20], rtol=1e-6)
+    assert np.isclose(np.linalg.norm(Zc.T @ Zc), golden["gram_comp_fro"][0], rtol=1e-8)
+
+
+def test_newton_with_initial_guess_and_old_feedback(ctx1, cfg1):
+    """z0 / mtxoldb arguments (solve_dae_ric.py:152-159)."""
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms, nwtn_max_steps=3)
+    rng = np.random.default_rng(5)
+    old = 1e-3 * olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J,
+                                         rhsv=rng.standard_normal((pr.NV, tb.shape[1])),
+                                         transposedprj=True)
+    z0 = 1e-2 * olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=rng.standard_normal((pr.NV, 3)))
+    ref = opru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=z0,
+                                      mtxoldb=old, nwtn_adi_dict=d)
+    Z, info = ctx1.ric_newtonadi(ms, tb.toarray(), trct, _lib.adi_params(d), Z0=z0, oldB=old)
+    assert info["nwtn_steps"] == ref["nwtn_steps"]
+    Kr = opru.get_mTzzTtb(pr.M.T, ref["zfac"], tb)
+    assert rel(opru.get_mTzzTtb(pr.M.T, Z, tb), Kr) < K_TOL
+
+
+# ----------------------------------------- the reference's own test, via the drop-in
+def test_reference_unit_test_through_dropin():
+    """/root/reference/tests/test_units_compfacres_compress.py:15-106 with
+    `pru` / `lau` resolved to the MI355X implementation."""
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    N, NY, thresh = 8, 5, 1e-6
+    sm = pb.stokes_system(N, nu=1.0)
+    M, A, J, NV = sm["M"], sm["A"], sm["J"], sm["NV"]
+    rng = np.random.default_rng(0)
+    R = sps.random(NV, NV, density=0.03, format="csr", random_state=rng)
+    F = (-M - 0.1 * A - 0.03 * M.diagonal().mean() * R).tocsr()
+    W = rng.standard_normal((NV, NY))
+    nwtn_adi_dict = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, nwtn_max_steps=24,
+                         nwtn_upd_reltol=4e-7, nwtn_upd_abstol=4e-7,
+                         full_upd_norm_check=True, verbose=False,
+                         ms=pb.logshifts(2.0, 8e3, 12))
+    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=nwtn_adi_dict)["zfac"]
+    MtZ = M.T * Z
+    MtXM = np.dot(M.T * Z, Z.T * M)
+    FtXM = F.T * np.dot(Z, Z.T) * M
+    Mlu = spsla.factorized(M.tocsc())
+    MinvJt = lau.app_luinv_to_spmat(Mlu, J.T)
+    Sinv = np.linalg.inv(J * MinvJt)
+    P = np.eye(NV) - np.dot(MinvJt, Sinv * J)
+    PtW = np.dot(P.T, W)
+    ProjRes = np.dot(P.T, np.dot(FtXM, P)) + np.dot(np.dot(P.T, FtXM.T), P) + np.dot(PtW, PtW.T)
+    resn = np.linalg.norm(ProjRes)
+    wwn = np.linalg.norm(np.dot(PtW, PtW.T))
+    ownresn = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Z, F, M, W, J)))
+    assert np.allclose(np.linalg.norm(MtXM), np.linalg.norm(np.dot(MtZ.T, MtZ)))
+    assert abs(resn - ownresn) <= 1e-5 * wwn and resn < 1e-6 * wwn
+    Zred = pru.compress_Zsvd(Z, k=None, thresh=thresh, shplot=True)
+    MtZr = M.T * Zred
+    MtXMr = np.dot(MtZr, MtZr.T)
+    assert np.allclose(MtXMr, np.dot(P.T, np.dot(MtXMr, P)))
+    assert np.allclose(np.linalg.norm(np.dot(MtZ.T, MtZ)), np.linalg.norm(np.dot(MtZr.T, MtZr)))
+    ownresr = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Zred, F, M, W, J)))
+    assert abs(ownresr - resn) <= 1e-5 * wwn
+    # the same Z as the oracle, as far as Z Z^T is concerned
+    Zo = opru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=nwtn_adi_dict)["zfac"]
+    assert opru.comp_diff_zzt_fnorm(Z, Zo) <= 1e-8 * np.linalg.norm(Zo.T @ Zo)
+    backend.reset()
+
+
+def test_unconverged_residual_norm_matches_oracle():
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    sm = pb.stokes_system(6, nu=1.0)
+    M, A, J, NV = sm["M"], sm["A"], sm["J"], sm["NV"]
+    rng = np.random.default_rng(2)
+    F = (-M - 0.1 * A).tocsr()
+    W = rng.standard_normal((NV, 4))
+    d = dict(adi_max_steps=3, adi_newZ_reltol=1e-30, ms=[-1.0, -4.0])
+    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    Zo = opru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    assert rel(Z, Zo) < 1e-8                    # sequential ADI: same columns, not just same ZZ^T
+    r_gpu = pru.comp_proj_lyap_res_norm(Z, F, M, W, J)
+    r_cpu = opru.comp_proj_lyap_res_norm(Zo, F, M, W, J)
+    assert r_cpu > 0 and np.isclose(r_gpu, r_cpu, rtol=1e-7)
+    backend.reset()
+
+
+# ------------------------------------------------------------------ a3, a4, a6-a8
+def test_compress_properties():
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    rng = np.random.default_rng(9)
+    n, c = 3000, 90
+    Q, _ = np.linalg.qr(rng.standard_normal((n, c)))
+    s = np.logspace(0, -9, c)
+    Z = (Q * s) @ np.linalg.qr(rng.standard_normal((c, c)))[0]
+    for thresh, k in ((1e-4, None), (None, 7), (1e-4, 5), (1e-30, None)):
+        Zc = pru.compress_Zsvd(Z, thresh=thresh, k=k)
+        Zo = opru.compress_Zsvd(Z, thresh=thresh, k=k)
+        if thresh != 1e-30:
+            assert Zc.shape == Zo.shape
+        # truncation error of Z Z^T is that of the optimal rank-k' truncation
+        kk = Zc.shape[1]
+        tail = np.sqrt(np.sum(s[kk:] ** 4))
+        err = opru.comp_diff_zzt_fnorm(Zc, Z)
+        assert err <= 1.01 * tail + 1e-14
+    # edge: a single column, and a zero threshold keeping everything numerically non-zero
+    z1 = rng.standard_normal((n, 1))
+    assert rel(pru.compress_Zsvd(z1, thresh=None, k=None) @ np.ones((1, 1)) * 1.0,
+               z1 * np.sign((pru.compress_Zsvd(z1).T @ z1))) < 1e-12
+    backend.reset()
+
+
+def test_get_mtzzttb_sparse_and_dense(cfg1):
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    pr, tb, trct, ms = cfg1
+    rng = np.random.default_rng(1)
+    Z = rng.standard_normal((pr.NV, 37))
+    ref = opru.get_mTzzTtb(pr.M.T, Z, tb)
+    assert rel(pru.get_mTzzTtb(pr.M.T, Z, tb), ref) < 1e-12            # sparse tb (optcont_main.py:505)
+    f = rng.standard_normal((pr.NV, 1))
+    assert rel(pru.get_mTzzTtb(pr.M.T, Z, f), opru.get_mTzzTtb(pr.M.T, Z, f)) < 1e-12   # dense NV x 1 (:183)
+    backend.reset()
+
+
+def test_lau_mirror(cfg1, golden):
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    backend.reset()
+    pr, tb, trct, ms = cfg1
+    # a7: projection (optcont_main.py:405-408)
+    got = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    ref = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    assert rel(got, ref) < 1e-8
+    assert rel(lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=trct),
+               olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=trct)) < 1e-8
+    # a6: feed-forward saddle solve with the closed-loop low-rank term (optcont_main.py:510-514)
+    wft = lau.solve_sadpnt_smw(amat=(pr.A + pr.Nc).T.tocsr(), jmat=pr.J, rhsv=golden["ff_rhs"],
+                               umat=golden["K_ric"], vmat=tb.T)[:pr.NV]
+    assert rel(wft, golden["ff_sol"]) < 1e-7
+    # a8: mass inverse, NV-sized (solve_dae_ric.py:100) and small (optcont_main.py:398)
+    assert rel(lau.apply_massinv(pr.M, trct), olau.apply_massinv(pr.M, trct)) < 1e-8
+    got = lau.apply_massinv(pr.y_masmat, pr.mc_mat, output="sparse")
+    assert sps.issparse(got)
+    assert rel(got.toarray(), olau.apply_massinv(pr.y_masmat, pr.mc_mat)) < 1e-12
+    backend.reset()
+
+
+# ------------------------------------------------ properties at the benchmark size
+def test_cfg2_size_properties():
+    """N=58 (BASELINE cfg2: n = 29 930): residual, constraint and linearity checks
+    that need no oracle factorisation, plus one LU cross-check."""
+    pr = pb.ricc_problem(58, 0.05)
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    ctx = _lib.Context(0)
+    ctx.set_operator(calA, pr.M.T.tocsr(), pr.J)
+    rng = np.random.default_rng(0)
+    R = rng.standard_normal((pr.NV, 16))
+    for p in (-1.0, -300.0):
+        X, its, rr = ctx.shift_solve(p, 1.0, R)
+        S = sps.bmat([[calA + p * pr.M, pr.J.T], [pr.J, None]], format="csr")
+        res = S @ X - np.vstack([R, np.zeros((pr.NP, 16))])
+        assert np.linalg.norm(res, axis=0).max() < 1e-10 * np.linalg.norm(R, axis=0).min()
+        assert np.abs(pr.J @ X[:pr.NV]).max() < 1e-9 * np.abs(X).max()
+    X2, _, _ = ctx.shift_solve(-300.0, 1.0, 2.0 * R[:, :4] - R[:, 4:8])
+    assert rel(X2, 2.0 * X[:, :4] - X[:, 4:8]) < 1e-8
+    Xo = olau.SaddleLU(calA - 300.0 * pr.M, pr.J).solve(R[:, :2])
+    assert rel(X[:pr.NV, :2], Xo[:pr.NV]) < 1e-8
+    ctx.close()
+
+
+def test_shift_parallel_hipops_matches_sequential(cfg1, golden):
+    """The multi-GPU orchestration on one GPU (world 1, sweep width 4)."""
+    import torch
+    from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    ctx = _lib.Context(0)
+    ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    torch.cuda.set_device(0)
+    ops = HipOps(ctx)
+    W = ops.to_panel(trct)     # already projected (mct_mat_reg)
+    blocks, info = lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200,
+                                           adi_newZ_reltol=1e-8, width=4)
+    Z = torch.cat(blocks, dim=1).cpu().numpy()
+    K = -(pr.M.T @ (Z @ (Z.T @ tb.toarray())))
+    assert rel(K, golden["K_lyap"]) < K_TOL
+    assert info["width"] == 4 and ops.shift_solves == info["adi_steps"]
+    ctx.close()
