@@ -146,7 +146,7 @@ def main():
     # linearisation point of the timed Newton step (so that the step sees the
     # closed-loop low-rank term and the full m = 16 panel, like steps >= 2 do)
     Zfull, info_full = ctx.ric_newtonadi(ms, tb, trct, prm_full, fetch=False)
-    Zk, _ = ctx.compress(None, thresh=1e-12, k=None)
+    Zk = ctx.factor_get()          # the Newton driver leaves the compressed iterate on the device
     K_ref = -ctx.gain(tb)
     if rank == 0:
         log("setup %.1fs: n=%d nnz(S)=%d m=%d; converged Newton: %s; |Z_k| cols %d"

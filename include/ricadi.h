@@ -69,6 +69,11 @@ typedef struct ricadi_adi_params {
   double nwtn_upd_abstol;
   int project_w;         /* project the rhs factor first (default 1)        */
   int verbose;
+  int compress_cols;     /* > 0: recompress the device factor whenever it has
+                            grown by this many columns (truncation at
+                            sqrt(eps)*sigma_1, i.e. exact to rounding in Z Z^T).
+                            0: ricadi_lyap_adi keeps the raw ADI columns like
+                            the reference; ricadi_ric_newtonadi uses 512.      */
 } ricadi_adi_params;
 
 const char* ricadi_last_error(void);

@@ -11,9 +11,13 @@
 //     matrix row and its lanes own the panel columns g, g+16, ...;
 //   * reductions over rows are two-stage (per-workgroup partials, then a small
 //     reduce kernel), so results are bitwise reproducible run to run.
+#include <cstdlib>
+
 #include "ricadi_internal.h"
 
 namespace ricadi {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
 // K1: CSR SpMM on row-major panels.
@@ -76,6 +80,80 @@ __global__ __launch_bounds__(256) void spmm_kernel(
   }
 }
 
+// Variant 2 (default).  The 16 lanes of a row group load 16 consecutive
+// (col, val) pairs with ONE coalesced load each and broadcast them with
+// width-16 shuffles, so the 16 x-row gathers of a chunk are independent and all
+// in flight together (the variant above serialises col -> gather per entry).
+// Padding entries use val = 0 / col = 0, i.e. a harmless cached gather,
+// so the inner loop is branch free.  Row blocks are dealt to the 8 XCDs in
+// contiguous ranges (blockIdx % 8 selects the range), which keeps the gathered
+// x rows of a band matrix inside that XCD's L2.
+template <int CPL>
+__global__ __launch_bounds__(256) void spmm_kernel_v2(
+    int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
+    const double* __restrict__ val, const double* __restrict__ x, int ldx,
+    const int* __restrict__ xmap, double* __restrict__ y, int ldy,
+    const double* __restrict__ r, int ldr, double alpha, double beta_r,
+    const double* __restrict__ rowscale, int m) {
+  // bijective XCD remap of the block index (cdna guide, T1)
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+  const int blk = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int g = threadIdx.x & 15;
+  const int row = blk * 16 + (threadIdx.x >> 4);
+  const bool live = row < nrows;
+  double acc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
+  const int k0 = live ? rp[row] : 0, k1 = live ? rp[row + 1] : 0;
+  // all 4 groups of the wave iterate the same number of chunks (shuffles need
+  // every lane): take the wave-wide maximum
+  int nch = (k1 - k0 + 15) >> 4;
+  nch = max(nch, __shfl_xor(nch, 16, 64));
+  nch = max(nch, __shfl_xor(nch, 32, 64));
+  for (int ch = 0; ch < nch; ++ch) {
+    const int k = k0 + ch * 16 + g;
+    int myc = 0;            // padding: val = 0 times row 0 of x (always a valid row;
+    double myv = 0.0;       // the matrix may be rectangular, so "own row" is not)
+    if (k < k1) {
+      myc = ci[k];
+      myv = val[k];
+      if (xmap) myc = xmap[myc];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int c0 = __shfl(myc, t, 16);
+      const double v0 = __shfl(myv, t, 16);
+      const double* x0 = x + (size_t)c0 * ldx;
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int col = g + 16 * c;
+        if (col < m) acc[c] = fma(v0, x0[col], acc[c]);
+      }
+    }
+  }
+  if (!live) return;
+  const double sc = alpha * (rowscale ? rowscale[row] : 1.0);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int col = g + 16 * c;
+    if (col < m) {
+      double out = sc * acc[c];
+      if (r) out += beta_r * r[(size_t)row * ldr + col];
+      y[(size_t)row * ldy + col] = out;
+    }
+  }
+}
+
+static int spmm_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RICADI_SPMM");
+    v = (e && e[0] == '1') ? 1 : 2;
+  }
+  return v;
+}
+
 void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
                  const double* x, int ldx, const int* xmap, double* y, int ldy,
                  const double* r, int ldr, double alpha, double beta_r,
@@ -83,10 +161,15 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
   if (nrows <= 0 || m <= 0) return;
   dim3 grid((nrows + 15) / 16), block(256);
   const int cpl = (m + 15) / 16;
+  const bool v2 = spmm_variant() == 2;
 #define RICADI_SPMM_CASE(C)                                                              \
   case C:                                                                                \
-    hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, nrows, rp, ci, val, x, ldx,   \
-                       xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);                \
+    if (v2)                                                                              \
+      hipLaunchKernelGGL(spmm_kernel_v2<C>, grid, block, 0, st, nrows, rp, ci, val, x,   \
+                         ldx, xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);         \
+    else                                                                                 \
+      hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, nrows, rp, ci, val, x, ldx, \
+                         xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);              \
     break;
   switch (cpl) {
     RICADI_SPMM_CASE(1)
@@ -218,14 +301,33 @@ __global__ __launch_bounds__(256) void cols_dots_kernel(
   }
 }
 
-// out[o] (+)= sum_b partial[b][o]
-__global__ void reduce_partials_kernel(int nblk, int nout, const double* __restrict__ partial,
-                                       double* __restrict__ out, int accumulate) {
-  int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= nout) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * nout + o];
-  out[o] = accumulate ? out[o] + s : s;
+// out[o] (+)= sum_b partial[b][o].  256 threads = 16 outputs x 16 block-slices:
+// the 16 lanes of a group read 16 consecutive outputs of one partial row (one
+// 128-B line), the 16 groups stride over the workgroups; LDS tree at the end.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(int nblk, int nout,
+                                                              const double* __restrict__ partial,
+                                                              double* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ double red[16][17];
+  const int oo = threadIdx.x & 15, bsl = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + oo;
+  double s0 = 0.0, s1 = 0.0;
+  if (o < nout) {
+    int b = bsl;
+    for (; b + 16 < nblk; b += 32) {
+      s0 += partial[(size_t)b * nout + o];
+      s1 += partial[(size_t)(b + 16) * nout + o];
+    }
+    if (b < nblk) s0 += partial[(size_t)b * nout + o];
+  }
+  red[bsl][oo] = s0 + s1;
+  __syncthreads();
+  if (bsl == 0 && o < nout) {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[t][oo];
+    out[o] = accumulate ? out[o] + s : s;
+  }
 }
 
 int dots_num_blocks(int nrows) { return (nrows + DOT_ROWS - 1) / DOT_ROWS; }
@@ -238,8 +340,8 @@ void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* 
   if (nout == 0) return;
   hipLaunchKernelGGL(cols_dots_kernel, dim3(nblk), dim3(256), DOT_ROWS * m * sizeof(double), st,
                      nrows, m, nvec, basis, vstride, w, want_self, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 127) / 128), dim3(128), 0, st, nblk,
-                     nout, partial, out, 0);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16), dim3(256), 0, st, nblk, nout,
+                     partial, out, 0);
 }
 
 // out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
@@ -387,27 +489,49 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
     int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
     const double* __restrict__ inv, const double* __restrict__ in, int ldi,
     double* __restrict__ out, int ldo, int m) {
+  // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
+  // inv[rows 16*ti.., k] * x[k, cols].  A-operand lane (r = l&15, q = l>>4)
+  // holds inv[16*ti + r][k0 + 4q + s] for MFMA s of a 16-wide k chunk (one
+  // 32-B load per lane and chunk); the matching B operand is the gathered
+  // input row rows[k0 + 4q + s], column c0 + r.
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= nblocks) return;
   const int lane = threadIdx.x & 63;
-  const int s = lane >> 4, g = lane & 15;
+  const int r = lane & 15, q = lane >> 4;
   const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
   const double* Bi = inv + (size_t)wave * BS * BS;
-  for (int cc = g; cc < m; cc += 16) {
-    double xin[BS];
+  constexpr int NT = BS / 16;
+  for (int c0 = 0; c0 < m; c0 += 16) {
+    const int col = c0 + r;
+    d4 acc[NT];
 #pragma unroll
-    for (int jl = 0; jl < BS; ++jl)
-      xin[jl] = (jl < nb) ? in[(size_t)rows[b0 + jl] * ldi + cc] : 0.0;
-    for (int il = s; il < nb; il += 4) {
-      const double* bi = Bi + il * BS;
-      double a0 = 0.0, a1 = 0.0;
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int jl = 0; jl < BS; jl += 2) {
-        a0 = fma(bi[jl], xin[jl], a0);
-        a1 = fma(bi[jl + 1], xin[jl + 1], a1);
+    for (int kc = 0; kc < NT; ++kc) {          // 16-wide chunks of the block's columns
+      double xb[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int kk = kc * 16 + 4 * q + s2;
+        xb[s2] = (kk < nb && col < m) ? in[(size_t)rows[b0 + kk] * ldi + col] : 0.0;
       }
-      out[(size_t)rows[b0 + il] * ldo + cc] = a0 + a1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const double2* p =
+            reinterpret_cast<const double2*>(Bi + (size_t)(16 * t + r) * BS + kc * 16 + 4 * q);
+        const double2 u = p[0], v = p[1];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, xb[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, xb[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, xb[2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, xb[3], acc[t], 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int il = 16 * t + q + 4 * e;
+        if (il < nb && col < m) out[(size_t)rows[b0 + il] * ldo + col] = acc[t][e];
+      }
   }
 }
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
@@ -579,45 +703,63 @@ void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows
                      in, ldi, rc, m);
 }
 
-// ec = Einv (k x k, row-major) * rc (k x m).  One wave per output row and
-// 16-column chunk; lanes run along the row of Einv (coalesced), 16 register
-// accumulators, butterfly reduction at the end.
-__global__ __launch_bounds__(256) void dense_apply_kernel(int k, int m,
+// ec = Einv (k x k, row-major) * rc (k x m) on the FP64 matrix cores.
+// A workgroup of 8 waves owns 16 output rows x 16 columns; wave w sweeps the
+// k-range [w*kslice, (w+1)*kslice) in chunks of 16 columns of Einv.  Per chunk a
+// lane (r = l&15, q = l>>4) loads Einv[i0+r][j0+4q .. j0+4q+3] as one 32-B
+// vector (the 4 q-lanes of a row cover one 128-B line) and feeds element s to
+// MFMA s; the k index of that MFMA's slot q is column j0+4q+s, so the B operand
+// is rc[j0+4q+s][c].  Partial tiles are summed through LDS.
+typedef double d4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void dense_apply_kernel(int k, int m,
                                                           const double* __restrict__ Einv,
                                                           const double* __restrict__ rc,
                                                           double* __restrict__ ec) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const int nchunk = (m + 15) / 16;
-  if (wave >= k * nchunk) return;
-  const int i = wave / nchunk, c0 = (wave - i * nchunk) * 16;
-  const int mc = min(16, m - c0);
-  double acc[16];
+  __shared__ double red[8][16][17];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+  const int nchunk = (k + 15) / 16;
+  const int per = (nchunk + 7) / 8;
+  const int ch0 = w * per, ch1 = min(nchunk, ch0 + per);
+  const int row = i0 + r;
+  const int col = c0 + r;           // B / D column owned by this lane
+  d4v acc = {0.0, 0.0, 0.0, 0.0};
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int j = ch * 16 + 4 * q;
+    double a[4];
+    if (row < k && j + 3 < k && ((size_t)row * k + j) % 2 == 0) {
+      const double2* p = reinterpret_cast<const double2*>(Einv + (size_t)row * k + j);
+      const double2 u = p[0], v = p[1];
+      a[0] = u.x; a[1] = u.y; a[2] = v.x; a[3] = v.y;
+    } else {
 #pragma unroll
-  for (int t = 0; t < 16; ++t) acc[t] = 0.0;
-  const double* Ei = Einv + (size_t)i * k;
-  for (int j = lane; j < k; j += 64) {
-    const double e = Ei[j];
-    const double* rj = rc + (size_t)j * m + c0;
+      for (int t = 0; t < 4; ++t) a[t] = (row < k && j + t < k) ? Einv[(size_t)row * k + j + t] : 0.0;
+    }
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (t < mc) acc[t] = fma(e, rj[t], acc[t]);
+    for (int t = 0; t < 4; ++t) {
+      const int jj = j + t;
+      const double b = (jj < k && col < m) ? rc[(size_t)jj * m + col] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b, acc, 0, 0, 0);
+    }
   }
+  // D[row = q + 4*e][col = r]
 #pragma unroll
-  for (int t = 0; t < 16; ++t) {
-    double v = acc[t];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    acc[t] = v;
+  for (int e = 0; e < 4; ++e) red[w][q + 4 * e][r] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum += red[t][rr][cc];
+    if (i0 + rr < k && c0 + cc < m) ec[(size_t)(i0 + rr) * m + c0 + cc] = sum;
   }
-  if (lane == 0)
-    for (int t = 0; t < mc; ++t) ec[(size_t)i * m + c0 + t] = acc[t];
 }
 void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
                         double* ec) {
   if (k <= 0) return;
-  const int nwaves = k * ((m + 15) / 16);
-  hipLaunchKernelGGL(dense_apply_kernel, dim3((nwaves + 3) / 4), dim3(256), 0, st, k, m, Einv, rc,
-                     ec);
+  dim3 grid((k + 15) / 16, (m + 15) / 16);
+  hipLaunchKernelGGL(dense_apply_kernel, grid, dim3(512), 0, st, k, m, Einv, rc, ec);
 }
 
 // z[r, :] += ec[aggof[r], :]
@@ -649,8 +791,6 @@ void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, cons
 // line.  A wave owns TI x TJ tiles of C over a row range; partial results are
 // added with FP64 atomics (C must be zeroed by the caller).
 // ---------------------------------------------------------------------------
-typedef double d4 __attribute__((ext_vector_type(4)));
-
 template <int TI, int TJ>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
                                                       const double* __restrict__ A, int lda,

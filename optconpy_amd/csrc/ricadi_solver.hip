@@ -393,6 +393,25 @@ struct DScalar {
   }
 };
 
+static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
+                        bool thresh_relative, double* dOut, std::vector<double>* sv_host);
+
+// Truncation level of the internal recompressions: the Gram-matrix route
+// resolves singular values down to sqrt(eps)*sigma_1; dropping what lies below
+// changes Z Z^T by at most eps*||Z Z^T|| -- rounding level.
+static const double kInternalRelThresh = 3e-8;
+
+// Recompress the device factor in place (columns [0, zc) of c->Z).
+static void factor_recompress(ricadi_ctx* c) {
+  if (c->zc == 0) return;
+  DArr<double> tmp;
+  tmp.alloc((size_t)c->nv * c->zc);
+  const int k = compress_dev(c, c->Z.p, c->zc, c->zld, kInternalRelThresh, 0, true, tmp.p, nullptr);
+  if (k > 0) launch_copy_cols(c->st, c->nv, k, tmp.p, k, 0, c->Z.p, c->zld, 0, 1.0);
+  HIPCHK(hipStreamSynchronize(c->st));
+  c->zc = k;
+}
+
 // ---- low-rank ADI (device resident) -------------------------------------------------
 struct AdiStats {
   int steps = 0;
@@ -412,6 +431,7 @@ static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double
   if (prm.project_w) project_panel(c, dW, m);
   const long it0 = c->total_iters;
   double znorm2 = 0.0;
+  int zc_last = c->zc;
   for (int step = 1; step <= prm.adi_max_steps; ++step) {
     const double p = shifts[(step - 1) % ns];
     ShiftData* sd = get_shift(c, p, 1.0);
@@ -440,6 +460,10 @@ static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double
       fprintf(stderr, "[ricadi] ADI step %3d: shift %10.3e rel new Z %9.3e gmres its %d\n", step,
               p, stt.rel, r.iters);
     if (stt.rel < prm.adi_newZ_reltol) break;
+    if (prm.compress_cols > 0 && c->zc - zc_last >= prm.compress_cols) {
+      factor_recompress(c);
+      zc_last = c->zc;
+    }
   }
   stt.gmres_iters = c->total_iters - it0;
   DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
@@ -604,6 +628,7 @@ void ricadi_default_adi_params(ricadi_adi_params* p) {
   p->nwtn_upd_abstol = 1e-7;
   p->project_w = 1;
   p->verbose = 0;
+  p->compress_cols = 0;
 }
 
 int ricadi_create(int device_id, ricadi_ctx** out) {
@@ -1002,6 +1027,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   ricadi_adi_params p2 = *prm;
   if (prm->project_w) project_panel(c, dWm.p, mw);
   p2.project_w = 0;
+  if (p2.compress_cols <= 0) p2.compress_cols = 512;
   double upd = 0, updrel = 0;
   long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves;
   int steps = 0;
@@ -1030,9 +1056,11 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     factor_reserve(c, prm->adi_max_steps * m);
     AdiStats s = lyap_adi_dev(c, shifts, ns, dRhs.p, m, p2);
     adi_total += s.steps;
-    // compressed copy of the new iterate (relative threshold at rounding level)
+    // compressed copy of the new iterate (truncation at the Gram noise floor)
+    factor_recompress(c);
     Znew.alloc((size_t)nv * c->zc);
-    int knew = compress_dev(c, c->Z.p, c->zc, c->zld, 1e-14, 0, true, Znew.p, nullptr);
+    const int knew = c->zc;
+    launch_copy_cols(st, nv, knew, c->Z.p, c->zld, 0, Znew.p, knew, 0, 1.0);
     double x1 = 0.0;
     upd = diff_zzt_fnorm(c, Znew.p, knew, Zk.p, kk, &x1);
     updrel = x1 > 0.0 ? upd / x1 : 0.0;

@@ -16,7 +16,7 @@ def lists(blk, nb):
     return order, ptr
 
 
-def mirror(calA, calE, J, alpha, beta, bs=32, av=16, ap=32, coarse_max=4096, use_coarse=True):
+def mirror(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, coarse_max=4096, use_coarse=True):
     nv, npp = calA.shape[0], J.shape[0]
     pat = (abs(calA) + abs(calE)).tocsr()
     pat.sort_indices()
