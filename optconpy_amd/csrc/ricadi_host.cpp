@@ -206,6 +206,69 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   hs.nbp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), bs, pblk.data()) : 0;
   lists_from_blocks(np, pblk.data(), hs.nbp, hs.bp_ptr, hs.bp_rows);
 
+  // ---- row blocks of the LDS-tiled SpMM ------------------------------------
+  // Rows are visited aggregate by aggregate (compact mesh patches) and packed
+  // greedily into blocks of <= 32 rows whose set of distinct columns stays
+  // within kSbMaxCols, so that the x tile of a block fits the LDS budget.
+  {
+    const int kSbMaxRows = 32, kSbMaxCols = 160;
+    std::vector<int> order;
+    order.reserve(n);
+    for (int q = 0; q < nv; ++q) order.push_back(hs.bv_rows[q]);
+    for (int q = 0; q < np; ++q) order.push_back(nv + hs.bp_rows[q]);
+    hs.sb_rowptr.assign(1, 0);
+    hs.sb_rows.clear();
+    hs.sb_rp.assign(1, 0);
+    hs.sb_cptr.assign(1, 0);
+    hs.sb_cols.clear();
+    hs.sb_perm.clear();
+    hs.sb_lidx.clear();
+    hs.sb_max_cols = hs.sb_max_nnz = 0;
+    std::vector<int> stamp(n, -1), pos(n, -1), cols, brows;
+    int bid = 0;
+    size_t at = 0;
+    while (at < order.size()) {
+      cols.clear();
+      brows.clear();
+      // a velocity block never continues into the pressure rows
+      const bool vel = order[at] < nv;
+      while (at < order.size() && (int)brows.size() < kSbMaxRows && (order[at] < nv) == vel) {
+        const int row = order[at];
+        int fresh = 0;
+        for (int k = hs.s_rp[row]; k < hs.s_rp[row + 1]; ++k)
+          if (stamp[hs.s_ci[k]] != bid) ++fresh;
+        if (!brows.empty() && (int)cols.size() + fresh > kSbMaxCols) break;
+        for (int k = hs.s_rp[row]; k < hs.s_rp[row + 1]; ++k) {
+          const int c = hs.s_ci[k];
+          if (stamp[c] != bid) {
+            stamp[c] = bid;
+            cols.push_back(c);
+          }
+        }
+        brows.push_back(row);
+        ++at;
+      }
+      std::sort(cols.begin(), cols.end());
+      for (size_t j = 0; j < cols.size(); ++j) pos[cols[j]] = (int)j;
+      const size_t nnz0 = hs.sb_perm.size();
+      for (int row : brows) {
+        for (int k = hs.s_rp[row]; k < hs.s_rp[row + 1]; ++k) {
+          hs.sb_perm.push_back(k);
+          hs.sb_lidx.push_back((uint16_t)pos[hs.s_ci[k]]);
+        }
+        hs.sb_rows.push_back(row);
+        hs.sb_rp.push_back((int)hs.sb_perm.size());
+      }
+      for (int c : cols) hs.sb_cols.push_back(c);
+      hs.sb_cptr.push_back((int)hs.sb_cols.size());
+      hs.sb_rowptr.push_back((int)hs.sb_rows.size());
+      hs.sb_max_cols = std::max(hs.sb_max_cols, (int)cols.size());
+      hs.sb_max_nnz = std::max(hs.sb_max_nnz, (int)(hs.sb_perm.size() - nnz0));
+      ++bid;
+    }
+    hs.sb_nblk = bid;
+  }
+
   // ---- aggregation coarse space -------------------------------------------
   hs.kc = hs.kcv = hs.kcp = 0;
   hs.agg_ptr.assign(1, 0);

@@ -46,6 +46,12 @@ struct HostSetup {
   // block-Jacobi, Schur complement
   int nbp = 0;
   std::vector<int> bp_ptr, bp_rows;  // rows are pressure-local (0..np)
+  // LDS-tiled SpMM: rows grouped in blocks of <= 64 (pairs of block-Jacobi
+  // aggregates = compact mesh patches); per block the distinct columns and
+  // 16-bit local column indices; arrays in block order
+  int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
+  std::vector<int> sb_rowptr, sb_rows, sb_rp, sb_cptr, sb_cols, sb_perm;
+  std::vector<uint16_t> sb_lidx;
   // coarse level
   int kc = 0, kcv = 0, kcp = 0;
   std::vector<int> agg_ptr, agg_rows;  // aggregates over all n dofs
@@ -60,6 +66,13 @@ int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
 void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
                  const double* x, int ldx, const int* xmap, double* y, int ldy, const double* r,
                  int ldr, double alpha, double beta_r, const double* rowscale, int m);
+void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
+                         const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
+                         const double* val, const double* x, int ldx, const int* xmap, double* y,
+                         int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
+                         int max_cols, int max_nnz);
+size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz);
+void launch_gather_vals(hipStream_t st, int nnz, const int* perm, const double* src, double* dst);
 void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const double* srcE,
                            const double* srcJ, double alpha, double beta, double* out);
 void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, double alpha,

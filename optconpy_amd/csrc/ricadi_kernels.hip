@@ -19,6 +19,22 @@ namespace ricadi {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Broadcast lane T of every 16-lane row to the whole row on the VALU
+// (DPP row_newbcast, gfx90a+): no LDS instruction, unlike __shfl/ds_bpermute.
+// The SpMM kernels were LDS-pipe bound by their broadcasts (SQ_ACTIVE_INST_LDS
+// ~72 % of the kernel, profiles/r01_spmm_pmc.txt).
+template <int T>
+__device__ __forceinline__ int bc16i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + T, 0xF, 0xF, false);
+}
+template <int T>
+__device__ __forceinline__ double bc16d(double v) {
+  const int lo = bc16i<T>(__double2loint(v));
+  const int hi = bc16i<T>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#define RICADI_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+
 // ---------------------------------------------------------------------------
 // K1: CSR SpMM on row-major panels.
 //   y[i,:] = beta_r * r[i,:] + alpha * rowscale[i] * sum_k val[k] * x[xrow(col[k]),:]
@@ -120,17 +136,18 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
       myv = val[k];
       if (xmap) myc = xmap[myc];
     }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int c0 = __shfl(myc, t, 16);
-      const double v0 = __shfl(myv, t, 16);
-      const double* x0 = x + (size_t)c0 * ldx;
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        const int col = g + 16 * c;
-        if (col < m) acc[c] = fma(v0, x0[col], acc[c]);
-      }
-    }
+#define RICADI_V2_STEP(T)                                             \
+  {                                                                   \
+    const int c0 = bc16i<T>(myc);                                     \
+    const double v0 = bc16d<T>(myv);                                  \
+    const double* x0 = x + (size_t)c0 * ldx;                          \
+    _Pragma("unroll") for (int c = 0; c < CPL; ++c) {                 \
+      const int col = g + 16 * c;                                     \
+      if (col < m) acc[c] = fma(v0, x0[col], acc[c]);                 \
+    }                                                                 \
+  }
+    RICADI_FOR16(RICADI_V2_STEP)
+#undef RICADI_V2_STEP
   }
   if (!live) return;
   const double sc = alpha * (rowscale ? rowscale[row] : 1.0);
@@ -184,6 +201,162 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
       break;  // m <= RICADI_MAX_M = 128 is enforced by the callers
   }
 #undef RICADI_SPMM_CASE
+}
+
+// ---------------------------------------------------------------------------
+// K1, LDS-tiled variant for the saddle operator.
+//
+// Rows are processed in blocks of <= 64 rows that form a compact patch of the
+// mesh (pairs of block-Jacobi aggregates), listed in `rows` -- the panels keep
+// the caller's row order: with m = 16 a panel row is one 128-B line, so neither
+// the gather of x rows nor the scatter of y rows needs neighbouring rows to be
+// neighbours in memory.  Per block:
+//   phase 1  the block's DISTINCT x rows (cols[cptr[b]..)) are loaded once into
+//            an LDS tile (one coalesced 128-B row per 16-lane group and load,
+//            all loads of a thread independent), and the block's slice of the
+//            matrix (values + 16-bit local column indices, contiguous in block
+//            order) is streamed into LDS with fully coalesced loads;
+//   phase 2  every 16-lane group accumulates its rows from LDS only.
+// A row of x is thus read from L2/HBM once per block instead of once per
+// non-zero (the v2 kernel re-gathers every row ~28 times through the vector L1).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_blocked_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ rows, const int* __restrict__ rp,
+    const int* __restrict__ cptr, const int* __restrict__ cols,
+    const uint16_t* __restrict__ lidx, const double* __restrict__ val,
+    const double* __restrict__ x, int ldx, const int* __restrict__ xmap,
+    double* __restrict__ y, int ldy, const double* __restrict__ r, int ldr, double alpha,
+    double beta_r, int m, int max_cols, int max_nnz) {
+  extern __shared__ double xs[];                             // max_cols x m
+  // XCD-contiguous block ranges (bijective remap, cdna guide T1)
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+  const int b = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int g = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int c0 = cptr[b], nc = cptr[b + 1] - c0;
+  const int q0 = rowptr[b], nr = rowptr[b + 1] - q0;
+  // phase 0: the (value, local index) pairs of this group's two rows (blocks
+  // hold <= 32 rows) are requested FIRST, 16 per lane-row and chunk, so that
+  // they are in flight together with the x-tile gathers of phase 1.
+  constexpr int NR = 2, NCH = 4;               // rows per group, 16-entry chunks held in registers
+  int ka[NR], kb[NR];
+  double myv[NR][NCH];
+  int myl[NR][NCH];
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    const int q = gq + 16 * rr;
+    ka[rr] = (q < nr) ? rp[q0 + q] : 0;
+    kb[rr] = (q < nr) ? rp[q0 + q + 1] : 0;
+  }
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int k = ka[rr] + ch * 16 + g;
+      const bool ok = k < kb[rr];
+      myv[rr][ch] = ok ? val[k] : 0.0;
+      myl[rr][ch] = ok ? (int)lidx[k] : 0;
+    }
+  // phase 1: x tile.  Indices first, then ALL gathers of the thread, then the
+  // LDS stores -- so that the loads are in flight together (a load followed by
+  // its own ds_write makes hipcc wait vmcnt(0) per row).
+  constexpr int XJ = 10;                       // 16 groups x 10 = 160 tile rows per pass
+  for (int cc = g; cc < m; cc += 16) {
+    for (int jb = 0; jb < nc; jb += 16 * XJ) {
+      int cidx[XJ];
+      double xv[XJ];
+#pragma unroll
+      for (int t = 0; t < XJ; ++t) {
+        const int j = jb + gq + 16 * t;
+        int c = (j < nc) ? cols[c0 + j] : -1;
+        if (xmap && c >= 0) c = xmap[c];
+        cidx[t] = c;
+      }
+#pragma unroll
+      for (int t = 0; t < XJ; ++t) xv[t] = (cidx[t] >= 0) ? x[(size_t)cidx[t] * ldx + cc] : 0.0;
+#pragma unroll
+      for (int t = 0; t < XJ; ++t) {
+        const int j = jb + gq + 16 * t;
+        if (j < nc) xs[j * m + cc] = xv[t];
+      }
+    }
+  }
+  __syncthreads();
+  // phase 2: operands: matrix entries from registers (broadcast inside the
+  // 16-lane row by DPP), x from the LDS tile.
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    const int q = gq + 16 * rr;
+    const bool live = q < nr;
+    // chunks needed by any of the wave's four groups (DPP needs all lanes)
+    int nch = (kb[rr] - ka[rr] + 15) >> 4;
+    nch = max(nch, __shfl_xor(nch, 16, 64));
+    nch = max(nch, __shfl_xor(nch, 32, 64));
+    for (int cc = g; cc < m + (16 - (m & 15)) % 16; cc += 16) {
+      const int ccs = cc < m ? cc : 0;         // lanes beyond m stay in the broadcasts
+      double a0 = 0.0, a1 = 0.0;
+#define RICADI_TILE_STEP(T)                                           \
+  {                                                                   \
+    const int l0 = bc16i<T>(lcur);                                    \
+    const double v0 = bc16d<T>(vcur);                                 \
+    if ((T)&1)                                                        \
+      a1 = fma(v0, xs[l0 * m + ccs], a1);                             \
+    else                                                              \
+      a0 = fma(v0, xs[l0 * m + ccs], a0);                             \
+  }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if (ch < nch) {
+          const int lcur = myl[rr][ch];
+          const double vcur = myv[rr][ch];
+          RICADI_FOR16(RICADI_TILE_STEP)
+        }
+      }
+      // rows longer than NCH*16 entries: stream the rest
+      for (int ch = NCH; ch < nch; ++ch) {
+        const int k = ka[rr] + ch * 16 + g;
+        int lcur = 0;
+        double vcur = 0.0;
+        if (k < kb[rr]) {
+          lcur = lidx[k];
+          vcur = val[k];
+        }
+        RICADI_FOR16(RICADI_TILE_STEP)
+      }
+#undef RICADI_TILE_STEP
+      if (live && cc < m) {
+        const int row = rows[q0 + q];
+        double out = alpha * (a0 + a1);
+        if (r) out += beta_r * r[(size_t)row * ldr + cc];
+        y[(size_t)row * ldy + cc] = out;
+      }
+    }
+  }
+}
+size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz) {
+  (void)max_nnz;
+  return (size_t)max_cols * m * sizeof(double) + 16;
+}
+void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
+                         const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
+                         const double* val, const double* x, int ldx, const int* xmap, double* y,
+                         int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
+                         int max_cols, int max_nnz) {
+  if (nblk <= 0) return;
+  hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk), dim3(256),
+                     spmm_blocked_lds_bytes(m, max_cols, max_nnz), st, rowptr, rows, rp, cptr, cols,
+                     lidx, val, x, ldx, xmap, y, ldy, r, ldr, alpha, beta_r, m, max_cols, max_nnz);
+}
+
+// dst[k] = src[perm[k]]  (assembled CSR values -> block order)
+__global__ void gather_vals_kernel(int nnz, const int* __restrict__ perm,
+                                   const double* __restrict__ src, double* __restrict__ dst) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += gridDim.x * blockDim.x)
+    dst[k] = src[perm[k]];
+}
+void launch_gather_vals(hipStream_t st, int nnz, const int* perm, const double* src, double* dst) {
+  int grid = std::min((nnz + 255) / 256, 2048);
+  hipLaunchKernelGGL(gather_vals_kernel, dim3(grid), dim3(256), 0, st, nnz, perm, src, dst);
 }
 
 // S_val = alpha * srcE + beta * srcA + srcJ on the unified saddle pattern.

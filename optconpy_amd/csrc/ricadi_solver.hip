@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -66,7 +67,7 @@ struct DArr {
 
 struct ShiftData {
   double alpha = 0, beta = 0;
-  DArr<double> sval, dinv, bvinv, bpinv, einv;
+  DArr<double> sval, svalb, dinv, bvinv, bpinv, einv;
 };
 
 struct DevCsr {
@@ -103,6 +104,11 @@ struct ricadi_ctx {
   DArr<double> bvA, bvE;
   DArr<int> agg_ptr, agg_rows, aggof;
   DArr<double> E0, EM, EJ;
+  // LDS-tiled SpMM structure
+  int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
+  bool sb_ok = false;
+  DArr<int> sb_rowptr, sb_rows, sb_rp, sb_cptr, sb_cols, sb_perm;
+  DArr<uint16_t> sb_lidx;
   // low rank
   int q = 0;
   DArr<double> U, V, lrc;
@@ -175,6 +181,10 @@ static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
   sd->sval.alloc(c->snnz);
   launch_assemble_shift(st, (int)c->snnz, c->srcA.p, c->srcE.p, c->srcJ.p, alpha, beta,
                         sd->sval.p);
+  if (c->sb_ok) {
+    sd->svalb.alloc(c->snnz);
+    launch_gather_vals(st, (int)c->snnz, c->sb_perm.p, sd->sval.p, sd->svalb.p);
+  }
   sd->dinv.alloc(c->nv);
   launch_diag_inv(st, c->nv, c->dA.p, c->dE.p, alpha, beta, sd->dinv.p);
   HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
@@ -211,12 +221,28 @@ static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
 }
 
 // ---- operator and preconditioner on device panels ---------------------------------
+// y = beta_r * r + alpha * S x on the saddle operator (optionally through the
+// prolongation map): LDS-tiled kernel when the block tiles fit, else the CSR one.
+static void saddle_spmm(ricadi_ctx* c, const ShiftData* sd, const double* x, const int* xmap,
+                        double* y, const double* r, double alpha, double beta_r, int m) {
+  static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
+  const bool fits =
+      c->sb_ok && !force_csr &&
+      spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
+  if (fits)
+    launch_spmm_blocked(c->st, c->sb_nblk, c->sb_rowptr.p, c->sb_rows.p, c->sb_rp.p, c->sb_cptr.p,
+                        c->sb_cols.p, c->sb_lidx.p, sd->svalb.p, x, m, xmap, y, m, r, m, alpha,
+                        beta_r, m, c->sb_max_cols, c->sb_max_nnz);
+  else
+    launch_spmm(c->st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, x, m, xmap, y, m, r, m, alpha,
+                beta_r, nullptr, m);
+}
+
 // y = S(alpha,beta) x   (n x m panels, ld = m); optional low-rank  - U V^T x_v
 static void op_apply(ricadi_ctx* c, const ShiftData* sd, const double* x, double* y, int m,
                      bool lowrank) {
   hipStream_t st = c->st;
-  launch_spmm(st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, x, m, nullptr, y, m, nullptr, 0, 1.0,
-              0.0, nullptr, m);
+  saddle_spmm(c, sd, x, nullptr, y, nullptr, 1.0, 0.0, m);
   if (lowrank && c->q > 0) {
     HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * c->q * m, st));
     launch_gemm_tn(st, c->nv, c->q, m, c->V.p, c->q, x, m, c->lrc.p, m);
@@ -234,8 +260,7 @@ static void precond_apply(ricadi_ctx* c, const ShiftData* sd, const double* r, d
     launch_restrict(st, c->kc, c->agg_ptr.p, c->agg_rows.p, r, m, c->rc.p, m);
     launch_dense_apply(st, c->kc, m, sd->einv.p, c->rc.p, c->ec.p);
     // r2 = r - S * (Y ec), prolongation folded into the gather
-    launch_spmm(st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, c->ec.p, m, c->aggof.p, c->r2.p, m, r,
-                m, -1.0, 1.0, nullptr, m);
+    saddle_spmm(c, sd, c->ec.p, c->aggof.p, c->r2.p, r, -1.0, 1.0, m);
     rr = c->r2.p;
   }
   launch_block_apply(st, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, sd->bvinv.p, rr, m, z, m, m);
@@ -746,13 +771,26 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->E0.upload(hs.E0, st);
   c->EM.upload(hs.EM, st);
   c->EJ.upload(hs.EJ, st);
+  c->sb_nblk = hs.sb_nblk;
+  c->sb_max_cols = hs.sb_max_cols;
+  c->sb_max_nnz = hs.sb_max_nnz;
+  c->sb_rowptr.upload(hs.sb_rowptr, st);
+  c->sb_rows.upload(hs.sb_rows, st);
+  c->sb_rp.upload(hs.sb_rp, st);
+  c->sb_cptr.upload(hs.sb_cptr, st);
+  c->sb_cols.upload(hs.sb_cols, st);
+  c->sb_perm.upload(hs.sb_perm, st);
+  c->sb_lidx.upload(hs.sb_lidx, st);
+  c->sb_ok = hs.sb_nblk > 0 && hs.sb_max_cols < 65536;
   c->q = 0;
   c->wm = 0;  // workspaces depend on n
   c->zc = 0;
   c->has_op = true;
   if (c->opts.verbose)
-    fprintf(stderr, "[ricadi] operator nv=%d np=%d nnz(S)=%zu | BJ blocks %d+%d (bs=%d) | coarse %d (%d+%d)\n",
-            nv, np, c->snnz, c->nbv, c->nbp, c->bs, c->kc, hs.kcv, hs.kcp);
+    fprintf(stderr, "[ricadi] operator nv=%d np=%d nnz(S)=%zu | BJ blocks %d+%d (bs=%d) | coarse %d (%d+%d) | "
+            "SpMM row blocks %d (max %d distinct cols, %d nnz; mean %.0f cols)\n",
+            nv, np, c->snnz, c->nbv, c->nbp, c->bs, c->kc, hs.kcv, hs.kcp, hs.sb_nblk,
+            hs.sb_max_cols, hs.sb_max_nnz, hs.sb_nblk ? (double)hs.sb_cols.size() / hs.sb_nblk : 0.0);
   API_END
 }
 
@@ -949,9 +987,7 @@ int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double*
   HIPCHK(hipEventCreate(&e1));
   // plain assembled-CSR saddle SpMM only (no low-rank term): the roofline kernel
   HIPCHK(hipEventRecord(e0, c->st));
-  for (int i = 0; i < reps; ++i)
-    launch_spmm(c->st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, dX, m, nullptr, dY, m, nullptr, 0,
-                1.0, 0.0, nullptr, m);
+  for (int i = 0; i < reps; ++i) saddle_spmm(c, sd, dX, nullptr, dY, nullptr, 1.0, 0.0, m);
   HIPCHK(hipEventRecord(e1, c->st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;

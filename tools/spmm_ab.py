@@ -5,7 +5,7 @@ import numpy as np, torch
 from optconpy_amd import _lib, problems as pb
 N = int(sys.argv[1]); m = int(sys.argv[2])
 pr = pb.ricc_problem(N, 0.05)
-ctx = _lib.Context(0, use_coarse=0)
+ctx = _lib.Context(0, use_coarse=0, verbose=1)
 calA = (-pr.A - pr.Nc).T.tocsr()
 ctx.set_operator(calA, pr.M.T.tocsr(), pr.J)
 n = pr.NV + pr.NP
