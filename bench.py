@@ -63,7 +63,7 @@ def spmm_roofline(ctx, nnz_s, n, m, reps=200):
     gbs = nbytes / (ms * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
-                kernel="ricadi::spmm_kernel_v2<1>", us_per_launch=round(ms * 1e3, 2),
+                kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(ms * 1e3, 2),
                 algorithmic_bytes=int(nbytes), n=int(n), m=int(m), nnz=int(nnz_s))
 
 

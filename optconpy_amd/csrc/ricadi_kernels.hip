@@ -557,59 +557,78 @@ void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double
 // applies the stored rotations, creates the new one, writes scale = 1/h_{j+1,j}
 // (0 on breakdown / frozen column) and the residual estimate |g_{j+1}|.
 // ---------------------------------------------------------------------------
-__global__ void gmres_hess_kernel(int m, int j, int restart, const double* __restrict__ h1,
-                                  const double* __restrict__ h2, double* __restrict__ H,
-                                  double* __restrict__ cs, double* __restrict__ sn,
-                                  double* __restrict__ g, double* __restrict__ scale,
-                                  double* __restrict__ resid, const double* __restrict__ bnorm,
-                                  double tol) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= m) return;
+// One 64-lane workgroup per panel column: the lanes stage h1+h2, cs, sn in LDS
+// with independent loads (and reduce ||h2||^2 with shuffles); lane 0 then runs
+// the sequential rotation chain out of LDS instead of a chain of dependent
+// global loads.
+__global__ __launch_bounds__(64) void gmres_hess_kernel(
+    int m, int j, int restart, const double* __restrict__ h1, const double* __restrict__ h2,
+    double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
+    double* __restrict__ g, double* __restrict__ scale, double* __restrict__ resid,
+    const double* __restrict__ bnorm, double tol) {
+  extern __shared__ double sh[];       // hcol[restart+2], csl[restart], snl[restart]
+  double* hcol = sh;
+  double* csl = sh + restart + 2;
+  double* snl = csl + restart;
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
   double* Hc = H + (size_t)c * (restart + 1) * restart + (size_t)j * (restart + 1);
   double* csc = cs + (size_t)c * restart;
   double* snc = sn + (size_t)c * restart;
   double* gc = g + (size_t)c * (restart + 1);
   const int nv = j + 1;
-  double h2sq = 0.0;
-  for (int i = 0; i < nv; ++i) {
+  double part = 0.0;
+  for (int i = lane; i < nv; i += 64) {
     const double b = h2[i * m + c];
-    h2sq += b * b;
-    Hc[i] = h1[i * m + c] + b;
+    part += b * b;
+    hcol[i] = h1[i * m + c] + b;
   }
+  for (int i = lane; i < j; i += 64) {
+    csl[i] = csc[i];
+    snl[i] = snc[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  __syncthreads();
+  if (lane != 0) return;
+  const double h2sq = part;
   const double ww = h2[nv * m + c];  // ||w'||^2 before the second projection
+  const double gj = gc[j];
   double hn2 = ww - h2sq;
   double hnext = hn2 > 0.0 ? sqrt(hn2) : 0.0;
   // frozen column (already converged, or exact breakdown): keep it inert
   const double tiny = 1e-300;
-  const bool dead = !(hnext > tiny) || (fabs(gc[j]) <= 0.01 * tol * bnorm[c]);
+  const bool dead = !(hnext > tiny) || (fabs(gj) <= 0.01 * tol * bnorm[c]);
   if (dead) hnext = 0.0;
+  double cur = hcol[0];
   for (int i = 0; i < j; ++i) {
-    const double t = csc[i] * Hc[i] + snc[i] * Hc[i + 1];
-    Hc[i + 1] = -snc[i] * Hc[i] + csc[i] * Hc[i + 1];
+    const double nxt = hcol[i + 1];
+    const double t = csl[i] * cur + snl[i] * nxt;
+    const double u = -snl[i] * cur + csl[i] * nxt;
     Hc[i] = t;
+    cur = u;
   }
-  const double d = hypot(Hc[j], hnext);
+  const double d = hypot(cur, hnext);
   double cj = 1.0, sj = 0.0;
-  if (d > tiny) { cj = Hc[j] / d; sj = hnext / d; }
+  if (d > tiny) { cj = cur / d; sj = hnext / d; }
   csc[j] = cj;
   snc[j] = sj;
   Hc[j] = (d > tiny) ? d : 1.0;  // keep R non-singular for frozen columns
   Hc[j + 1] = 0.0;
   if (d > tiny) {
-    gc[j + 1] = -sj * gc[j];
-    gc[j] = cj * gc[j];
+    gc[j + 1] = -sj * gj;
+    gc[j] = cj * gj;
   } else {
     gc[j + 1] = 0.0;
     gc[j] = 0.0;
   }
   scale[c] = (hnext > tiny) ? 1.0 / hnext : 0.0;
-  resid[c] = fabs(gc[j + 1]);
+  resid[c] = (d > tiny) ? fabs(sj * gj) : 0.0;
 }
 void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
                        const double* h2, double* H, double* cs, double* sn, double* g,
                        double* scale, double* resid, const double* bnorm, double tol) {
-  hipLaunchKernelGGL(gmres_hess_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, j, restart, h1,
-                     h2, H, cs, sn, g, scale, resid, bnorm, tol);
+  hipLaunchKernelGGL(gmres_hess_kernel, dim3(m), dim3(64), (3 * restart + 4) * sizeof(double), st,
+                     m, j, restart, h1, h2, H, cs, sn, g, scale, resid, bnorm, tol);
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
@@ -897,10 +916,11 @@ __global__ __launch_bounds__(512) void dense_apply_kernel(int k, int m,
   const int ch0 = w * per, ch1 = min(nchunk, ch0 + per);
   const int row = i0 + r;
   const int col = c0 + r;           // B / D column owned by this lane
-  d4v acc = {0.0, 0.0, 0.0, 0.0};
-  for (int ch = ch0; ch < ch1; ++ch) {
+  d4v acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  // fetch of one 16-column chunk: 4 values of Einv (one 32-B read when aligned)
+  // and the 4 matching rows of rc
+  auto fetch = [&](int ch, double (&a)[4], double (&bb)[4]) {
     const int j = ch * 16 + 4 * q;
-    double a[4];
     if (row < k && j + 3 < k && ((size_t)row * k + j) % 2 == 0) {
       const double2* p = reinterpret_cast<const double2*>(Einv + (size_t)row * k + j);
       const double2 u = p[0], v = p[1];
@@ -912,10 +932,30 @@ __global__ __launch_bounds__(512) void dense_apply_kernel(int k, int m,
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int jj = j + t;
-      const double b = (jj < k && col < m) ? rc[(size_t)jj * m + col] : 0.0;
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b, acc, 0, 0, 0);
+      bb[t] = (jj < k && col < m) ? rc[(size_t)jj * m + col] : 0.0;
+    }
+  };
+  // four chunks are requested before the first MFMA consumes any of them, so the
+  // wave keeps ~20 loads in flight instead of waiting per chunk
+  for (int ch = ch0; ch < ch1; ch += 4) {
+    double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    fetch(ch, a0, b0);
+    fetch(ch + 1 < ch1 ? ch + 1 : nchunk, a1, b1);
+    fetch(ch + 2 < ch1 ? ch + 2 : nchunk, a2, b2);
+    fetch(ch + 3 < ch1 ? ch + 3 : nchunk, a3, b3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[t], b2[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3[t], b3[t], acc2, 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
   // D[row = q + 4*e][col = r]
 #pragma unroll
   for (int e = 0; e < 4; ++e) red[w][q + 4 * e][r] = acc[e];

@@ -1,6 +1,6 @@
 """Developer bring-up: exercise every layer of the HIP path against the oracle.
 
-Run on a GPU box:  python tools/bringup.py [N] [nu]
+Run on a GPU box:  python tests/dev_bringup.py [N] [nu]   (developer script, not collected by pytest)
 """
 import sys
 import time
