@@ -1057,9 +1057,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc) {
   if (n <= 0 || p <= 0 || q <= 0) return;
-  // enough row slices to fill the chip, at least 64 rows each
+  // enough row slices to fill the chip; thin products (one or two output tiles,
+  // e.g. the low-rank term V^T x) take long slices so that few partial tiles
+  // contend on the same atomics
   const int tiles = ((p + 31) / 32) * ((q + 31) / 32);
-  int slices = std::max(1, std::min((n + 63) / 64, std::max(1, 4096 / std::max(1, tiles))));
+  const int min_rows = tiles <= 2 ? 256 : 64;
+  int slices = std::max(1, std::min((n + min_rows - 1) / min_rows,
+                                    std::max(1, 4096 / std::max(1, tiles))));
   int rows_per_wave = (n + slices - 1) / slices;
   rows_per_wave = (rows_per_wave + 3) & ~3;
   slices = (n + rows_per_wave - 1) / rows_per_wave;
