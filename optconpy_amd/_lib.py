@@ -13,7 +13,7 @@ import numpy as np
 import scipy.sparse as sps
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libricadi_hip.so")
+LIB_PATH = os.environ.get("RICADI_LIB", os.path.join(_HERE, "libricadi_hip.so"))
 
 RICADI_OK = 0
 RICADI_ENOCONV = -3

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
       const int k = ka[rr] + ch * 16 + g;
       const bool ok = k < kb[rr];
       myv[rr][ch] = ok ? val[k] : 0.0;
-      myl[rr][ch] = ok ? (int)lidx[k] : 0;
+      myl[rr][ch] = ok ? (int)lidx[k] : 0;   // NOT touched before the barrier: see below
     }
   // phase 1: x tile.  Indices first, then ALL gathers of the thread, then the
   // LDS stores -- so that the loads are in flight together (a load followed by
@@ -282,6 +282,14 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     }
   }
   __syncthreads();
+  // Local index -> element offset of the tile row, once per entry.  Done here and
+  // not at load time: using a phase-0 value before the barrier makes the wave
+  // wait for those loads before it has issued the x-tile gathers (measured:
+  // 198 us instead of 168 us at n = 5e5).
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) myl[rr][ch] *= m;
   // phase 2: operands: matrix entries from registers (broadcast inside the
   // 16-lane row by DPP), x from the LDS tile.
 #pragma unroll
@@ -300,9 +308,9 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const int l0 = bc16i<T>(lcur);                                    \
     const double v0 = bc16d<T>(vcur);                                 \
     if ((T)&1)                                                        \
-      a1 = fma(v0, xs[l0 * m + ccs], a1);                             \
+      a1 = fma(v0, xs[l0 + ccs], a1);                                 \
     else                                                              \
-      a0 = fma(v0, xs[l0 * m + ccs], a0);                             \
+      a0 = fma(v0, xs[l0 + ccs], a0);                                 \
   }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
         int lcur = 0;
         double vcur = 0.0;
         if (k < kb[rr]) {
-          lcur = lidx[k];
+          lcur = (int)lidx[k] * m;
           vcur = val[k];
         }
         RICADI_FOR16(RICADI_TILE_STEP)
