@@ -282,16 +282,38 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     }
   }
   __syncthreads();
-  // Local index -> element offset of the tile row, once per entry.  Done here and
+  // Local index -> BYTE offset of the tile row, once per entry.  Done here and
   // not at load time: using a phase-0 value before the barrier makes the wave
   // wait for those loads before it has issued the x-tile gathers (measured:
   // 198 us instead of 168 us at n = 5e5).
+  const unsigned rowbytes = (unsigned)m * 8u;
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) myl[rr][ch] *= m;
-  // phase 2: operands: matrix entries from registers (broadcast inside the
-  // 16-lane row by DPP), x from the LDS tile.
+    for (int ch = 0; ch < NCH; ++ch) myl[rr][ch] *= (int)rowbytes;
+  // The DPP operands below are read by hand-written DPP instructions: keep the
+  // VALU writes above two wait states away from them (hipcc pads nothing for asm).
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 2");
+  __builtin_amdgcn_sched_barrier(0);
+  // phase 2.  Per (row, entry) step and wave: ONE v_add_u32_dpp (row_newbcast of
+  // the entry's tile-row offset + this lane's column address), ONE ds_read_b64
+  // and ONE v_fmac_f64_dpp (row_newbcast of the value fused into the FP64 FMA;
+  // gfx90a+ allows row_newbcast on 64-bit DPP ALU ops).  Compiler-generated
+  // code for the same step was 9 VALU instructions (profiles/r01_spmm_pmc.txt).
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double*)xs;
+#define RICADI_TILE_STEP(T)                                                                  \
+  {                                                                                          \
+    unsigned ad;                                                                             \
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf"            \
+        : "=v"(ad)                                                                           \
+        : "v"(lcur), "v"(lane_base));                                                        \
+    const double xv = *(lds_cdouble*)(size_t)ad;                                             \
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf"           \
+        : "+v"(acc[(T)&3])                                                                   \
+        : "v"(vcur), "v"(xv));                                                               \
+  }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
     const int q = gq + 16 * rr;
@@ -302,16 +324,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     nch = max(nch, __shfl_xor(nch, 32, 64));
     for (int cc = g; cc < m + (16 - (m & 15)) % 16; cc += 16) {
       const int ccs = cc < m ? cc : 0;         // lanes beyond m stay in the broadcasts
-      double a0 = 0.0, a1 = 0.0;
-#define RICADI_TILE_STEP(T)                                           \
-  {                                                                   \
-    const int l0 = bc16i<T>(lcur);                                    \
-    const double v0 = bc16d<T>(vcur);                                 \
-    if ((T)&1)                                                        \
-      a1 = fma(v0, xs[l0 + ccs], a1);                                 \
-    else                                                              \
-      a0 = fma(v0, xs[l0 + ccs], a0);                                 \
-  }
+      const unsigned lane_base = xs_lds + (unsigned)ccs * 8u;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         if (ch < nch) {
@@ -326,20 +340,23 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
         int lcur = 0;
         double vcur = 0.0;
         if (k < kb[rr]) {
-          lcur = (int)lidx[k] * m;
+          lcur = (int)lidx[k] * (int)rowbytes;
           vcur = val[k];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 2");
+        __builtin_amdgcn_sched_barrier(0);
         RICADI_FOR16(RICADI_TILE_STEP)
       }
-#undef RICADI_TILE_STEP
       if (live && cc < m) {
         const int row = rows[q0 + q];
-        double out = alpha * (a0 + a1);
+        double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (r) out += beta_r * r[(size_t)row * ldr + cc];
         y[(size_t)row * ldy + cc] = out;
       }
     }
   }
+#undef RICADI_TILE_STEP
 }
 size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz) {
   (void)max_nnz;
