@@ -8,6 +8,7 @@
 // Nothing here follows reference code: the reference solves these systems with
 // SuperLU.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -211,7 +212,9 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   // greedily into blocks of <= 32 rows whose set of distinct columns stays
   // within kSbMaxCols, so that the x tile of a block fits the LDS budget.
   {
-    const int kSbMaxRows = 32, kSbMaxCols = 160;
+    int kSbMaxRows = 32, kSbMaxCols = 160;
+    if (const char* e = getenv("RICADI_SB_MAXCOLS")) kSbMaxCols = std::max(48, atoi(e));
+    if (const char* e = getenv("RICADI_SB_MAXROWS")) kSbMaxRows = std::max(1, std::min(32, atoi(e)));
     std::vector<int> order;
     order.reserve(n);
     for (int q = 0; q < nv; ++q) order.push_back(hs.bv_rows[q]);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   // phase 0: the (value, local index) pairs of this group's two rows (blocks
   // hold <= 32 rows) are requested FIRST, 16 per lane-row and chunk, so that
   // they are in flight together with the x-tile gathers of phase 1.
-  constexpr int NR = 2, NCH = 4;               // rows per group, 16-entry chunks held in registers
+  constexpr int NR = 2, NCH = 3;               // rows per group, 16-entry chunks held in registers
   int ka[NR], kb[NR];
   double myv[NR][NCH];
   int myl[NR][NCH];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   // phase 1: x tile.  Indices first, then ALL gathers of the thread, then the
   // LDS stores -- so that the loads are in flight together (a load followed by
   // its own ds_write makes hipcc wait vmcnt(0) per row).
-  constexpr int XJ = 10;                       // 16 groups x 10 = 160 tile rows per pass
+  constexpr int XJ = 5;                        // 16 groups x 5 = 80 tile rows per pass
   for (int cc = g; cc < m; cc += 16) {
     for (int jb = 0; jb < nc; jb += 16 * XJ) {
       int cidx[XJ];
