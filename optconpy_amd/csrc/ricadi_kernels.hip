@@ -25,13 +25,13 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ~72 % of the kernel, profiles/r01_spmm_pmc.txt).
 template <int T>
 __device__ __forceinline__ int bc16i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + T, 0xF, 0xF, false);
+  // mov_dpp: "old" operand undefined + bound_ctrl, so no zero-initialising v_mov
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + T, 0xF, 0xF, true);
 }
 template <int T>
 __device__ __forceinline__ double bc16d(double v) {
-  const int lo = bc16i<T>(__double2loint(v));
-  const int hi = bc16i<T>(__double2hiint(v));
-  return __hiloint2double(hi, lo);
+  // one v_mov_b64_dpp (row_newbcast is the one DPP control 64-bit moves accept)
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + T, 0xF, 0xF, true);
 }
 #define RICADI_FOR16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
@@ -119,8 +119,12 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
   const int row = blk * 16 + (threadIdx.x >> 4);
   const bool live = row < nrows;
   double acc[CPL];
+  int colx[CPL];      // lanes beyond m read column 0 (branch-free loop); their result is dropped
 #pragma unroll
-  for (int c = 0; c < CPL; ++c) acc[c] = 0.0;
+  for (int c = 0; c < CPL; ++c) {
+    acc[c] = 0.0;
+    colx[c] = (g + 16 * c < m) ? g + 16 * c : 0;
+  }
   const int k0 = live ? rp[row] : 0, k1 = live ? rp[row + 1] : 0;
   // all 4 groups of the wave iterate the same number of chunks (shuffles need
   // every lane): take the wave-wide maximum
@@ -141,10 +145,8 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
     const int c0 = bc16i<T>(myc);                                     \
     const double v0 = bc16d<T>(myv);                                  \
     const double* x0 = x + (size_t)c0 * ldx;                          \
-    _Pragma("unroll") for (int c = 0; c < CPL; ++c) {                 \
-      const int col = g + 16 * c;                                     \
-      if (col < m) acc[c] = fma(v0, x0[col], acc[c]);                 \
-    }                                                                 \
+    _Pragma("unroll") for (int c = 0; c < CPL; ++c)                   \
+        acc[c] = fma(v0, x0[colx[c]], acc[c]);                        \
   }
     RICADI_FOR16(RICADI_V2_STEP)
 #undef RICADI_V2_STEP
