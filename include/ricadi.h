@@ -49,7 +49,7 @@ typedef struct ricadi_ctx ricadi_ctx;
  * GMRES).  Zero-initialise and call ricadi_default_opts() first.            */
 typedef struct ricadi_opts {
   double gmres_tol;      /* relative residual per column (default 1e-11)    */
-  int gmres_restart;     /* Krylov vectors per cycle (default 60)           */
+  int gmres_restart;     /* Krylov vectors per cycle (default 20)           */
   int gmres_maxit;       /* max iterations per solve (default 3000)         */
   int bj_block;          /* block-Jacobi block size, <= 64 (default 32)     */
   int agg_v;             /* velocity aggregate size of the coarse level     */
