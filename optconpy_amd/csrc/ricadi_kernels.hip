@@ -1042,8 +1042,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
   const int i0 = blockIdx.y * 16 * TI;
   const int j0 = blockIdx.z * 16 * TJ;
   const int rbeg = (blockIdx.x * 4 + wave_in_blk) * rows_per_wave;
-  const int rend = min(n, rbeg + rows_per_wave);
-  if (rbeg >= n) return;
+  const int rend = min(n, rbeg + rows_per_wave);   // empty range for surplus waves (they still join the barrier)
   const int lc = lane & 15, lk = lane >> 4;
   d4 acc[TI][TJ];
 #pragma unroll
@@ -1070,25 +1069,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
       for (int b = 0; b < TJ; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
+  // combine the block's four partial tile sets in LDS, then one atomic per
+  // output element and block (4x fewer contended atomics than one set per wave)
+  __shared__ double red[4][TI * TJ * 4][64];
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TJ; ++b)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int row = i0 + 16 * a + lk + 4 * e;
-        const int col = j0 + 16 * b + lc;
-        if (row < p && col < q) atomicAdd(&C[(size_t)row * ldc + col], acc[a][b][e]);
-      }
+      for (int e = 0; e < 4; ++e) red[wave_in_blk][(a * TJ + b) * 4 + e][lane] = acc[a][b][e];
+  __syncthreads();
+  if (wave_in_blk == 0) {
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = (a * TJ + b) * 4 + e;
+          const double v = (red[0][idx][lane] + red[1][idx][lane]) + (red[2][idx][lane] + red[3][idx][lane]);
+          const int row = i0 + 16 * a + lk + 4 * e;
+          const int col = j0 + 16 * b + lc;
+          if (row < p && col < q) atomicAdd(&C[(size_t)row * ldc + col], v);
+        }
+  }
 }
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc) {
   if (n <= 0 || p <= 0 || q <= 0) return;
-  // enough row slices to fill the chip; thin products (one or two output tiles,
-  // e.g. the low-rank term V^T x) take long slices so that few partial tiles
-  // contend on the same atomics
+  // enough row slices to fill the chip, at least 64 rows per wave
   const int tiles = ((p + 31) / 32) * ((q + 31) / 32);
-  const int min_rows = tiles <= 2 ? 256 : 64;
+  const int min_rows = 64;
   int slices = std::max(1, std::min((n + min_rows - 1) / min_rows,
                                     std::max(1, 4096 / std::max(1, tiles))));
   int rows_per_wave = (n + slices - 1) / slices;

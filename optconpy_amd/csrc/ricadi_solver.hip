@@ -103,7 +103,7 @@ struct ricadi_ctx {
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows;
   DArr<double> bvA, bvE;
   DArr<int> agg_ptr, agg_rows, aggof;
-  DArr<double> E0, EM, EJ;
+  DArr<double> E0, EM, EJ, ones;
   // LDS-tiled SpMM structure
   int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
   bool sb_ok = false;
@@ -257,7 +257,9 @@ static void precond_apply(ricadi_ctx* c, const ShiftData* sd, const double* r, d
   const int nv = c->nv, np = c->np;
   const double* rr = r;
   if (c->kc > 0) {
-    launch_restrict(st, c->kc, c->agg_ptr.p, c->agg_rows.p, r, m, c->rc.p, m);
+    // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
+    launch_spmm(st, c->kc, c->agg_ptr.p, c->agg_rows.p, c->ones.p, r, m, nullptr, c->rc.p, m, nullptr,
+                0, 1.0, 0.0, nullptr, m);
     launch_dense_apply(st, c->kc, m, sd->einv.p, c->rc.p, c->ec.p);
     // r2 = r - S * (Y ec), prolongation folded into the gather
     saddle_spmm(c, sd, c->ec.p, c->aggof.p, c->r2.p, r, -1.0, 1.0, m);
@@ -771,6 +773,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->E0.upload(hs.E0, st);
   c->EM.upload(hs.EM, st);
   c->EJ.upload(hs.EJ, st);
+  c->ones.upload(std::vector<double>((size_t)c->n, 1.0), st);
   c->sb_nblk = hs.sb_nblk;
   c->sb_max_cols = hs.sb_max_cols;
   c->sb_max_nnz = hs.sb_max_nnz;
