@@ -135,7 +135,12 @@ def main():
     backend.reset()
     calA = (-pr.A - pr.Nc).T.tocsr()
     calE = pr.M.T.tocsr()
-    ctx = _lib.Context(local)
+    # developer hook for option sweeps: RICADI_OPTS="agg_v=24,agg_p=36,gmres_restart=20"
+    xopts = {}
+    for kv in filter(None, os.environ.get("RICADI_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        xopts[k] = float(v) if "tol" in k else int(v)
+    ctx = _lib.Context(local, **xopts)
     ctx.set_operator(calA, calE, pr.J)
     d = dict(pb.default_nwtn_adi_dict(), ms=ms)
     prm_full = _lib.adi_params(d)

@@ -102,6 +102,20 @@ def test_shift_solve_edge_panels(ctx1, cfg1):
     assert rel(X, lu.solve(Rv, Rp)) < 1e-8
 
 
+def test_shift_solve_wide_panel(ctx1, cfg1):
+    """w_mat of the DRE sweep is up to comprz_maxc + NY' ~ 70 columns wide
+    (solve_dae_ric.py:149); panels beyond 128 columns are split by the host layer."""
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(8)
+    lu = olau.SaddleLU(calA - 30.0 * pr.M, pr.J)
+    for m in (70, 130):
+        R = rng.standard_normal((pr.NV, m))
+        X, its, rr = ctx1.shift_solve(-30.0, 1.0, R)
+        assert rr.max() < 1e-10
+        assert rel(X[:pr.NV], lu.solve(R)[:pr.NV]) < 1e-8
+
+
 def test_argument_errors(ctx1, cfg1):
     pr = cfg1[0]
     with pytest.raises(ValueError):
