@@ -86,6 +86,9 @@ int dots_num_blocks(int nrows);
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
                       double* out);
+void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                             size_t vstride, const double* h, double* w, double* partial,
+                             double* out);
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
                         const double* scale, double* out);

@@ -544,6 +544,64 @@ void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* 
                      partial, out, 0);
 }
 
+// Fused CGS2 middle step: for a chunk of DOT_ROWS rows
+//   w'[r,c] = w[r,c] - sum_i h[i,c] V_i[r,c]          (first Gram-Schmidt update, written back)
+//   partial[blk][i,c] = sum_r V_i[r,c] w'[r,c],  i <= nvec  (row nvec = ||w'||^2)
+// The dot products of the second pass are row-local, so the block computes them
+// right after its slice of w' -- the basis slice it has just read is still in
+// L1/L2 -- which saves one launch and one pass over the Krylov basis per
+// iteration compared with separate update and dots kernels.
+__global__ __launch_bounds__(256) void cols_update_dots_kernel(
+    int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    const double* __restrict__ h, double* __restrict__ w, double* __restrict__ partial) {
+  extern __shared__ double wl[];  // DOT_ROWS x m
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  const size_t base = (size_t)r0 * m;
+  for (int e = threadIdx.x; e < nr * m; e += blockDim.x) {
+    const int c = e % m;
+    double s0 = 0.0, s1 = 0.0;
+    int i = 0;
+    for (; i + 1 < nvec; i += 2) {
+      s0 = fma(h[i * m + c], basis[(size_t)i * vstride + base + e], s0);
+      s1 = fma(h[(i + 1) * m + c], basis[(size_t)(i + 1) * vstride + base + e], s1);
+    }
+    if (i < nvec) s0 = fma(h[i * m + c], basis[(size_t)i * vstride + base + e], s0);
+    const double v = w[base + e] - (s0 + s1);
+    wl[e] = v;
+    w[base + e] = v;
+  }
+  __syncthreads();
+  const int nout = (nvec + 1) * m;
+  for (int o = threadIdx.x; o < nout; o += blockDim.x) {
+    const int i = o / m, c = o - i * m;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < nvec) {
+      const double* v = basis + (size_t)i * vstride + base + c;
+      int r = 0;
+      for (; r + 1 < nr; r += 2) {
+        s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
+        s1 = fma(v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+      }
+      if (r < nr) s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
+    } else {
+      for (int r = 0; r < nr; ++r) s0 = fma(wl[r * m + c], wl[r * m + c], s0);
+    }
+    partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
+  }
+}
+void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
+                             size_t vstride, const double* h, double* w, double* partial,
+                             double* out) {
+  const int nblk = dots_num_blocks(nrows);
+  const int nout = (nvec + 1) * m;
+  hipLaunchKernelGGL(cols_update_dots_kernel, dim3(nblk), dim3(256),
+                     DOT_ROWS * m * sizeof(double), st, nrows, m, nvec, basis, vstride, h, w,
+                     partial);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16), dim3(256), 0, st, nblk, nout,
+                     partial, out, 0);
+}
+
 // out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
 // (scale may be NULL = 1; w may be NULL = 0).  Streams nvec panels once.
 __global__ __launch_bounds__(256) void cols_update_kernel(

@@ -348,8 +348,8 @@ static GmresResult gmres_solve(ricadi_ctx* c, const ShiftData* sd, const double*
       precond_apply(c, sd, vj, c->zv.p, m);
       op_apply(c, sd, c->zv.p, c->wv.p, m, lowrank);
       launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 0, c->partial.p, c->h1.p);
-      launch_cols_update(st, n, m, j + 1, V, nm, c->h1.p, -1.0, c->wv.p, nullptr, c->wv.p);
-      launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 1, c->partial.p, c->h2.p);
+      // first update fused with the dot products of the second pass
+      launch_cols_update_dots(st, n, m, j + 1, V, nm, c->h1.p, c->wv.p, c->partial.p, c->h2.p);
       launch_gmres_hess(st, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p, c->g.p,
                         c->scale.p, c->resid.p, c->bnorm2.p, tol);
       launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
