@@ -119,7 +119,8 @@ struct ricadi_ctx {
   DArr<double> basis, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
-  double* h_resid = nullptr;  // pinned
+  double* h_resid = nullptr;  // pinned: [0,M) bnorm scratch, then two residual slots
+  hipEvent_t ev_res[2] = {nullptr, nullptr};
   // factor
   DArr<double> Z;
   int zc = 0, zld = 0;
@@ -128,6 +129,8 @@ struct ricadi_ctx {
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
+    for (int i = 0; i < 2; ++i)
+      if (ev_res[i]) (void)hipEventDestroy(ev_res[i]);
     if (rb) rocblas_destroy_handle(rb);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -164,7 +167,10 @@ static void ensure_work(ricadi_ctx* c, int m) {
   c->bnorm2.alloc(mm);
   c->nrm2.alloc(mm);
   c->lrc.alloc((size_t)64 * mm + 64);
-  if (!c->h_resid) HIPCHK(hipHostMalloc((void**)&c->h_resid, sizeof(double) * 2 * RICADI_MAX_M));
+  if (!c->h_resid) {
+    HIPCHK(hipHostMalloc((void**)&c->h_resid, sizeof(double) * 4 * RICADI_MAX_M));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_res[i], hipEventDisableTiming));
+  }
   c->wm = mm;
   c->wrestart = restart;
 }
@@ -354,11 +360,21 @@ static GmresResult gmres_solve(ricadi_ctx* c, const ShiftData* sd, const double*
                         c->scale.p, c->resid.p, c->bnorm2.p, tol);
       launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
                          V + (size_t)(j + 1) * nm);
-      HIPCHK(hipMemcpyAsync(hb, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
+      // Residual estimates travel to a pinned slot behind an event; the host
+      // looks at the PREVIOUS iteration's slot, so it never drains the stream
+      // (one iteration of lag: at most one surplus Arnoldi step per solve).
+      double* slot = hb + 2 * RICADI_MAX_M + (size_t)(j & 1) * RICADI_MAX_M;
+      HIPCHK(hipMemcpyAsync(slot, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipEventRecord(c->ev_res[j & 1], st));
       ++res.iters;
       k = j + 1;
-      if (all_converged(hb) || res.iters >= maxit) break;
+      bool stop = res.iters >= maxit;
+      if (j >= 1) {
+        HIPCHK(hipEventSynchronize(c->ev_res[(j - 1) & 1]));
+        const double* prev = hb + 2 * RICADI_MAX_M + (size_t)((j - 1) & 1) * RICADI_MAX_M;
+        if (all_converged(prev)) stop = true;
+      }
+      if (stop) break;
     }
     launch_gmres_backsolve(st, m, k, restart, c->H.p, c->g.p, c->yv.p);
     launch_cols_update(st, n, m, k, V, nm, c->yv.p, 1.0, nullptr, nullptr, c->wv.p);
