@@ -144,7 +144,8 @@ def main():
     ctx.set_operator(calA, calE, pr.J)
     d = dict(pb.default_nwtn_adi_dict(), ms=ms)
     prm_full = _lib.adi_params(d)
-    prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1))
+    prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1,
+                                   compress_cols=int(os.environ.get("RICADI_CC", "0"))))
     nb, mw = tb.shape[1], trct.shape[1]
     m = nb + mw
     n = pr.NV + pr.NP
