@@ -853,6 +853,7 @@ int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
 
 static int check_panel(ricadi_ctx* c, int m) {
   REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  (void)hipSetDevice(c->dev);   // host worker threads start on device 0
   REQUIRE(m >= 1 && m <= RICADI_MAX_M, RICADI_EINVAL, "panel width must be in [1, 128]");
   return RICADI_OK;
 }

@@ -32,13 +32,64 @@ from . import _lib
 
 
 class HipOps:
-    """Local panel operations on device tensors through the C-ABI."""
+    """Local panel operations on device tensors through the C-ABI.
 
-    def __init__(self, ctx):
+    ``extra_ctxs``: further contexts holding the SAME operator on the same GPU.
+    Each context owns a HIP stream; the shifts a rank has to solve in one sweep
+    are then solved concurrently, one host thread and one stream per shift
+    (``solve_many``).  At n ~ 3e4 a single shift-solve is a chain of short,
+    latency-bound kernels that leaves most of the chip idle, so concurrent
+    streams raise the throughput almost linearly for a few streams.
+    """
+
+    def __init__(self, ctx, extra_ctxs=()):
         self.ctx = ctx
+        self.ctxs = [ctx] + list(extra_ctxs)
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.gmres_iters = 0
         self.shift_solves = 0
+        self._pool = None
+
+    def set_lowrank(self, U=None, V=None):
+        for c in self.ctxs:
+            c.set_lowrank(U, V)
+
+    def clear_cache(self):
+        for c in self.ctxs:
+            c.clear_cache()
+
+    def _solve_on(self, ctx, p, W):
+        m = W.shape[1]
+        X = self.empty(ctx.n, m)
+        its, _ = ctx.shift_solve_dev(float(p), 1.0, W.data_ptr(), m, X.data_ptr(), strict=False)
+        ctx.synchronize()
+        return X[:ctx.nv].contiguous(), its
+
+    def solve_many(self, ps, W):
+        """Solve the same panel ``W`` against several shifts; concurrent when
+        more than one context is available.  Shift ``i`` of the list always goes
+        to context ``i % len(ctxs)`` so that per-shift data stay cached there.
+        (Splitting the panel's columns over streams as well was tried and is
+        slower on one GPU: every sub-panel repeats the per-shift setup and the
+        full launch sequence, and the host launch path is the limiter.)"""
+        nctx = len(self.ctxs)
+        if nctx == 1 or len(ps) <= 1:
+            return [self.solve(p, W) for p in ps]
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=nctx)
+        self._sync_in()
+
+        def lane(k):            # one host thread per context, its shifts in order
+            return [(i, self._solve_on(self.ctxs[k], ps[i], W)) for i in range(k, len(ps), nctx)]
+
+        out = [None] * len(ps)
+        for res in self._pool.map(lane, range(min(nctx, len(ps)))):
+            for i, (U, its) in res:
+                out[i] = U
+                self.gmres_iters += its
+                self.shift_solves += 1
+        return out
 
     def to_panel(self, W):
         return torch.as_tensor(np.ascontiguousarray(W), dtype=torch.float64).to(self.device)
@@ -47,20 +98,16 @@ class HipOps:
         return torch.empty(*shape, dtype=torch.float64, device=self.device)
 
     def _sync_in(self):
-        # torch's stream -> ricadi's stream hand-off (both orders are rare: once per sweep)
+        # torch's stream -> ricadi's stream hand-off (rare: a few times per sweep)
         torch.cuda.current_stream().synchronize()
 
     def solve(self, p, W):
         """First NV rows of ``S(p,1)^-1 [W; 0]`` as a new NV x m tensor."""
-        ctx = self.ctx
-        m = W.shape[1]
-        X = self.empty(ctx.n, m)
         self._sync_in()
-        its, _ = ctx.shift_solve_dev(float(p), 1.0, W.data_ptr(), m, X.data_ptr(), strict=False)
-        ctx.synchronize()
+        U, its = self._solve_on(self.ctx, p, W)
         self.gmres_iters += its
         self.shift_solves += 1
-        return X[:ctx.nv].contiguous()
+        return U
 
     def lincomb(self, coef, U_all):
         """``sum_i coef[i] * U_all[i]``; ``U_all`` is G x NV x m, contiguous."""
@@ -137,7 +184,10 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         if len(set(ps)) != G:
             raise ValueError("shifts within one sweep must be distinct: {0}".format(ps))
         mine = [g for g in range(G) if g % world == rank]
-        local = [ops.solve(ps[g], W) for g in mine]
+        if hasattr(ops, "solve_many"):
+            local = ops.solve_many([ps[g] for g in mine], W)
+        else:
+            local = [ops.solve(ps[g], W) for g in mine]
         while len(local) < per_rank:
             local.append(torch.zeros_like(W))
         U_loc = torch.stack(local, dim=0).contiguous()

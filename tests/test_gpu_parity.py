@@ -344,4 +344,14 @@ def test_shift_parallel_hipops_matches_sequential(cfg1, golden):
     K = -(pr.M.T @ (Z @ (Z.T @ tb.toarray())))
     assert rel(K, golden["K_lyap"]) < K_TOL
     assert info["width"] == 4 and ops.shift_solves == info["adi_steps"]
+    # the same sweeps with two contexts (two HIP streams, two host threads)
+    ctx2 = _lib.Context(0)
+    ctx2.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    ops2 = HipOps(ctx, [ctx2])
+    blocks2, info2 = lyap_adi_shift_parallel(ops2, ms, W, adi_max_steps=200,
+                                             adi_newZ_reltol=1e-8, width=4)
+    Z2 = torch.cat(blocks2, dim=1).cpu().numpy()
+    assert info2["adi_steps"] == info["adi_steps"] and ops2.shift_solves == info2["adi_steps"]
+    assert opru.comp_diff_zzt_fnorm(Z2, Z) <= 1e-9 * np.linalg.norm(Z.T @ Z)
+    ctx2.close()
     ctx.close()
