@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <tuple>
 
 #include "ricadi_internal.h"
 
@@ -67,7 +68,17 @@ struct DArr {
 
 struct ShiftData {
   double alpha = 0, beta = 0;
+  bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
   DArr<double> sval, svalb, dinv, bvinv, bpinv, einv;
+  // hipGraph of one GMRES iteration body, keyed by (panel width, Arnoldi step, low-rank width);
+  // valid for one workspace epoch of the owning context
+  long epoch = -1;
+  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+  void drop_graphs() {
+    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+    graphs.clear();
+  }
+  ~ShiftData() { drop_graphs(); }
 };
 
 struct DevCsr {
@@ -111,7 +122,7 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx;
   // low rank
   int q = 0;
-  DArr<double> U, V, lrc;
+  DArr<double> U, V, lrc, scratch;   // lrc is captured in the iteration graphs: never reallocate it elsewhere
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
@@ -126,6 +137,7 @@ struct ricadi_ctx {
   int zc = 0, zld = 0;
   // stats
   long total_iters = 0, total_solves = 0;
+  long work_epoch = 0;   // bumped whenever a buffer captured in the iteration graphs is reallocated
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
@@ -173,40 +185,47 @@ static void ensure_work(ricadi_ctx* c, int m) {
   }
   c->wm = mm;
   c->wrestart = restart;
+  ++c->work_epoch;
 }
 
 // ---- per-shift setup ---------------------------------------------------------
+template <class T>
+static void stable_alloc(DArr<T>& a, size_t n) {
+  if (a.n != n) a.alloc(n);   // same size: keep the pointer (it is baked into captured graphs)
+}
+
 static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
   auto key = std::make_pair(alpha, beta);
   auto it = c->cache.find(key);
-  if (it != c->cache.end()) return it->second.get();
-  std::unique_ptr<ShiftData> sd(new ShiftData);
+  if (it != c->cache.end() && it->second->valid) return it->second.get();
+  if (it == c->cache.end()) it = c->cache.emplace(key, std::unique_ptr<ShiftData>(new ShiftData)).first;
+  ShiftData* sd = it->second.get();
   sd->alpha = alpha;
   sd->beta = beta;
   hipStream_t st = c->st;
-  sd->sval.alloc(c->snnz);
+  stable_alloc(sd->sval, c->snnz);
   launch_assemble_shift(st, (int)c->snnz, c->srcA.p, c->srcE.p, c->srcJ.p, alpha, beta,
                         sd->sval.p);
   if (c->sb_ok) {
-    sd->svalb.alloc(c->snnz);
+    stable_alloc(sd->svalb, c->snnz);
     launch_gather_vals(st, (int)c->snnz, c->sb_perm.p, sd->sval.p, sd->svalb.p);
   }
-  sd->dinv.alloc(c->nv);
+  stable_alloc(sd->dinv, (size_t)c->nv);
   launch_diag_inv(st, c->nv, c->dA.p, c->dE.p, alpha, beta, sd->dinv.p);
   HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
   const size_t bsz = (size_t)c->bs * c->bs;
-  sd->bvinv.alloc((size_t)c->nbv * bsz);
+  stable_alloc(sd->bvinv, (size_t)c->nbv * bsz);
   launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
   launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
   if (c->nbp > 0) {
-    sd->bpinv.alloc((size_t)c->nbp * bsz);
+    stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
     launch_schur_blocks(st, c->nbp, c->bs, c->bp_ptr.p, c->bp_rows.p, c->J.rp.p, c->J.ci.p,
                         c->J.v.p, sd->dinv.p, sd->bpinv.p);
     launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
   }
   if (c->kc > 0) {
     const int k = c->kc;
-    sd->einv.alloc((size_t)k * k);
+    stable_alloc(sd->einv, (size_t)k * k);
     launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
     c->ipiv.ensure(k);
     // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
@@ -221,9 +240,8 @@ static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
   HIPCHK(hipMemcpyAsync(&flag, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (flag) throw HipError{"singular block-Jacobi block"};
-  ShiftData* out = sd.get();
-  c->cache[key] = std::move(sd);
-  return out;
+  sd->valid = true;
+  return sd;
 }
 
 // ---- operator and preconditioner on device panels ---------------------------------
@@ -299,7 +317,7 @@ struct GmresResult {
   double max_relres = 0.0;
 };
 
-static GmresResult gmres_solve(ricadi_ctx* c, const ShiftData* sd, const double* b, double* x,
+static GmresResult gmres_solve(ricadi_ctx* c, ShiftData* sd, const double* b, double* x,
                                int m, bool lowrank, double* relres_host) {
   ensure_work(c, m);
   hipStream_t st = c->st;
@@ -350,16 +368,46 @@ static GmresResult gmres_solve(ricadi_ctx* c, const ShiftData* sd, const double*
     launch_colscale(st, n, m, c->scale.p, c->wv.p, 0.0, V);
     int k = 0;
     for (int j = 0; j < restart; ++j) {
-      const double* vj = V + (size_t)j * nm;
-      precond_apply(c, sd, vj, c->zv.p, m);
-      op_apply(c, sd, c->zv.p, c->wv.p, m, lowrank);
-      launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 0, c->partial.p, c->h1.p);
-      // first update fused with the dot products of the second pass
-      launch_cols_update_dots(st, n, m, j + 1, V, nm, c->h1.p, c->wv.p, c->partial.p, c->h2.p);
-      launch_gmres_hess(st, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p, c->g.p,
-                        c->scale.p, c->resid.p, c->bnorm2.p, tol);
-      launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
-                         V + (size_t)(j + 1) * nm);
+      // One iteration body = ~15 dependent launches.  With RICADI_GRAPH=1 it is
+      // captured once per (shift, panel width, step j, low-rank width) into a
+      // hipGraph and replayed with a single call.  Measured (cfg2, 8 streams):
+      // 94.6 vs 97.2 shift-solves/s without -- no gain, the kernels themselves
+      // (each fills the chip with latency-bound waves) are the limit, not the host
+      // launch path -- so direct launches stay the default.
+      auto body = [&]() {
+        const double* vj = V + (size_t)j * nm;
+        precond_apply(c, sd, vj, c->zv.p, m);
+        op_apply(c, sd, c->zv.p, c->wv.p, m, lowrank);
+        launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 0, c->partial.p, c->h1.p);
+        // first update fused with the dot products of the second pass
+        launch_cols_update_dots(st, n, m, j + 1, V, nm, c->h1.p, c->wv.p, c->partial.p, c->h2.p);
+        launch_gmres_hess(st, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p, c->g.p,
+                          c->scale.p, c->resid.p, c->bnorm2.p, tol);
+        launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
+                           V + (size_t)(j + 1) * nm);
+      };
+      static const bool use_graph = getenv("RICADI_GRAPH") != nullptr;
+      if (use_graph) {
+        if (sd->epoch != c->work_epoch) {
+          sd->drop_graphs();
+          sd->epoch = c->work_epoch;
+        }
+        const auto gkey = std::make_tuple(m, j, (lowrank && c->q > 0) ? c->q : 0);
+        auto git = sd->graphs.find(gkey);
+        if (git == sd->graphs.end()) {
+          hipGraph_t gr = nullptr;
+          hipGraphExec_t ex = nullptr;
+          HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+          body();
+          HIPCHK(hipStreamEndCapture(st, &gr));
+          HIPCHK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
+          (void)hipGraphDestroy(gr);
+          git = sd->graphs.emplace(gkey, ex).first;
+        }
+        HIPCHK(hipGraphLaunch(git->second, st));
+      } else {
+        body();
+      }
       // Residual estimates travel to a pinned slot behind an event; the host
       // looks at the PREVIOUS iteration's slot, so it never drains the stream
       // (one iteration of lag: at most one surplus Arnoldi step per solve).
@@ -419,7 +467,7 @@ struct DScalar {
   // tiny helper: Frobenius norm of W^T W and ||W||_F^2 of a device panel
   static void gram_norms(ricadi_ctx* c, const double* dW, int nrows, int m, double* gram_fro,
                          double* nrm2) {
-    DArr<double>& G = c->lrc;
+    DArr<double>& G = c->scratch;
     G.ensure((size_t)m * m + 64);
     HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * m * m, c->st));
     launch_gemm_tn(c->st, nrows, m, m, dW, m, dW, m, G.p, m);
@@ -817,7 +865,7 @@ int ricadi_clear_cache(ricadi_ctx* c) {
   REQUIRE(c, RICADI_EINVAL, "NULL ctx");
   API_BEGIN
   HIPCHK(hipStreamSynchronize(c->st));
-  c->cache.clear();
+  for (auto& kv : c->cache) kv.second->valid = false;   // buffers (and iteration graphs) stay
   API_END
 }
 
@@ -842,6 +890,7 @@ int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
   c->q = q;
   if (q > 0) {
     const size_t cnt = (size_t)c->nv * q;
+    if (cnt > c->U.n || cnt > c->V.n) ++c->work_epoch;
     c->U.ensure(cnt);
     c->V.ensure(cnt);
     HIPCHK(hipMemcpyAsync(c->U.p, U, cnt * sizeof(double), hipMemcpyHostToDevice, c->st));
@@ -967,10 +1016,10 @@ int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* 
   std::vector<double> h((size_t)nvec * m);
   for (int i = 0; i < nvec; ++i)
     for (int j = 0; j < m; ++j) h[(size_t)i * m + j] = coef[i];
-  c->lrc.ensure((size_t)nvec * m + 64);
-  HIPCHK(hipMemcpyAsync(c->lrc.p, h.data(), sizeof(double) * nvec * m, hipMemcpyHostToDevice, c->st));
+  c->scratch.ensure((size_t)nvec * m + 64);
+  HIPCHK(hipMemcpyAsync(c->scratch.p, h.data(), sizeof(double) * nvec * m, hipMemcpyHostToDevice, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
-  launch_cols_update(c->st, nrows, m, nvec, dBasis, (size_t)stride, c->lrc.p, 1.0, nullptr, nullptr,
+  launch_cols_update(c->st, nrows, m, nvec, dBasis, (size_t)stride, c->scratch.p, 1.0, nullptr, nullptr,
                      dOut);
   API_END
 }
@@ -1101,6 +1150,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     const bool lr = (kk > 0) || oldB;
     c->q = lr ? nb : 0;
     if (lr) {
+      if ((size_t)nv * nb > c->U.n || (size_t)nv * nb > c->V.n) ++c->work_epoch;
       c->U.ensure((size_t)nv * nb);
       c->V.ensure((size_t)nv * nb);
       HIPCHK(hipMemcpyAsync(c->U.p, dKall.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
@@ -1246,10 +1296,10 @@ int ricadi_lyap_res_norm(ricadi_ctx* c, const double* Z, int cz, const double* W
     launch_copy_cols(st, nv, w, dZ.p, cz, c0, in, w, 0, 1.0);
     launch_spmm(st, nv, c->A.rp.p, c->A.ci.p, c->A.v.p, in, w, nullptr, out, w, nullptr, 0, 1.0, 0.0, nullptr, w);
     if (c->q > 0) {
-      c->lrc.ensure((size_t)c->q * w + 64);
-      HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * c->q * w, st));
-      launch_gemm_tn(st, nv, c->q, w, c->V.p, c->q, in, w, c->lrc.p, w);
-      launch_gemm_nn(st, nv, c->q, w, c->U.p, c->q, c->lrc.p, w, out, w, -1.0, 1.0);
+      c->scratch.ensure((size_t)c->q * w + 64);
+      HIPCHK(hipMemsetAsync(c->scratch.p, 0, sizeof(double) * c->q * w, st));
+      launch_gemm_tn(st, nv, c->q, w, c->V.p, c->q, in, w, c->scratch.p, w);
+      launch_gemm_nn(st, nv, c->q, w, c->U.p, c->q, c->scratch.p, w, out, w, -1.0, 1.0);
     }
     launch_copy_cols(st, nv, w, out, w, 0, S.p, wtot, c0, 1.0);
     launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, in, w, nullptr, out, w, nullptr, 0, 1.0, 0.0, nullptr, w);
