@@ -207,6 +207,36 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   hs.nbp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), bs, pblk.data()) : 0;
   lists_from_blocks(np, pblk.data(), hs.nbp, hs.bp_ptr, hs.bp_rows);
 
+  // ---- dense J sub-blocks for the consistent SIMPLE Schur complement ---------
+  // S_bb = sum_beta J_{b,beta} Ahat_beta^-1 J_{b,beta}^T needs, per pressure block b,
+  // the bs x bs slices of J against every velocity block beta it touches.  J does
+  // not depend on the shift, so the slices are extracted once.
+  {
+    hs.jd_ptr.assign(1, 0);
+    hs.jd_vblk.clear();
+    hs.jd_val.clear();
+    std::vector<int> slot(std::max(hs.nbv, 1), -1), touched;
+    for (int b = 0; b < hs.nbp; ++b) {
+      touched.clear();
+      const size_t base = hs.jd_vblk.size();
+      for (int q = hs.bp_ptr[b]; q < hs.bp_ptr[b + 1]; ++q) {
+        const int k = hs.bp_rows[q], il = q - hs.bp_ptr[b];
+        for (int e = J.rp[k]; e < J.rp[k + 1]; ++e) {
+          const int j = J.ci[e], vb = blk[j];
+          if (slot[vb] < 0) {
+            slot[vb] = (int)touched.size();
+            touched.push_back(vb);
+            hs.jd_vblk.push_back(vb);
+            hs.jd_val.resize(hs.jd_val.size() + (size_t)bs * bs, 0.0);
+          }
+          hs.jd_val[(base + slot[vb]) * (size_t)bs * bs + (size_t)il * bs + local[j]] += J.v[e];
+        }
+      }
+      for (int vb : touched) slot[vb] = -1;
+      hs.jd_ptr.push_back((int)hs.jd_vblk.size());
+    }
+  }
+
   // ---- row blocks of the LDS-tiled SpMM ------------------------------------
   // Rows are visited aggregate by aggregate (compact mesh patches) and packed
   // greedily into blocks of <= 32 rows whose set of distinct columns stays

@@ -46,6 +46,10 @@ struct HostSetup {
   // block-Jacobi, Schur complement
   int nbp = 0;
   std::vector<int> bp_ptr, bp_rows;  // rows are pressure-local (0..np)
+  // dense bs x bs blocks of J for every (pressure block, coupled velocity block) pair:
+  // row = pressure dof local to its block, column = velocity dof local to its block
+  std::vector<int> jd_ptr, jd_vblk;
+  std::vector<double> jd_val;
   // LDS-tiled SpMM: rows grouped in blocks of <= 64 (pairs of block-Jacobi
   // aggregates = compact mesh patches); per block the distinct columns and
   // 16-bit local column indices; arrays in block order
@@ -100,12 +104,16 @@ void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const dou
 void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
                         double* scale, double* resid);
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
-                        const double* inv, const double* in, int ldi, double* out, int ldo, int m);
+                        const double* inv, const double* in, int ldi, double* out, int ldo, int m,
+                        int subtract = 0);
 void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const double* Be,
                           double alpha, double beta, double* out);
 void launch_schur_blocks(hipStream_t st, int nblocks, int bs, const int* bptr, const int* rows,
                          const int* jrp, const int* jci, const double* jv, const double* dinv,
                          double* blocks);
+void launch_schur_blocks_bj(hipStream_t st, int nblocks, int bs, const int* bptr, const int* jd_ptr,
+                            const int* jd_vblk, const double* jd_val, const double* bvinv,
+                            double* blocks);
 void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
                          int* flag);
 void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows, const double* in,

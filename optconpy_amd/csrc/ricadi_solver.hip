@@ -111,8 +111,9 @@ struct ricadi_ctx {
   DArr<double> srcA, srcE, srcJ;
   DevCsr A, E, J, JT;
   DArr<double> dA, dE;
-  DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows;
-  DArr<double> bvA, bvE;
+  DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
+  DArr<double> bvA, bvE, jd_val;
+  bool simple_diag = false;   // RICADI_SIMPLE_DIAG=1: diagonal (classical) SIMPLE instead of the consistent one
   DArr<int> agg_ptr, agg_rows, aggof;
   DArr<double> E0, EM, EJ, ones;
   // LDS-tiled SpMM structure
@@ -219,8 +220,12 @@ static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
   launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
   if (c->nbp > 0) {
     stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
-    launch_schur_blocks(st, c->nbp, c->bs, c->bp_ptr.p, c->bp_rows.p, c->J.rp.p, c->J.ci.p,
-                        c->J.v.p, sd->dinv.p, sd->bpinv.p);
+    if (c->simple_diag)
+      launch_schur_blocks(st, c->nbp, c->bs, c->bp_ptr.p, c->bp_rows.p, c->J.rp.p, c->J.ci.p,
+                          c->J.v.p, sd->dinv.p, sd->bpinv.p);
+    else
+      launch_schur_blocks_bj(st, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p, c->jd_val.p,
+                             sd->bvinv.p, sd->bpinv.p);
     launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
   }
   if (c->kc > 0) {
@@ -297,9 +302,17 @@ static void precond_apply(ricadi_ctx* c, const ShiftData* sd, const double* r, d
     double* zp = z + (size_t)nv * m;
     launch_block_apply(st, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, sd->bpinv.p, c->tp.p, m, zp,
                        m, m);
-    // z_v -= Dinv * J^T z_p
-    launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, z, m, z, m, -1.0, 1.0,
-                sd->dinv.p, m);
+    if (c->simple_diag) {
+      // z_v -= Dinv * J^T z_p
+      launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, z, m, z, m, -1.0, 1.0,
+                  sd->dinv.p, m);
+    } else {
+      // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks
+      double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
+      launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, tmp, m, nullptr, 0, 1.0,
+                  0.0, nullptr, m);
+      launch_block_apply(st, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, sd->bvinv.p, tmp, m, z, m, m, 1);
+    }
   }
   if (c->kc > 0) launch_prolong_add(st, c->n, m, c->aggof.p, c->ec.p, z);
 }
@@ -831,6 +844,10 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->bp_rows.upload(hs.bp_rows, st);
   c->bvA.upload(hs.bv_A, st);
   c->bvE.upload(hs.bv_E, st);
+  c->jd_ptr.upload(hs.jd_ptr, st);
+  c->jd_vblk.upload(hs.jd_vblk, st);
+  c->jd_val.upload(hs.jd_val, st);
+  c->simple_diag = getenv("RICADI_SIMPLE_DIAG") != nullptr;
   c->agg_ptr.upload(hs.agg_ptr, st);
   c->agg_rows.upload(hs.agg_rows, st);
   c->aggof.upload(hs.aggof, st);
