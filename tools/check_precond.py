@@ -27,7 +27,6 @@ def mirror(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, coarse_max=4096, use
     Ap = (beta * calA + alpha * calE).tocsr()
     D = Ap.diagonal()
     S = sps.bmat([[Ap, J.T], [J, None]], format="csr")
-    Sh = (J @ sps.diags(1.0 / D) @ J.T).tocsr()
 
     def bj(Mat, blk, nb):
         order, ptr = lists(blk, nb)
@@ -42,9 +41,13 @@ def mirror(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, coarse_max=4096, use
             out = np.empty_like(z)
             out[order] = z
             return out
-        return app
-    Ainv = bj(Ap, blk, nb)
-    Sinv = bj(Sh, pblk, npb)
+        return app, order, invs
+    Ainv, aorder, ainvs = bj(Ap, blk, nb)
+    # consistent SIMPLE: Schur complement and velocity update with the block-Jacobi inverse
+    Pm = sps.csr_matrix((np.ones(nv), (np.arange(nv), aorder)), shape=(nv, nv))
+    AinvM = (Pm.T @ sps.block_diag(ainvs) @ Pm).tocsr()
+    Sh = (J @ AinvM @ J.T).tocsr()
+    Sinv, _, _ = bj(Sh, pblk, npb)
     Y = None
     if use_coarse:
         g = calE if calE.nnz > 2 * nv else pat
@@ -62,7 +65,7 @@ def mirror(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, coarse_max=4096, use
     def P1(r):
         zv = Ainv(r[:nv])
         zp = Sinv(J @ zv - r[nv:])
-        zv = zv - (J.T @ zp) / D[:, None]
+        zv = zv - Ainv(J.T @ zp)
         return np.vstack([zv, zp])
 
     def P(r):
