@@ -69,7 +69,7 @@ def eval_costfunc(V=None, W=None, cmat=None, ystar=None, tbmat=None, tmesh=None,
     (``optcont_main.py:213-264``), ``dy = y* - C v``, ``u = mtxtb^T v + B~^T w``."""
     def dywdy(t, Wt):
         dy = ystar(t) - cmat @ veldict[t]
-        return float(dy.T @ (Wt @ dy))
+        return float(np.asarray(dy.T @ (Wt @ dy)).ravel()[0])
 
     def uru(t):
         if not penau or fbftdict is None:
@@ -77,7 +77,7 @@ def eval_costfunc(V=None, W=None, cmat=None, ystar=None, tbmat=None, tmesh=None,
         key = None if static_feedback else t
         fb = store.load(fbftdict[key]["mtxtb"]).T @ veldict[t]
         ft = tbmat.T @ store.load(fbftdict[key]["w"])
-        return float((fb + ft).T @ (fb + ft))
+        return float(np.asarray((fb + ft).T @ (fb + ft)).ravel()[0])
 
     cfv = 0.0
     old = dywdy(tmesh[0], W) + uru(tmesh[0])
