@@ -73,6 +73,22 @@ def spmm_roofline(ctx, nnz_s, n, m, reps=200):
                 algorithmic_bytes=int(nbytes), n=int(n), m=int(m), nnz=int(nnz_s))
 
 
+def gram_mfma(ctx, nv, c, reps=20):
+    """K5: G = Z^T Z on v_mfma_f64_16x16x4_f64 -- the 2*NV*c^2 flops of the compression step
+     against the FP64 matrix peak (78.6 TFLOP/s)."""
+    import torch
+    z = torch.randn(nv, c, dtype=torch.float64, device="cuda")
+    g = torch.empty(c, c, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.time_gram_dev(z.data_ptr(), c, g.data_ptr(), 3)
+    ms = ctx.time_gram_dev(z.data_ptr(), c, g.data_ptr(), reps)
+    flops = 2.0 * nv * c * c
+    tf = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(tf, 2), peak=78.6, unit="TFLOP/s",
+                frac=round(tf / 78.6, 4), kernel="ricadi::gemm_tn_kernel<4,4> (symmetric)",
+                us_per_launch=round(ms * 1e3, 1), nv=int(nv), c=int(c))
+
+
 def cpu_baseline(pr, ms, m, adi_steps, nsample_shifts=3, solves_per_shift=4):
     """Oracle (scipy SuperLU, as the reference's technology) on a bounded sample:
     LU of `nsample_shifts` shifted saddle matrices + `solves_per_shift` panel solves
@@ -263,6 +279,7 @@ def main():
             },
         }
         out["roofline"] = spmm_roofline(ctx, nnz_s, n, m)
+        out["roofline_gram_mfma"] = gram_mfma(ctx, pr.NV, 512)
         if world == 1 and not args.no_large_roofline:
             # the HBM-resident instance (BASELINE cfg5 pattern, n ~ 5e5)
             try:

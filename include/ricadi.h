@@ -217,6 +217,12 @@ int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,
 int ricadi_time_spmm_dev(ricadi_ctx* ctx, double alpha, double beta, const double* dX,
                          int m, double* dY, int reps, double* ms_per_launch);
 
+/* Average duration (ms) of the FP64-MFMA Gram kernel G = Z^T Z (the 2*NV*c^2 flop
+ * part of ricadi_compress) for a device-resident NV x c factor, HIP events on the
+ * context stream.  dG must hold c*c doubles.                                   */
+int ricadi_time_gram_dev(ricadi_ctx* ctx, const double* dZ, int c, double* dG, int reps,
+                         double* ms_per_launch);
+
 /* ---- host-side logic exported for CPU tests ---------------------------- */
 /* Greedy BFS aggregation of the graph of a CSR pattern into blocks of at
  * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
     "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
                                        _dp]),
+    "ricadi_time_gram_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _dp]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
 }
@@ -436,6 +437,15 @@ class Context:
         _chk(self._lib.ricadi_time_spmm_dev(self._h, alpha, beta, x_ptr, m, y_ptr, reps,
                                             C.byref(ms)))
         return ms.value
+
+
+def _time_gram_dev(self, z_ptr, c, g_ptr, reps):
+    ms = C.c_double(0.0)
+    _chk(self._lib.ricadi_time_gram_dev(self._h, z_ptr, c, g_ptr, reps, C.byref(ms)))
+    return ms.value
+
+
+Context.time_gram_dev = _time_gram_dev
 
 
 def host_aggregate(pattern, bsize):

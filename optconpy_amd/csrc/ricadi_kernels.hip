@@ -1155,7 +1155,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
                                                       const double* __restrict__ A, int lda,
                                                       const double* __restrict__ B, int ldb,
                                                       double* __restrict__ C, int ldc,
-                                                      int rows_per_wave) {
+                                                      int rows_per_wave, int symmetric) {
+  // symmetric (A == B, Gram matrix): only tile blocks on / above the diagonal
+  // are computed, the strictly upper ones are mirrored when written
+  if (symmetric && blockIdx.z < blockIdx.y) return;
   const int lane = threadIdx.x & 63;
   const int wave_in_blk = threadIdx.x >> 6;
   const int i0 = blockIdx.y * 16 * TI;
@@ -1188,15 +1191,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
       for (int b = 0; b < TJ; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
-  // combine the block's four partial tile sets in LDS, then one atomic per
-  // output element and block (4x fewer contended atomics than one set per wave)
-  __shared__ double red[4][TI * TJ * 4][64];
+  if (TI * TJ > 4) {
+    // wide products: the atomics are spread over many outputs; every wave adds
+    // its own tiles (an LDS combine buffer would need 131 KB)
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+      for (int b = 0; b < TJ; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int row = i0 + 16 * a + lk + 4 * e;
+          const int col = j0 + 16 * b + lc;
+          if (rbeg < n && row < p && col < q) {
+            atomicAdd(&C[(size_t)row * ldc + col], acc[a][b][e]);
+            if (symmetric && blockIdx.z > blockIdx.y)
+              atomicAdd(&C[(size_t)col * ldc + row], acc[a][b][e]);
+          }
+        }
+    return;
+  }
+  // thin products: combine the block's four partial tile sets in LDS, then one
+  // atomic per output element and block (4x fewer contended atomics)
+  constexpr int NT = (TI * TJ > 4) ? 1 : TI * TJ * 4;
+  __shared__ double red[4][NT][64];
 #pragma unroll
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TJ; ++b)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[wave_in_blk][(a * TJ + b) * 4 + e][lane] = acc[a][b][e];
+      for (int e = 0; e < 4; ++e) red[wave_in_blk][((a * TJ + b) * 4 + e) % NT][lane] = acc[a][b][e];
   __syncthreads();
   if (wave_in_blk == 0) {
 #pragma unroll
@@ -1205,28 +1228,44 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
       for (int b = 0; b < TJ; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int idx = (a * TJ + b) * 4 + e;
+          const int idx = ((a * TJ + b) * 4 + e) % NT;
           const double v = (red[0][idx][lane] + red[1][idx][lane]) + (red[2][idx][lane] + red[3][idx][lane]);
           const int row = i0 + 16 * a + lk + 4 * e;
           const int col = j0 + 16 * b + lc;
-          if (row < p && col < q) atomicAdd(&C[(size_t)row * ldc + col], v);
+          if (row < p && col < q) {
+            atomicAdd(&C[(size_t)row * ldc + col], v);
+            if (symmetric && blockIdx.z > blockIdx.y) atomicAdd(&C[(size_t)col * ldc + row], v);
+          }
         }
   }
 }
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc) {
   if (n <= 0 || p <= 0 || q <= 0) return;
-  // enough row slices to fill the chip, at least 64 rows per wave
-  const int tiles = ((p + 31) / 32) * ((q + 31) / 32);
-  const int min_rows = 64;
+  const int symmetric = (A == B && lda == ldb && p == q) ? 1 : 0;
+  // wide products: 64 x 64 output per wave (16 MFMAs per 8 loaded operands);
+  // thin ones (low-rank term, gain): 32 x 32
+  const bool wide = p >= 128 && q >= 128;
+  const int tp = wide ? 64 : 32;
+  const int tp_ = (p + tp - 1) / tp, tq_ = (q + tp - 1) / tp;
+  const int tiles = symmetric ? tp_ * (tp_ + 1) / 2 : tp_ * tq_;
+  // Row slices: every slice adds its partial tiles with atomics, so wide products
+  // (many output elements) take few, long slices -- about 1.5 waves per SIMD in
+  // total -- while thin ones take many short slices to fill the chip.
+  const int min_rows = wide ? 256 : 64;
+  const int target_waves = wide ? 1536 : 8192;
   int slices = std::max(1, std::min((n + min_rows - 1) / min_rows,
-                                    std::max(1, 4096 / std::max(1, tiles))));
+                                    std::max(1, target_waves / std::max(1, tiles))));
   int rows_per_wave = (n + slices - 1) / slices;
   rows_per_wave = (rows_per_wave + 3) & ~3;
   slices = (n + rows_per_wave - 1) / rows_per_wave;
-  dim3 grid((slices + 3) / 4, (p + 31) / 32, (q + 31) / 32), block(256);
-  hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
-                     rows_per_wave);
+  dim3 grid((slices + 3) / 4, (p + tp - 1) / tp, (q + tp - 1) / tp), block(256);
+  if (wide)
+    hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
+                       rows_per_wave, symmetric);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
+                       rows_per_wave, symmetric);
 }
 
 // gemm_nn:  Y (n x q) = alpha * A (n x p) * C (p x q) + beta * Y.

@@ -1084,6 +1084,28 @@ int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double*
   API_END
 }
 
+int ricadi_time_gram_dev(ricadi_ctx* c, const double* dZ, int cz, double* dG, int reps,
+                         double* ms_per_launch) {
+  REQUIRE(c && c->nv > 0 && dZ && dG && cz > 0 && reps > 0 && ms_per_launch, RICADI_EINVAL,
+          "bad argument");
+  API_BEGIN
+  (void)hipSetDevice(c->dev);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipMemsetAsync(dG, 0, sizeof(double) * cz * cz, c->st));
+  HIPCHK(hipEventRecord(e0, c->st));
+  for (int i = 0; i < reps; ++i) launch_gemm_tn(c->st, c->nv, cz, cz, dZ, cz, dZ, cz, dG, cz);
+  HIPCHK(hipEventRecord(e1, c->st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  API_END
+}
+
 int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W, int m,
                     const ricadi_adi_params* prm, double* Z_out, int* c_out, double* stats_out) {
   if (int rc = check_panel(c, m)) return rc;
