@@ -212,7 +212,15 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         rel = float(np.sqrt(n2 / G / znorm2)) if znorm2 > 0 else 0.0
         if verbose and rank == 0:
             print("sweep {0:3d}: shifts {1} rel new Z {2:9.3e}".format(nsweeps, ps, rel))
-        if rel < adi_newZ_reltol:
+        stop = rel < adi_newZ_reltol
+        if world > 1:
+            # The norms above come from kernels with atomic accumulation: ranks may
+            # differ in the last bits and must not disagree on leaving the loop
+            # (the next all-gather would hang).  Rank 0 decides for everybody.
+            flag = W.new_tensor([1.0 if stop else 0.0])
+            dist.broadcast(flag, src=0, group=group)
+            stop = bool(flag.item() > 0.5)
+        if stop:
             break
     info = dict(adi_steps=steps, sweeps=nsweeps, width=G, adi_rel_newZ=rel,
                 res_fro=ops.gram_fro(W), resfac=W)
