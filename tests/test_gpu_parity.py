@@ -355,3 +355,21 @@ def test_shift_parallel_hipops_matches_sequential(cfg1, golden):
     assert opru.comp_diff_zzt_fnorm(Z2, Z) <= 1e-9 * np.linalg.norm(Z.T @ Z)
     ctx2.close()
     ctx.close()
+
+
+def test_two_ranks_on_one_gpu():
+    """The distributed shift-parallel path with device tensors: 2 processes on GPU 0
+    (gloo; NCCL refuses two ranks per device), 2 streams each, all-gather + collective
+    stop decision; both ranks must reproduce the golden gain."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rehearse_2ranks.py")],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    errs = [float(x) for x in re.findall(r"K rel diff vs golden ([0-9.e+-]+)", out.stdout)]
+    solves = [int(x) for x in re.findall(r"local solves (\d+)", out.stdout)]
+    assert len(errs) == 2 and max(errs) < K_TOL
+    assert len(solves) == 2 and solves[0] == solves[1] and solves[0] > 0
