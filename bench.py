@@ -67,8 +67,16 @@ def spmm_roofline(ctx, nnz_s, n, m, reps=200):
     ms = ctx.time_spmm_dev(-3.0, 1.0, x.data_ptr(), m, y.data_ptr(), reps)
     nbytes = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
     gbs = nbytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC passes of this kernel and shape
+    # (profiles/r01_spmm_traffic.json); None for shapes that were not profiled
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")) as f:
+            traffic = json.load(f).get("%dx%d" % (n, m), {}).get("hbm_bytes")
+    except (OSError, ValueError):
+        pass
     return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic,
                 kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(ms * 1e3, 2),
                 algorithmic_bytes=int(nbytes), n=int(n), m=int(m), nnz=int(nnz_s))
 
