@@ -139,8 +139,9 @@ int ricadi_shift_solve(ricadi_ctx* ctx, double alpha, double beta,
  * W is NV x m.  Z_out must hold NV x (adi_max_steps*m) doubles, row-major
  * with ld = *c_out on return (columns are packed).  Z_out may be NULL: the
  * factor then stays on the device (see ricadi_factor_*).
- * stats_out (may be NULL) receives [steps, rel_newZ, total_gmres_iters,
- * shift_solves, ||W_end^T W_end||_F].                                       */
+ * stats_out (may be NULL, else >= 8 doubles) receives [steps, rel_newZ,
+ * total_gmres_iters, shift_solves, ||W_end^T W_end||_F, shift-solves that
+ * missed the GMRES tolerance, their worst relative residual].               */
 int ricadi_lyap_adi(ricadi_ctx* ctx, const double* shifts, int nshifts,
                     const double* W, int m, const ricadi_adi_params* prm,
                     double* Z_out, int* c_out, double* stats_out);
@@ -150,8 +151,9 @@ int ricadi_lyap_adi(ricadi_ctx* ctx, const double* shifts, int nshifts,
  * /root/reference/solve_dae_ric.py:152-159).  B is NV x nb dense, W NV x mw,
  * Z0 NV x c0 (or NULL), oldB NV x nb (mtxoldb, or NULL).  Z_out capacity
  * NV x zcap doubles (zcap >= adi_max_steps*(mw+nb)); may be NULL.
- * stats_out: [newton_steps, last_upd_abs, last_upd_rel, total_adi_steps,
- * total_gmres_iters, shift_solves].                                         */
+ * stats_out (>= 8 doubles): [newton_steps, last_upd_abs, last_upd_rel,
+ * total_adi_steps, total_gmres_iters, shift_solves, shift-solves that missed
+ * the GMRES tolerance, their worst relative residual].                       */
 int ricadi_ric_newtonadi(ricadi_ctx* ctx, const double* shifts, int nshifts,
                          const double* B, int nb, const double* W, int mw,
                          const double* Z0, int c0, const double* oldB,

@@ -156,6 +156,17 @@ def as_csr(a):
             np.ascontiguousarray(m.data, dtype=np.float64), m.shape)
 
 
+def _warn_nonconverged(info):
+    """Non-convergence of an inner solve is not an error at the C-ABI (the outer
+    loops go on, like the reference's when it hits *_max_steps) -- but say so."""
+    if info.get("gmres_nonconverged", 0):
+        import warnings
+        warnings.warn("ricadi: {0} of {1} shift-solves stopped at gmres_maxit above the tolerance "
+                      "(worst relative residual {2:.1e}); the low-rank factor may be inaccurate"
+                      .format(info["gmres_nonconverged"], info["shift_solves"],
+                              info["gmres_worst_relres"]), RuntimeWarning, stacklevel=3)
+
+
 def default_opts(**kw):
     o = RicadiOpts()
     load().ricadi_default_opts(C.byref(o))
@@ -327,7 +338,9 @@ class Context:
         if fetch:
             Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
         info = dict(adi_steps=int(stats[0]), adi_rel_newZ=stats[1], gmres_iters=int(stats[2]),
-                    shift_solves=int(stats[3]), res_fro=stats[4], cols=c)
+                    shift_solves=int(stats[3]), res_fro=stats[4], cols=c,
+                    gmres_nonconverged=int(stats[5]), gmres_worst_relres=stats[6])
+        _warn_nonconverged(info)
         return Z, info
 
     def ric_newtonadi(self, shifts, B, W, prm, Z0=None, oldB=None, fetch=True):
@@ -351,7 +364,9 @@ class Context:
             Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
         info = dict(nwtn_steps=int(stats[0]), upd_abs=stats[1], upd_rel=stats[2],
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
-                    shift_solves=int(stats[5]), cols=c)
+                    shift_solves=int(stats[5]), cols=c,
+                    gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7])
+        _warn_nonconverged(info)
         return Z, info
 
     def compress(self, Z=None, thresh=None, k=None):

@@ -523,6 +523,8 @@ struct AdiStats {
   long gmres_iters = 0;
   long shift_solves = 0;
   double res_fro = 0.0;
+  long nonconverged = 0;      // shift-solves that hit gmres_maxit above the tolerance
+  double worst_relres = 0.0;
 };
 
 // dW: NV x m device panel (overwritten by the final residual factor).
@@ -541,9 +543,13 @@ static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double
     ShiftData* sd = get_shift(c, p, 1.0);
     load_rhs(c, dW, m, c->bvec.p);
     GmresResult r = gmres_solve(c, sd, c->bvec.p, c->xs.p, m, true, nullptr);
-    if (!r.converged && prm.verbose)
-      fprintf(stderr, "[ricadi] ADI step %d shift %g: GMRES stopped at relres %.2e after %d its\n",
-              step, p, r.max_relres, r.iters);
+    if (!r.converged) {
+      stt.nonconverged++;
+      stt.worst_relres = std::max(stt.worst_relres, r.max_relres);
+      if (prm.verbose)
+        fprintf(stderr, "[ricadi] ADI step %d shift %g: GMRES stopped at relres %.2e after %d its\n",
+                step, p, r.max_relres, r.iters);
+    }
     stt.shift_solves++;
     // W <- W - 2 p E V
     launch_spmm(st, c->nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->xs.p, m, nullptr, dW, m, dW, m,
@@ -1131,6 +1137,8 @@ int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W
     stats_out[2] = (double)s.gmres_iters;
     stats_out[3] = (double)s.shift_solves;
     stats_out[4] = s.res_fro;
+    stats_out[5] = (double)s.nonconverged;
+    stats_out[6] = s.worst_relres;
   }
   API_END
 }
@@ -1173,7 +1181,8 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   p2.project_w = 0;
   if (p2.compress_cols <= 0) p2.compress_cols = 512;
   double upd = 0, updrel = 0;
-  long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves;
+  long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves, nonconv = 0;
+  double worst = 0.0;
   int steps = 0;
   for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
     int m = mw;
@@ -1201,6 +1210,8 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     factor_reserve(c, prm->adi_max_steps * m);
     AdiStats s = lyap_adi_dev(c, shifts, ns, dRhs.p, m, p2);
     adi_total += s.steps;
+    nonconv += s.nonconverged;
+    worst = std::max(worst, s.worst_relres);
     // compressed copy of the new iterate (truncation at the Gram noise floor)
     factor_recompress(c);
     Znew.alloc((size_t)nv * c->zc);
@@ -1233,6 +1244,8 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     stats_out[3] = (double)adi_total;
     stats_out[4] = (double)(c->total_iters - it0);
     stats_out[5] = (double)(c->total_solves - sol0);
+    stats_out[6] = (double)nonconv;
+    stats_out[7] = worst;
   }
   API_END
 }

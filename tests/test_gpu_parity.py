@@ -116,6 +116,21 @@ def test_shift_solve_wide_panel(ctx1, cfg1):
         assert rel(X[:pr.NV], lu.solve(R)[:pr.NV]) < 1e-8
 
 
+def test_nonconvergence_is_reported(cfg1):
+    """An inner solve that cannot reach its tolerance is not an error (the ADI loop
+    goes on, as the reference's loops do at *_max_steps) but must be visible."""
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    ctx = _lib.Context(0, gmres_maxit=5)
+    ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    prm = _lib.adi_params(dict(adi_max_steps=2, project_w=False))
+    with pytest.warns(RuntimeWarning, match="shift-solves stopped"):
+        Z, info = ctx.lyap_adi(ms, trct, prm)
+    assert info["gmres_nonconverged"] == 2 and info["gmres_worst_relres"] > 1e-11
+    assert np.isfinite(Z).all()
+    ctx.close()
+
+
 def test_argument_errors(ctx1, cfg1):
     pr = cfg1[0]
     with pytest.raises(ValueError):
