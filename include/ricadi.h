@@ -219,6 +219,13 @@ int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,
 int ricadi_time_spmm_dev(ricadi_ctx* ctx, double alpha, double beta, const double* dX,
                          int m, double* dY, int reps, double* ms_per_launch);
 
+/* K5: thin QR factorisation Z = Q R of an NV x c host matrix (c <= NV) by block
+ * Gram-Schmidt with re-orthogonalisation over 32-column panels, each panel
+ * factorised by a Householder TSQR tree.  R_out: c x c row-major upper triangular;
+ * Q_out: NV x c or NULL.  The "QR" of the reference's compress_Zsvd comment
+ * (/root/reference/optcont_main.py:133-134) and of the Newton update norm.      */
+int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_out);
+
 /* Average duration (ms) of the FP64-MFMA Gram kernel G = Z^T Z (the 2*NV*c^2 flop
  * part of ricadi_compress) for a device-resident NV x c factor, HIP events on the
  * context stream.  dG must hold c*c doubles.                                   */

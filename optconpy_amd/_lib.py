@@ -79,6 +79,7 @@ SIGNATURES = {
     "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
     "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
                                        _dp]),
+    "ricadi_qr": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
     "ricadi_time_gram_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _dp]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
@@ -461,6 +462,19 @@ def _time_gram_dev(self, z_ptr, c, g_ptr, reps):
 
 
 Context.time_gram_dev = _time_gram_dev
+
+
+def _qr(self, Z, want_q=True):
+    """Thin QR by TSQR panels + block Gram-Schmidt (K5); returns (Q or None, R)."""
+    Z = as_panel(Z, self.nv)
+    c = Z.shape[1]
+    R = np.empty((c, c))
+    Q = np.empty_like(Z) if want_q else None
+    _chk(self._lib.ricadi_qr(self._h, _d(Z), c, None if Q is None else _d(Q), _d(R)))
+    return Q, R
+
+
+Context.qr = _qr
 
 
 def host_aggregate(pattern, bsize):

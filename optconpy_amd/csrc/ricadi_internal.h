@@ -126,6 +126,12 @@ void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int ld
                     int ldb, double* C, int ldc);
 void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
                     int ldc, double* Y, int ldy, double alpha, double beta);
+int tsqr_num_blocks(int nrows);
+void launch_tsqr_local(hipStream_t st, int nrows, int w, const double* A, int lda, double* Qloc,
+                       double* Rstack);
+void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, const double* G,
+                       double* Qout, int ldq);
+void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);
 void launch_set_identity(hipStream_t st, int k, double* out);

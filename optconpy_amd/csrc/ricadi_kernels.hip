@@ -1316,6 +1316,188 @@ void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int ld
                      alpha, beta);
 }
 
+// ---------------------------------------------------------------------------
+// K5: Householder TSQR of a tall n x w panel (w <= 32).
+//
+// tsqr_local: one workgroup per block of TSQR_RB rows.  The block is copied into
+// LDS and factorised by w Householder reflectors (LAPACK conventions: v_k(k) = 1,
+// H_k = I - tau_k v_k v_k^T); the upper triangle is the block's R.  The explicit
+// thin Q of the block (TSQR_RB x w) is then formed in a second LDS tile by
+// applying the reflectors in reverse order to [I; 0] -- Householder quality,
+// also for (numerically) rank-deficient panels, unlike Q = A R^-1.
+// The host stacks the R factors and repeats until one block is left; tsqr_apply
+// multiplies the local Q's by the 32 x 32 blocks of the next level's Q on the
+// way down.
+// ---------------------------------------------------------------------------
+constexpr int TSQR_RB = 256, TSQR_W = 32, TSQR_LD = TSQR_W + 1;
+
+__device__ __forceinline__ double tsqr_block_sum(double v, double* red, int tid) {
+  // sum over the 256 threads of the workgroup (4 waves)
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const double s = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(256) void tsqr_local_kernel(int nrows, int w,
+                                                         const double* __restrict__ A, int lda,
+                                                         double* __restrict__ Qloc,
+                                                         double* __restrict__ Rstack) {
+  extern __shared__ double sm[];
+  double* T = sm;                               // TSQR_RB x TSQR_LD  (the panel block)
+  double* E = sm + TSQR_RB * TSQR_LD;           // TSQR_RB x TSQR_LD  (explicit Q)
+  double* wsum = E + TSQR_RB * TSQR_LD;         // 8 x TSQR_W partial dot products
+  double* tau = wsum + 8 * TSQR_W;              // TSQR_W
+  double* red = tau + TSQR_W;                   // 4
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * TSQR_RB;
+  const int nr = min(TSQR_RB, nrows - r0);
+  for (int e = tid; e < TSQR_RB * TSQR_W; e += 256) {
+    const int i = e / TSQR_W, j = e - i * TSQR_W;
+    T[i * TSQR_LD + j] = (i < nr && j < w) ? A[(size_t)(r0 + i) * lda + j] : 0.0;
+  }
+  __syncthreads();
+  const int jc = tid & 31, sl = tid >> 5;       // column / 32-row slice owned in the updates
+  for (int k = 0; k < w; ++k) {
+    // reflector for column k
+    double part = 0.0;
+    for (int i = k + 1 + tid; i < TSQR_RB; i += 256) part += T[i * TSQR_LD + k] * T[i * TSQR_LD + k];
+    const double ssq = tsqr_block_sum(part, red, tid);
+    const double alpha = T[k * TSQR_LD + k];
+    double tk = 0.0, scale = 0.0, beta = alpha;
+    if (ssq > 0.0) {
+      beta = -copysign(sqrt(alpha * alpha + ssq), alpha);
+      tk = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    __syncthreads();
+    for (int i = k + 1 + tid; i < TSQR_RB; i += 256) T[i * TSQR_LD + k] *= scale;
+    if (tid == 0) {
+      T[k * TSQR_LD + k] = beta;
+      tau[k] = tk;
+    }
+    __syncthreads();
+    // trailing update: w_j = v^T T[:, j], T[:, j] -= tau v w_j   (j > k)
+    double ps = 0.0;
+    if (jc > k && jc < w) {
+      for (int i = max(k, sl * 32); i < sl * 32 + 32; ++i) {
+        const double vi = (i == k) ? 1.0 : T[i * TSQR_LD + k];
+        ps = fma(vi, T[i * TSQR_LD + jc], ps);
+      }
+    }
+    wsum[sl * TSQR_W + jc] = ps;
+    __syncthreads();
+    if (jc > k && jc < w) {
+      double wj = 0.0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) wj += wsum[t * TSQR_W + jc];
+      wj *= tk;
+      for (int i = max(k, sl * 32); i < sl * 32 + 32; ++i) {
+        const double vi = (i == k) ? 1.0 : T[i * TSQR_LD + k];
+        T[i * TSQR_LD + jc] = fma(-vi, wj, T[i * TSQR_LD + jc]);
+      }
+    }
+    __syncthreads();
+  }
+  // R of this block
+  for (int e = tid; e < TSQR_W * TSQR_W; e += 256) {
+    const int i = e / TSQR_W, j = e - i * TSQR_W;
+    Rstack[(size_t)blockIdx.x * TSQR_W * TSQR_W + e] = (j >= i && i < w && j < w) ? T[i * TSQR_LD + j] : 0.0;
+  }
+  // explicit Q = H_0 ... H_{w-1} [I; 0]
+  for (int e = tid; e < TSQR_RB * TSQR_W; e += 256) {
+    const int i = e / TSQR_W, j = e - i * TSQR_W;
+    E[i * TSQR_LD + j] = (i == j && j < w) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int k = w - 1; k >= 0; --k) {
+    double ps = 0.0;
+    if (jc < w) {
+      for (int i = max(k, sl * 32); i < sl * 32 + 32; ++i) {
+        const double vi = (i == k) ? 1.0 : T[i * TSQR_LD + k];
+        ps = fma(vi, E[i * TSQR_LD + jc], ps);
+      }
+    }
+    wsum[sl * TSQR_W + jc] = ps;
+    __syncthreads();
+    if (jc < w) {
+      double wj = 0.0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) wj += wsum[t * TSQR_W + jc];
+      wj *= tau[k];
+      for (int i = max(k, sl * 32); i < sl * 32 + 32; ++i) {
+        const double vi = (i == k) ? 1.0 : T[i * TSQR_LD + k];
+        E[i * TSQR_LD + jc] = fma(-vi, wj, E[i * TSQR_LD + jc]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nr * TSQR_W; e += 256) {
+    const int i = e / TSQR_W, j = e - i * TSQR_W;
+    Qloc[(size_t)(r0 + i) * TSQR_W + j] = E[i * TSQR_LD + j];
+  }
+}
+int tsqr_num_blocks(int nrows) { return (nrows + TSQR_RB - 1) / TSQR_RB; }
+void launch_tsqr_local(hipStream_t st, int nrows, int w, const double* A, int lda, double* Qloc,
+                       double* Rstack) {
+  const size_t lds = (size_t)(2 * TSQR_RB * TSQR_LD + 8 * TSQR_W + TSQR_W + 8) * sizeof(double);
+  static bool attr_set = false;   // 137 KB of dynamic LDS: above the 64 KB default limit
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tsqr_local_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tsqr_local_kernel, dim3(tsqr_num_blocks(nrows)), dim3(256), lds, st, nrows, w,
+                     A, lda, Qloc, Rstack);
+}
+
+// Q[rows of block b] <- Qloc[rows of block b] (RB x 32) * G[b*32 .. b*32+31][:] (32 x 32);
+// a block of the lower level consists of 8 stacked R's, i.e. row block b of the
+// lower level's matrix corresponds to rows b*32.. of the upper level's Q.
+__global__ __launch_bounds__(256) void tsqr_apply_kernel(int nrows, int w,
+                                                         const double* __restrict__ Qloc,
+                                                         const double* __restrict__ G,
+                                                         double* __restrict__ Qout, int ldq) {
+  __shared__ double g[TSQR_W][TSQR_W + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int e = tid; e < TSQR_W * TSQR_W; e += 256)
+    g[e / TSQR_W][e % TSQR_W] = G[(size_t)b * TSQR_W * TSQR_W + e];
+  __syncthreads();
+  const int r0 = b * TSQR_RB;
+  const int nr = min(TSQR_RB, nrows - r0);
+  for (int e = tid; e < nr * TSQR_W; e += 256) {
+    const int i = e / TSQR_W, j = e - i * TSQR_W;
+    const double* q = Qloc + (size_t)(r0 + i) * TSQR_W;
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < TSQR_W; ++t) s = fma(q[t], g[t][j], s);
+    if (j < w) Qout[(size_t)(r0 + i) * ldq + j] = s;   // the destination may be only w columns wide
+  }
+}
+void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, const double* G,
+                       double* Qout, int ldq) {
+  hipLaunchKernelGGL(tsqr_apply_kernel, dim3(tsqr_num_blocks(nrows)), dim3(256), 0, st, nrows, w,
+                     Qloc, G, Qout, ldq);
+}
+
+// out[j, i] = sgn(j) * in[i, j]  for a k x k matrix; sgn(j) = +1 for j < k1, sneg otherwise
+__global__ void transpose_sign_kernel(int k, int k1, double sneg, const double* __restrict__ in,
+                                      double* __restrict__ out) {
+  size_t n = (size_t)k * k;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(e / k), i = (int)(e % k);
+    out[e] = (j < k1 ? 1.0 : sneg) * in[(size_t)i * k + j];
+  }
+}
+void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out) {
+  size_t n = (size_t)k * k;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(transpose_sign_kernel, dim3(grid), dim3(256), 0, st, k, k1, sneg, in, out);
+}
+
 // coarse matrix combine: out = beta*E0 + alpha*EM + EJ  (dense k x k)
 __global__ void combine3_kernel(size_t n, const double* a0, const double* a1, const double* a2,
                                 double alpha, double beta, double* out) {

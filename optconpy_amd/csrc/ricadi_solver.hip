@@ -633,40 +633,114 @@ static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double
   return k;
 }
 
+// ---- K5: Householder TSQR tree and block QR ----------------------------------------
+// Q (n x w, leading dimension ldq) and R (w x w upper, row-major, written with leading
+// dimension ldr) of the n x w panel P (ldp), w <= 32.
+static void tsqr_dev(ricadi_ctx* c, const double* P, int ldp, int n, int w, double* Q, int ldq,
+                     double* R, int ldr) {
+  hipStream_t st = c->st;
+  std::vector<int> rows;        // rows of the matrix factorised at each level
+  rows.push_back(n);
+  while (tsqr_num_blocks(rows.back()) > 1) rows.push_back(tsqr_num_blocks(rows.back()) * 32);
+  const int L = (int)rows.size();
+  std::vector<DArr<double>> qloc(L), rst(L), qfin(L);
+  for (int l = 0; l < L; ++l) {
+    qloc[l].alloc((size_t)rows[l] * 32);
+    rst[l].alloc((size_t)tsqr_num_blocks(rows[l]) * 32 * 32);
+    launch_tsqr_local(st, rows[l], w, l == 0 ? P : rst[l - 1].p, l == 0 ? ldp : 32, qloc[l].p,
+                      rst[l].p);
+  }
+  // R of the top level; Q on the way down
+  launch_copy_cols(st, w, w, rst[L - 1].p, 32, 0, R, ldr, 0, 1.0);
+  const double* upper = qloc[L - 1].p;       // explicit Q of the top level (one block)
+  if (L == 1) {
+    launch_copy_cols(st, n, w, qloc[0].p, 32, 0, Q, ldq, 0, 1.0);
+  } else {
+    for (int l = L - 2; l >= 0; --l) {
+      double* dst;
+      int ld;
+      if (l == 0) {
+        dst = Q;
+        ld = ldq;
+      } else {
+        qfin[l].alloc((size_t)rows[l] * 32);
+        dst = qfin[l].p;
+        ld = 32;
+      }
+      // intermediate levels keep all 32 columns (ld 32); the final Q only w
+      launch_tsqr_apply(st, rows[l], l == 0 ? w : 32, qloc[l].p, upper, dst, ld);
+      upper = dst;
+    }
+    // tsqr_apply writes all 32 columns; columns >= w of Q are exact zeros
+  }
+  HIPCHK(hipStreamSynchronize(st));
+}
+
+// D = Q R for a tall n x kk matrix (ldd): block classical Gram-Schmidt with
+// re-orthogonalisation between 32-column panels (both passes on the FP64 MFMA
+// GEMMs), Householder TSQR inside a panel.  Q: n x kk (ld kk), R: kk x kk
+// row-major upper triangular.  Q may be NULL-free scratch of the caller.
+static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
+                         double* R) {
+  hipStream_t st = c->st;
+  DArr<double> P, C1, C2;
+  P.alloc((size_t)n * 32);
+  C1.alloc((size_t)kk * 32);
+  C2.alloc((size_t)kk * 32);
+  HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * kk * kk, st));
+  for (int c0 = 0; c0 < kk; c0 += 32) {
+    const int w = std::min(32, kk - c0);
+    HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));
+    launch_copy_cols(st, n, w, D, ldd, c0, P.p, 32, 0, 1.0);
+    if (c0 > 0) {
+      for (int pass = 0; pass < 2; ++pass) {
+        double* C = pass == 0 ? C1.p : C2.p;
+        HIPCHK(hipMemsetAsync(C, 0, sizeof(double) * c0 * w, st));
+        launch_gemm_tn(st, n, c0, w, Q, kk, P.p, 32, C, w);
+        launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, 32, -1.0, 1.0);
+      }
+      launch_axpby(st, (size_t)c0 * w, 1.0, C2.p, 1.0, C1.p);
+      launch_copy_cols(st, c0, w, C1.p, w, 0, R, kk, c0, 1.0);
+    }
+    tsqr_dev(c, P.p, 32, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+}
+
 // || Z1 Z1^T - Z0 Z0^T ||_F  via an LQ factorisation of [Z1, Z0]^T (Householder,
 // rocSOLVER) -- no squaring, so updates far below 1e-8 relative are resolved.
 static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const double* dZ0, int k0,
                              double* x1norm) {
+  // D = [Z1, Z0] = Q R  (Householder TSQR panels, no squaring of the condition
+  // number);  D S D^T = Q (R S R^T) Q^T with S = diag(I_k1, -I_k0), so the norm
+  // is that of the small matrix R S R^T -- updates far below 1e-8 are resolved.
   hipStream_t st = c->st;
   const int kk = k1 + k0, nv = c->nv;
-  DArr<double> D, tau;
+  DArr<double> D, Q, R, Rt, Rts, T;
   D.alloc((size_t)nv * kk);
-  tau.alloc(std::max(kk, 1));
+  Q.alloc((size_t)nv * kk);
+  R.alloc((size_t)kk * kk);
+  Rt.alloc((size_t)kk * kk);
+  Rts.alloc((size_t)kk * kk);
+  T.alloc((size_t)kk * kk);
   launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
   if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
-  // row-major NV x kk  ==  column-major kk x NV :  D^T = L Q
-  RBCHK(rocsolver_dgelqf(c->rb, kk, nv, D.p, kk, tau.p));
-  // L is kk x min(kk, NV), lower trapezoidal, in the first columns of the
-  // column-major kk x NV array (= the first rows of the row-major one)
-  const int nl = std::min(kk, nv);
-  std::vector<double> Lh((size_t)kk * nl);
-  HIPCHK(hipMemcpyAsync(Lh.data(), D.p, sizeof(double) * kk * nl, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  auto Lat = [&](int i, int j) { return i >= j ? Lh[(size_t)i + (size_t)j * kk] : 0.0; };
-  // D = Q^T L^T (NV x kk)  =>  D S D^T = Q^T (L^T S L) Q,  S = diag(I_k1, -I_k0)
-  double f = 0.0, f1 = 0.0;
-  for (int a = 0; a < nl; ++a)
-    for (int b = 0; b < nl; ++b) {
-      double t = 0.0, t1 = 0.0;
-      for (int i = std::max(a, b); i < kk; ++i) {
-        const double pr = Lat(i, a) * Lat(i, b);
-        if (i < k1) { t += pr; t1 += pr; } else { t -= pr; }
-      }
-      f += t * t;
-      f1 += t1 * t1;
-    }
-  if (x1norm) *x1norm = std::sqrt(f1);
-  return std::sqrt(f);
+  block_qr_dev(c, D.p, kk, nv, kk, Q.p, R.p);
+  std::vector<double> Th((size_t)kk * kk);
+  auto fro_of = [&](double sneg) {
+    // (S R^T)^T (R^T) = R S R^T  with the transposes formed explicitly (kk x kk)
+    launch_transpose_sign(st, kk, kk, 1.0, R.p, Rt.p);
+    launch_transpose_sign(st, kk, k1, sneg, R.p, Rts.p);
+    HIPCHK(hipMemsetAsync(T.p, 0, sizeof(double) * kk * kk, st));
+    launch_gemm_tn(st, kk, kk, kk, Rts.p, kk, Rt.p, kk, T.p, kk);
+    HIPCHK(hipMemcpyAsync(Th.data(), T.p, sizeof(double) * kk * kk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double f = 0.0;
+    for (double v : Th) f += v * v;
+    return std::sqrt(f);
+  };
+  if (x1norm) *x1norm = fro_of(0.0);     // S1 = diag(I, 0): || Z1 Z1^T ||_F
+  return fro_of(-1.0);
 }
 
 // K = E * (Z * (Z^T B))  (device);  dK is NV x nb
@@ -1087,6 +1161,24 @@ int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double*
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_per_launch = (double)ms / reps;
+  API_END
+}
+
+int ricadi_qr(ricadi_ctx* c, const double* Z, int cz, double* Q_out, double* R_out) {
+  REQUIRE(c && c->nv > 0, RICADI_ESTATE, "set the operator (or the dimensions) first");
+  REQUIRE(Z && R_out && cz > 0 && cz <= c->nv, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  (void)hipSetDevice(c->dev);
+  const int nv = c->nv;
+  DArr<double> dZ, dQ, dR;
+  dZ.alloc((size_t)nv * cz);
+  dQ.alloc((size_t)nv * cz);
+  dR.alloc((size_t)cz * cz);
+  HIPCHK(hipMemcpyAsync(dZ.p, Z, sizeof(double) * nv * cz, hipMemcpyHostToDevice, c->st));
+  block_qr_dev(c, dZ.p, cz, nv, cz, dQ.p, dR.p);
+  HIPCHK(hipMemcpyAsync(R_out, dR.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, c->st));
+  if (Q_out) HIPCHK(hipMemcpyAsync(Q_out, dQ.p, sizeof(double) * nv * cz, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
   API_END
 }
 

@@ -388,3 +388,34 @@ def test_two_ranks_on_one_gpu():
     solves = [int(x) for x in re.findall(r"local solves (\d+)", out.stdout)]
     assert len(errs) == 2 and max(errs) < K_TOL
     assert len(solves) == 2 and solves[0] == solves[1] and solves[0] > 0
+
+
+@pytest.mark.parametrize("n,c", [(300, 7), (3000, 70), (26450, 456)])
+def test_tsqr_block_qr(n, c):
+    """K5: Householder TSQR panels + block Gram-Schmidt: Z = Q R to rounding, Q orthonormal,
+    R upper triangular -- also for a numerically rank-deficient Z (the Newton update norm
+    factorises [Z_new, Z_old] with Z_new ~ Z_old)."""
+    rng = np.random.default_rng(n + c)
+    ctx = _lib.Context(0)
+    ctx.set_dims(n)
+    Z = rng.standard_normal((n, c))
+    Q, R = ctx.qr(Z)
+    assert np.allclose(np.tril(R, -1), 0.0)
+    assert np.linalg.norm(Q @ R - Z) <= 1e-13 * np.linalg.norm(Z)
+    assert np.linalg.norm(Q.T @ Q - np.eye(c)) <= 1e-12
+    # |R| matches LAPACK's up to row signs
+    Rl = np.linalg.qr(Z, mode="r")
+    assert np.allclose(np.abs(np.diag(R)), np.abs(np.diag(Rl)), rtol=1e-10)
+    # rank deficient: second half = first half + 1e-9 perturbation
+    h = c // 2
+    if h >= 2:
+        Zd = np.hstack([Z[:, :h], Z[:, :h] + 1e-9 * rng.standard_normal((n, h))])
+        Qd, Rd = ctx.qr(Zd)
+        assert np.linalg.norm(Qd @ Rd - Zd) <= 1e-13 * np.linalg.norm(Zd)
+        assert np.linalg.norm(Qd.T @ Qd - np.eye(2 * h)) <= 1e-10
+        # || Z1 Z1^T - Z0 Z0^T ||_F from the factor, against the oracle's QR-based value
+        S = np.r_[np.ones(h), -np.ones(h)]
+        got = np.linalg.norm((Rd * S) @ Rd.T)
+        ref = opru.comp_diff_zzt_fnorm(Zd[:, :h], Zd[:, h:])
+        assert np.isclose(got, ref, rtol=1e-6)
+    ctx.close()
