@@ -57,6 +57,9 @@ typedef struct ricadi_opts {
   int coarse_max;        /* cap on coarse dimension (default 4096)          */
   int use_coarse;        /* 0: one-level block-Jacobi only                  */
   int verbose;
+  int compress_qr;       /* ricadi_compress: 0 = Gram matrix + eigendecomposition
+                            (fast; resolves singular values down to sqrt(eps)*s_1),
+                            1 = TSQR block QR + SVD of R (resolves them to eps*s_1) */
 } ricadi_opts;
 
 /* Parameters of the ADI / Newton loops; same meaning as the keys of the

@@ -24,7 +24,7 @@ class RicadiOpts(C.Structure):
     _fields_ = [("gmres_tol", C.c_double), ("gmres_restart", C.c_int),
                 ("gmres_maxit", C.c_int), ("bj_block", C.c_int), ("agg_v", C.c_int),
                 ("agg_p", C.c_int), ("coarse_max", C.c_int), ("use_coarse", C.c_int),
-                ("verbose", C.c_int)]
+                ("verbose", C.c_int), ("compress_qr", C.c_int)]
 
 
 class RicadiAdiParams(C.Structure):

@@ -498,7 +498,10 @@ struct DScalar {
 };
 
 static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
-                        bool thresh_relative, double* dOut, std::vector<double>* sv_host);
+                        bool thresh_relative, double* dOut, std::vector<double>* sv_host,
+                        bool use_qr = false);
+static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
+                         double* R);
 
 // Truncation level of the internal recompressions: the Gram-matrix route
 // resolves singular values down to sqrt(eps)*sigma_1; dropping what lies below
@@ -590,9 +593,47 @@ static void factor_reserve(ricadi_ctx* c, int ld) {
 // dZ: NV x cz (ld = ldz).  Returns k and writes Zc (NV x k, ld = k) into dOut
 // (which must hold NV*cz doubles).  Singular values (descending) to sv_host.
 static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
-                        bool thresh_relative, double* dOut, std::vector<double>* sv_host) {
+                        bool thresh_relative, double* dOut, std::vector<double>* sv_host,
+                        bool use_qr) {
   hipStream_t st = c->st;
   if (cz == 0) return 0;
+  if (use_qr && cz <= c->nv) {
+    // Z = Q R (TSQR panels), R^T = U' S V'^T (rocSOLVER, column-major view of the
+    // row-major R), right singular vectors of R = U'; Zc = Z V_k.
+    DArr<double> Q, R, S, U, E5;
+    Q.alloc((size_t)c->nv * cz);
+    R.alloc((size_t)cz * cz);
+    S.alloc(cz);
+    U.alloc((size_t)cz * cz);
+    E5.alloc(cz);
+    block_qr_dev(c, dZ, ldz, c->nv, cz, Q.p, R.p);
+    RBCHK(rocsolver_dgesvd(c->rb, rocblas_svect_all, rocblas_svect_none, cz, cz, R.p, cz, S.p, U.p, cz,
+                           nullptr, 1, E5.p, rocblas_outofplace, c->info.p));
+    std::vector<double> sv(cz), Uh((size_t)cz * cz);
+    HIPCHK(hipMemcpyAsync(sv.data(), S.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(Uh.data(), U.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int k = std::min(cz, c->nv);
+    if (thresh >= 0.0) {
+      const double t = thresh_relative ? thresh * sv[0] : thresh;
+      int cnt = 0;
+      while (cnt < cz && sv[cnt] > t) ++cnt;
+      k = std::min(k, cnt);
+    }
+    if (kmax > 0) k = std::min(k, kmax);
+    if (sv_host) *sv_host = sv;
+    if (k == 0) return 0;
+    // row jj of the row-major view of U' = right singular vector jj of R
+    std::vector<double> Ch((size_t)cz * k);
+    for (int jj = 0; jj < k; ++jj)
+      for (int i = 0; i < cz; ++i) Ch[(size_t)i * k + jj] = Uh[(size_t)jj * cz + i];
+    DArr<double> sel;
+    sel.alloc((size_t)cz * k);
+    HIPCHK(hipMemcpyAsync(sel.p, Ch.data(), sizeof(double) * cz * k, hipMemcpyHostToDevice, st));
+    launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
+    HIPCHK(hipStreamSynchronize(st));
+    return k;
+  }
   DArr<double> G, ev, work, sel;
   G.alloc((size_t)cz * cz);
   ev.alloc(cz);
@@ -800,6 +841,7 @@ void ricadi_default_opts(ricadi_opts* o) {
   o->coarse_max = 4096;
   o->use_coarse = 1;
   o->verbose = 0;
+  o->compress_qr = 0;
 }
 
 void ricadi_default_adi_params(ricadi_adi_params* p) {
@@ -1364,7 +1406,7 @@ int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int k
   }
   out.alloc((size_t)c->nv * cz);
   std::vector<double> sv;
-  int k = compress_dev(c, dZ, cz, ld, thresh, kmax, false, out.p, &sv);
+  int k = compress_dev(c, dZ, cz, ld, thresh, kmax, false, out.p, &sv, c->opts.compress_qr != 0);
   *k_out = k;
   if (k > 0) {
     HIPCHK(hipMemcpyAsync(Zc_out, out.p, sizeof(double) * c->nv * k, hipMemcpyDeviceToHost, c->st));

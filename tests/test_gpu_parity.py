@@ -419,3 +419,29 @@ def test_tsqr_block_qr(n, c):
         ref = opru.comp_diff_zzt_fnorm(Zd[:, :h], Zd[:, h:])
         assert np.isclose(got, ref, rtol=1e-6)
     ctx.close()
+
+
+def test_compress_qr_mode_resolves_small_singular_values():
+    """compress_qr=1: TSQR block QR + SVD of R.  Singular values far below
+    sqrt(eps)*s_1 are resolved (the Gram route cannot), so the kept rank equals the
+    oracle's QR + SVD (the reference's "QR ... SVD", optcont_main.py:133-134)."""
+    rng = np.random.default_rng(21)
+    n, c = 4000, 60
+    Qm, _ = np.linalg.qr(rng.standard_normal((n, c)))
+    s = np.logspace(0, -13, c)
+    Z = (Qm * s) @ np.linalg.qr(rng.standard_normal((c, c)))[0]
+    ctx = _lib.Context(0, compress_qr=1)
+    ctx.set_dims(n)
+    for thresh in (1e-6, 1e-10, 3e-12):
+        Zc, sv = ctx.compress(Z, thresh=thresh)
+        Zo = opru.compress_Zsvd(Z, thresh=thresh)
+        assert Zc.shape == Zo.shape, (thresh, Zc.shape, Zo.shape)
+        assert np.allclose(sv[:Zc.shape[1]], s[:Zc.shape[1]], rtol=1e-6)
+        assert opru.comp_diff_zzt_fnorm(Zc, Zo) <= 1e-12 * np.linalg.norm(Zo.T @ Zo)
+    ctx.close()
+    # the default Gram route: same result down to sqrt(eps), not below
+    ctx = _lib.Context(0)
+    ctx.set_dims(n)
+    Zc, _ = ctx.compress(Z, thresh=1e-6)
+    assert Zc.shape == opru.compress_Zsvd(Z, thresh=1e-6).shape
+    ctx.close()
