@@ -275,7 +275,7 @@ def main():
             "config": {
                 "workload": "driven cavity N=%d (cfg2: n=%d, nnz(S)=%d), nu=%g, %d log-spaced "
                             "ADI shifts, 1 Newton step (closed-loop Lyapunov ADI to "
-                            "adi_newZ_reltol=1e-8) + gain K; panel m=%d; GMRES tol 1e-11"
+                            "adi_newZ_reltol=1e-8) + gain K; panel m=%d; GMRES tol 1e-10"
                             % (args.N, n, nnz_s, args.nu, len(ms), m),
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),

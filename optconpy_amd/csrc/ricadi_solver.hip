@@ -832,7 +832,7 @@ int ricadi_version(void) { return 100; }
 
 void ricadi_default_opts(ricadi_opts* o) {
   if (!o) return;
-  o->gmres_tol = 1e-11;
+  o->gmres_tol = 1e-10;
   o->gmres_restart = 20;
   o->gmres_maxit = 3000;
   o->bj_block = 32;

@@ -28,7 +28,8 @@ def worker(rank, world, port, out):
     Z = torch.cat(blocks, dim=1).contiguous()
     K = ops.gain(-1.0, Z, ops.to_panel(tb.toarray())).cpu().numpy()
     np.save(os.path.join(out, "K%d.npy" % rank), K)
-    print("rank", rank, info["adi_steps"], info["sweeps"], "local solves", ops.shift_solves, flush=True)
+    np.save(os.path.join(out, "info%d.npy" % rank),
+            np.array([info["adi_steps"], info["sweeps"], ops.shift_solves]))
     dist.destroy_process_group()
 
 
@@ -39,4 +40,6 @@ if __name__ == "__main__":
     g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cfg1_golden.npz"))
     for r in range(2):
         K = np.load(os.path.join(out, "K%d.npy" % r))
+        steps, sweeps, solves = np.load(os.path.join(out, "info%d.npy" % r))
+        print("rank %d: %d ADI steps in %d sweeps, local solves %d" % (r, steps, sweeps, solves))
         print("rank %d K rel diff vs golden %.2e" % (r, np.linalg.norm(K - g["K_lyap"]) / np.linalg.norm(g["K_lyap"])))
