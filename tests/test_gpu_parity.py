@@ -445,3 +445,25 @@ def test_compress_qr_mode_resolves_small_singular_values():
     Zc, _ = ctx.compress(Z, thresh=1e-6)
     assert Zc.shape == opru.compress_Zsvd(Z, thresh=1e-6).shape
     ctx.close()
+
+
+def test_newton_parity_other_ordering_and_viscosity():
+    """Interleaved dof ordering and nu = 0.02 (four Newton steps): same step count as the
+    oracle and K within the parity bar."""
+    for nu, order in ((0.02, "component"), (0.1, "interleaved")):
+        pr = pb.ricc_problem(15, nu, ordering=order)
+        F = (-pr.A - pr.Nc).tocsr()
+        mct = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+        tb = olau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+        trct = olau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+        ms = pb.logshifts(1.0, 1e3, 8)
+        d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+        ctx = _lib.Context(0)
+        ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+        Z, info = ctx.ric_newtonadi(ms, tb, trct, _lib.adi_params(d))
+        K = -ctx.gain(tb)
+        ctx.close()
+        ref = opru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct,
+                                          nwtn_adi_dict=d)
+        assert info["nwtn_steps"] == ref["nwtn_steps"]
+        assert rel(K, -opru.get_mTzzTtb(pr.M.T, ref["zfac"], tb)) < K_TOL
