@@ -16,12 +16,14 @@ Every N runs the same problem with the shift-parallel Cauchy sweeps
 (optconpy_amd/shift_parallel.py): sweeps of 8 distinct shifts solved
 independently against the same residual factor, recombined with the 8 x 8
 Cauchy matrix -- identical to 8 sequential ADI steps.  Shift g of a sweep is
-solved by rank g % N; a rank solves its 8/N shifts concurrently on 8/N HIP
-streams (one library context and one host thread per stream), since one
-shift-solve at this size is a chain of short latency-bound kernels that leaves
-most of the chip idle.  N > 1: one process per GPU (torch.distributed, RCCL),
-one all-gather per sweep -> total work fixed, "scaling": "strong".
-`--sequential` times the single-stream device-resident C++ ADI instead.
+solved by rank g % N; a rank solves its 8/N shifts in ONE batched GMRES
+(ricadi_shift_solve_batch_dev: all shifts advance in lockstep, every kernel of
+the iteration is launched once with grid.z = shifts still iterating), since one
+shift-solve at this size is a chain of short kernels that leaves most of the
+chip idle.  N > 1: one process per GPU (torch.distributed, RCCL), one
+all-gather per sweep -> total work fixed, "scaling": "strong".
+`--sequential` times the single-panel device-resident C++ ADI instead;
+`--streams k` the older scheme of k concurrent per-shift solves on k HIP streams.
 
 The JSON line also carries the SpMM roofline figures (kernel time from HIP
 events on the library's stream) and the CPU baseline (oracle = scipy SuperLU on
@@ -139,9 +141,9 @@ def main():
     ap.add_argument("--sequential", action="store_true",
                     help="N=1 only: single-stream sequential ADI inside libricadi_hip.so")
     ap.add_argument("--sweep-width", type=int, default=8, help="shifts per sweep (<= 8)")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="concurrent shift-solves per GPU in the shift-parallel path "
-                         "(one library context / HIP stream each; 0 = sweep width / ranks)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="1 (default): the shifts of a rank go through one batched solve; k > 1: "
+                         "k concurrent per-shift solves (one library context / HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-roofline", action="store_true")
     args = ap.parse_args()
@@ -203,7 +205,7 @@ def main():
             return info["shift_solves"], info["gmres_iters"], K, info["shift_solves"]
     else:
         from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel
-        nstreams = args.streams if args.streams > 0 else max(1, -(-min(args.sweep_width, 8) // world))
+        nstreams = max(1, args.streams)
         extra = []
         for _ in range(max(0, nstreams - 1)):
             cx = _lib.Context(local, **xopts)
@@ -280,9 +282,9 @@ def main():
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),
                 "parallelism": "sequential ADI, 1 GPU" if not use_sp
-                else "shift-parallel ADI on %d GPU(s), %d shifts/sweep, %d concurrent stream(s)/GPU, "
-                     "1 all-gather/sweep"
-                % (world, G, nstreams),
+                else "shift-parallel ADI on %d GPU(s), %d shifts/sweep, %s, 1 all-gather/sweep"
+                % (world, G, "one batched lockstep solve per rank and sweep" if nstreams == 1
+                   else "%d concurrent stream(s)/GPU" % nstreams),
                 "K_rel_diff_vs_converged": k_err,
             },
         }

@@ -50,7 +50,9 @@ typedef struct ricadi_ctx ricadi_ctx;
 typedef struct ricadi_opts {
   double gmres_tol;      /* relative residual per column (default 1e-10, the
                             unit of work of SURVEY.md section 8d)            */
-  int gmres_restart;     /* Krylov vectors per cycle (default 20)           */
+  int gmres_restart;     /* max Krylov vectors per cycle (default 30); cycles
+                            start at 12 vectors and grow to this whenever a
+                            cycle gains less than a factor 10 on some column */
   int gmres_maxit;       /* max iterations per solve (default 3000)         */
   int bj_block;          /* block-Jacobi block size, <= 64 (default 32)     */
   int agg_v;             /* velocity aggregate size of the coarse level     */
@@ -203,6 +205,20 @@ int ricadi_spmm_dev(ricadi_ctx* ctx, double alpha, double beta,
 int ricadi_shift_solve_dev(ricadi_ctx* ctx, double alpha, double beta,
                            const double* dR, int m, double* dX,
                            int* iters_out, double* relres_out);
+/* The shifts of one ADI sweep in ONE batched solve: for g < ng solve
+ *   S(alphas[g], betas[g]) X_g = [R_g; 0]
+ * with R_g = dR + g*r_stride (NV x m each; r_stride in doubles, 0 = the same
+ * right-hand side for every shift, the shift-parallel sweep) and X_g =
+ * dX + g*n*m (n x m each).  All groups advance in lockstep inside one launch
+ * sequence (grid.z = groups still iterating), which fills the chip where a
+ * single n ~ 3e4 panel cannot.  ng <= 16, ng*m <= 2048.  iters_out: ng ints,
+ * relres_out: ng*m doubles (either may be NULL).  Returns RICADI_ENOCONV if a
+ * group stopped at gmres_maxit.  Counterpart of the per-shift factorise-and-
+ * solve calls in the ADI loop, /root/reference/proj_ric_utils.py:183-262.    */
+int ricadi_shift_solve_batch_dev(ricadi_ctx* ctx, int ng, const double* alphas,
+                                 const double* betas, const double* dR,
+                                 int64_t r_stride, int m, double* dX,
+                                 int* iters_out, double* relres_out);
 /* dW (NV x m) += coef * E * dV (first NV rows of an n x m or NV x m panel) */
 int ricadi_apply_e_dev(ricadi_ctx* ctx, double coef, const double* dV, int m, double* dW);
 /* dOut (nrows x m) = sum_i coef[i] * panel_i, panel_i = dBasis + i*stride

@@ -73,6 +73,8 @@ SIGNATURES = {
     "ricadi_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_shift_solve_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp,
                                          C.POINTER(C.c_int), _dp]),
+    "ricadi_shift_solve_batch_dev": (C.c_int, [_vp, C.c_int, _dp, _dp, _vp, C.c_int64, C.c_int, _vp,
+                                               C.POINTER(C.c_int), _dp]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
@@ -430,6 +432,20 @@ class Context:
                                               C.byref(it), _d(rr))
         _chk(rc, allow_noconv=not strict)
         return it.value, rr
+
+    def shift_solve_batch_dev(self, alphas, betas, r_ptr, r_stride, m, x_ptr, strict=True):
+        """One batched solve for the shifts ``(alphas[g], betas[g])``; the right-hand sides
+        are ``r_ptr + g*r_stride`` (``r_stride = 0``: shared), the solutions the ``n x m``
+        panels ``x_ptr + g*n*m``.  Returns ``(iters per group, relres (ng x m))``."""
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        ng = al.size
+        its = (C.c_int * ng)()
+        rr = np.zeros((ng, m))
+        rc = self._lib.ricadi_shift_solve_batch_dev(self._h, ng, _d(al), _d(be), r_ptr,
+                                                    int(r_stride), m, x_ptr, its, _d(rr))
+        _chk(rc, allow_noconv=not strict)
+        return list(its), rr
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):
         _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))

@@ -13,6 +13,7 @@
 #include "../../include/ricadi.h"
 
 #define RICADI_MAX_M 128
+#define RICADI_MAX_GROUPS 16
 
 namespace ricadi {
 
@@ -66,7 +67,79 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
                  HostSetup& hs);
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
 
+// ---- batches of panels ------------------------------------------------------------
+// A *batch* is a set of up to RICADI_MAX_GROUPS panels (one per ADI shift of a
+// sweep), stored group-major: panel g of a buffer starts g * (group stride)
+// doubles behind panel 0.  Batched launches add the ACTIVE groups as grid.z:
+// block z works on group gid[z], so groups whose solve has converged simply
+// drop out of the table while their data stay where they are.  Shift-dependent
+// operands (matrix values, block inverses, coarse inverse) come as one pointer
+// per group id.  Both tables travel by value in the kernel arguments.
+struct GroupTab {
+  int ng;
+  int gid[RICADI_MAX_GROUPS];
+};
+struct GroupPtrs {
+  const double* p[RICADI_MAX_GROUPS];
+};
+inline GroupTab single_group() {
+  GroupTab t{};
+  t.ng = 1;
+  return t;
+}
+inline GroupPtrs same_ptr(const double* q) {
+  GroupPtrs g;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) g.p[i] = q;
+  return g;
+}
+
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
+// The *_b launchers are the batched forms (GroupTab + group strides `gs*`, in
+// doubles); the plain ones run a single panel.
+void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                   const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
+                   double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
+                   double alpha, double beta_r, int m);
+void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rowptr,
+                           const int* rows, const int* rp, const int* cptr, const int* cols,
+                           const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
+                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
+                           const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
+                           int max_cols, int max_nnz);
+void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
+                    size_t gsx, double b, double* y, size_t gsy);
+void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                       const double* x, size_t gsx, double b, double* y, size_t gsy);
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const double* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                        int want_self, double* partial, size_t gsp, double* out, size_t gso);
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const double* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso);
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const double* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso);
+void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
+                         const double* h1, const double* h2, double* H, double* cs, double* sn,
+                         double* g, double* scale, double* resid, const double* bnorm, double tol);
+void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, int k, int restart,
+                              const double* H, const double* g, double* y);
+void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart,
+                          const double* nrm2, double* g, double* scale, double* resid);
+void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                          const int* rows, const GroupPtrs& inv, const double* in, int ldi,
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract);
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
+                          const double* rc, double* ec);
+void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
+                          const double* ec, size_t gse, double* z, size_t gsz);
+void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
+                      int lda, const double* B, int ldb, size_t gsB, double* C, int ldc, size_t gsC);
+void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
+                      int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
+                      double alpha, double beta);
 void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
                  const double* x, int ldx, const int* xmap, double* y, int ldy, const double* r,
                  int ldr, double alpha, double beta_r, const double* rowscale, int m);

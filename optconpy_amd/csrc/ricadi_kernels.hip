@@ -45,11 +45,16 @@ __device__ __forceinline__ double bc16d(double v) {
 // ---------------------------------------------------------------------------
 template <int CPL>
 __global__ __launch_bounds__(256) void spmm_kernel(
-    int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
-    const double* __restrict__ val, const double* __restrict__ x, int ldx,
-    const int* __restrict__ xmap, double* __restrict__ y, int ldy,
-    const double* __restrict__ r, int ldr, double alpha, double beta_r,
+    GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
+    GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
+    const int* __restrict__ xmap, double* __restrict__ y, int ldy, size_t gsy,
+    const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
     const double* __restrict__ rowscale, int m) {
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ val = vals.p[grp];
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
+  if (r) r += (size_t)grp * gsr;
   const int g = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= nrows) return;
@@ -106,11 +111,16 @@ __global__ __launch_bounds__(256) void spmm_kernel(
 // x rows of a band matrix inside that XCD's L2.
 template <int CPL>
 __global__ __launch_bounds__(256) void spmm_kernel_v2(
-    int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
-    const double* __restrict__ val, const double* __restrict__ x, int ldx,
-    const int* __restrict__ xmap, double* __restrict__ y, int ldy,
-    const double* __restrict__ r, int ldr, double alpha, double beta_r,
+    GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
+    GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
+    const int* __restrict__ xmap, double* __restrict__ y, int ldy, size_t gsy,
+    const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
     const double* __restrict__ rowscale, int m) {
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ val = vals.p[grp];
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
+  if (r) r += (size_t)grp * gsr;
   // bijective XCD remap of the block index (cdna guide, T1)
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -173,22 +183,25 @@ static int spmm_variant() {
   return v;
 }
 
-void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
-                 const double* x, int ldx, const int* xmap, double* y, int ldy,
-                 const double* r, int ldr, double alpha, double beta_r,
-                 const double* rowscale, int m) {
-  if (nrows <= 0 || m <= 0) return;
-  dim3 grid((nrows + 15) / 16), block(256);
+static void spmm_dispatch(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
+                          const int* ci, const GroupPtrs& vals, const double* x, int ldx,
+                          size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
+                          const double* r, int ldr, size_t gsr, double alpha, double beta_r,
+                          const double* rowscale, int m) {
+  if (nrows <= 0 || m <= 0 || gt.ng <= 0) return;
+  dim3 grid((nrows + 15) / 16, 1, gt.ng), block(256);
   const int cpl = (m + 15) / 16;
   const bool v2 = spmm_variant() == 2;
 #define RICADI_SPMM_CASE(C)                                                              \
   case C:                                                                                \
     if (v2)                                                                              \
-      hipLaunchKernelGGL(spmm_kernel_v2<C>, grid, block, 0, st, nrows, rp, ci, val, x,   \
-                         ldx, xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);         \
+      hipLaunchKernelGGL(spmm_kernel_v2<C>, grid, block, 0, st, gt, nrows, rp, ci, vals, \
+                         x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r,     \
+                         rowscale, m);                                                   \
     else                                                                                 \
-      hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, nrows, rp, ci, val, x, ldx, \
-                         xmap, y, ldy, r, ldr, alpha, beta_r, rowscale, m);              \
+      hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, gt, nrows, rp, ci, vals, x, \
+                         ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r,        \
+                         rowscale, m);                                                   \
     break;
   switch (cpl) {
     RICADI_SPMM_CASE(1)
@@ -203,6 +216,20 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
       break;  // m <= RICADI_MAX_M = 128 is enforced by the callers
   }
 #undef RICADI_SPMM_CASE
+}
+void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
+                 const double* x, int ldx, const int* xmap, double* y, int ldy,
+                 const double* r, int ldr, double alpha, double beta_r,
+                 const double* rowscale, int m) {
+  spmm_dispatch(st, single_group(), nrows, rp, ci, same_ptr(val), x, ldx, 0, xmap, y, ldy, 0, r, ldr,
+                0, alpha, beta_r, rowscale, m);
+}
+void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                   const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
+                   double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
+                   double alpha, double beta_r, int m) {
+  spmm_dispatch(st, gt, nrows, rp, ci, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha,
+                beta_r, nullptr, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -225,11 +252,16 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ rows, const int* __restrict__ rp,
     const int* __restrict__ cptr, const int* __restrict__ cols,
-    const uint16_t* __restrict__ lidx, const double* __restrict__ val,
-    const double* __restrict__ x, int ldx, const int* __restrict__ xmap,
-    double* __restrict__ y, int ldy, const double* __restrict__ r, int ldr, double alpha,
-    double beta_r, int m, int max_cols, int max_nnz) {
+    const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
+    const double* __restrict__ x, int ldx, size_t gsx, const int* __restrict__ xmap,
+    double* __restrict__ y, int ldy, size_t gsy, const double* __restrict__ r, int ldr,
+    size_t gsr, double alpha, double beta_r, int m, int max_cols, int max_nnz) {
   extern __shared__ double xs[];                             // max_cols x m
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ val = vals.p[grp];
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
+  if (r) r += (size_t)grp * gsr;
   // XCD-contiguous block ranges (bijective remap, cdna guide T1)
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -364,15 +396,25 @@ size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz) {
   (void)max_nnz;
   return (size_t)max_cols * m * sizeof(double) + 16;
 }
+void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rowptr,
+                           const int* rows, const int* rp, const int* cptr, const int* cols,
+                           const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
+                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
+                           const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
+                           int max_cols, int max_nnz) {
+  if (nblk <= 0 || gt.ng <= 0) return;
+  hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+                     spmm_blocked_lds_bytes(m, max_cols, max_nnz), st, rowptr, rows, rp, cptr, cols,
+                     lidx, gt, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m,
+                     max_cols, max_nnz);
+}
 void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
                          const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
                          const double* val, const double* x, int ldx, const int* xmap, double* y,
                          int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
                          int max_cols, int max_nnz) {
-  if (nblk <= 0) return;
-  hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk), dim3(256),
-                     spmm_blocked_lds_bytes(m, max_cols, max_nnz), st, rowptr, rows, rp, cptr, cols,
-                     lidx, val, x, ldx, xmap, y, ldy, r, ldr, alpha, beta_r, m, max_cols, max_nnz);
+  launch_spmm_blocked_b(st, single_group(), nblk, rowptr, rows, rp, cptr, cols, lidx, same_ptr(val),
+                        x, ldx, 0, xmap, y, ldy, 0, r, ldr, 0, alpha, beta_r, m, max_cols, max_nnz);
 }
 
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)
@@ -416,31 +458,49 @@ void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, 
 // ---------------------------------------------------------------------------
 // elementwise panel helpers (K4)
 // ---------------------------------------------------------------------------
-__global__ void axpby_kernel(size_t n, double a, const double* __restrict__ x, double b,
-                             double* __restrict__ y) {
+__global__ void axpby_kernel(GroupTab gt, size_t n, double a, const double* __restrict__ x,
+                             size_t gsx, double b, double* __restrict__ y, size_t gsy) {
+  const int grp = gt.gid[blockIdx.z];
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
-void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y) {
-  if (!n) return;
+void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
+                    size_t gsx, double b, double* y, size_t gsy) {
+  if (!n || gt.ng <= 0) return;
   int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid), dim3(256), 0, st, n, a, x, b, y);
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, n, a, x, gsx, b, y,
+                     gsy);
+}
+void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y) {
+  launch_axpby_b(st, single_group(), n, a, x, 0, b, y, 0);
 }
 
 // y[r, c] = a[c] * x[r, c] + b * y[r, c]   (per-column scale, contiguous panel)
-__global__ void colscale_kernel(size_t n, int m, const double* __restrict__ a,
-                                const double* __restrict__ x, double b, double* __restrict__ y) {
+__global__ void colscale_kernel(GroupTab gt, size_t n, int m, const double* __restrict__ a,
+                                const double* __restrict__ x, size_t gsx, double b,
+                                double* __restrict__ y, size_t gsy) {
+  const int grp = gt.gid[blockIdx.z];
+  a += (size_t)grp * m;
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
     y[i] = a[i % m] * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
 }
+void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                       const double* x, size_t gsx, double b, double* y, size_t gsy) {
+  size_t n = nrows * m;
+  if (!n || gt.ng <= 0) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(colscale_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, n, m, a, x, gsx,
+                     b, y, gsy);
+}
 void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
                      double b, double* y) {
-  size_t n = nrows * m;
-  if (!n) return;
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(colscale_kernel, dim3(grid), dim3(256), 0, st, n, m, a, x, b, y);
+  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0);
 }
 
 // copy a strided block of columns: dst[r, dc0 + c] = scale * src[r, sc0 + c], c < w
@@ -477,9 +537,14 @@ void launch_copy_cols(hipStream_t st, int nrows, int w, const double* src, int l
 constexpr int DOT_ROWS = 64;
 
 __global__ __launch_bounds__(256) void cols_dots_kernel(
-    int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
-    const double* __restrict__ w, int want_self, double* __restrict__ partial) {
+    GroupTab gt, int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    size_t gsb, const double* __restrict__ w, size_t gsw, int want_self,
+    double* __restrict__ partial, size_t gsp) {
   extern __shared__ double wl[];  // DOT_ROWS x m
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
   const int r0 = blockIdx.x * DOT_ROWS;
   const int nr = min(DOT_ROWS, nrows - r0);
   for (int e = threadIdx.x; e < nr * m; e += blockDim.x) wl[e] = w[(size_t)r0 * m + e];
@@ -504,11 +569,14 @@ __global__ __launch_bounds__(256) void cols_dots_kernel(
 // out[o] (+)= sum_b partial[b][o].  256 threads = 16 outputs x 16 block-slices:
 // the 16 lanes of a group read 16 consecutive outputs of one partial row (one
 // 128-B line), the 16 groups stride over the workgroups; LDS tree at the end.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(int nblk, int nout,
+__global__ __launch_bounds__(256) void reduce_partials_kernel(GroupTab gt, int nblk, int nout,
                                                               const double* __restrict__ partial,
-                                                              double* __restrict__ out,
-                                                              int accumulate) {
+                                                              size_t gsp, double* __restrict__ out,
+                                                              size_t gso, int accumulate) {
   __shared__ double red[16][17];
+  const int grp = gt.gid[blockIdx.z];
+  partial += (size_t)grp * gsp;
+  out += (size_t)grp * gso;
   const int oo = threadIdx.x & 15, bsl = threadIdx.x >> 4;
   const int o = blockIdx.x * 16 + oo;
   double s0 = 0.0, s1 = 0.0;
@@ -532,16 +600,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(int nblk, int nout
 
 int dots_num_blocks(int nrows) { return (nrows + DOT_ROWS - 1) / DOT_ROWS; }
 
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const double* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                        int want_self, double* partial, size_t gsp, double* out, size_t gso) {
+  const int nblk = dots_num_blocks(nrows);
+  const int nout = (nvec + (want_self ? 1 : 0)) * m;
+  if (nout == 0 || gt.ng <= 0) return;
+  hipLaunchKernelGGL(cols_dots_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+                     DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, w,
+                     gsw, want_self, partial, gsp);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                     nblk, nout, partial, gsp, out, gso, 0);
+}
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
                       double* out) {
-  const int nblk = dots_num_blocks(nrows);
-  const int nout = (nvec + (want_self ? 1 : 0)) * m;
-  if (nout == 0) return;
-  hipLaunchKernelGGL(cols_dots_kernel, dim3(nblk), dim3(256), DOT_ROWS * m * sizeof(double), st,
-                     nrows, m, nvec, basis, vstride, w, want_self, partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16), dim3(256), 0, st, nblk, nout,
-                     partial, out, 0);
+  launch_cols_dots_b(st, single_group(), nrows, m, nvec, basis, vstride, 0, w, 0, want_self, partial,
+                     0, out, 0);
 }
 
 // Fused CGS2 middle step: for a chunk of DOT_ROWS rows
@@ -552,9 +627,15 @@ void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* 
 // L1/L2 -- which saves one launch and one pass over the Krylov basis per
 // iteration compared with separate update and dots kernels.
 __global__ __launch_bounds__(256) void cols_update_dots_kernel(
-    int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
-    const double* __restrict__ h, double* __restrict__ w, double* __restrict__ partial) {
+    GroupTab gt, int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    size_t gsb, const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
+    double* __restrict__ partial, size_t gsp) {
   extern __shared__ double wl[];  // DOT_ROWS x m
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
   const int r0 = blockIdx.x * DOT_ROWS;
   const int nr = min(DOT_ROWS, nrows - r0);
   const size_t base = (size_t)r0 * m;
@@ -590,24 +671,39 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
     partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
   }
 }
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const double* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso) {
+  if (gt.ng <= 0) return;
+  const int nblk = dots_num_blocks(nrows);
+  const int nout = (nvec + 1) * m;
+  hipLaunchKernelGGL(cols_update_dots_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+                     DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, h,
+                     gsh, w, gsw, partial, gsp);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                     nblk, nout, partial, gsp, out, gso, 0);
+}
 void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                              size_t vstride, const double* h, double* w, double* partial,
                              double* out) {
-  const int nblk = dots_num_blocks(nrows);
-  const int nout = (nvec + 1) * m;
-  hipLaunchKernelGGL(cols_update_dots_kernel, dim3(nblk), dim3(256),
-                     DOT_ROWS * m * sizeof(double), st, nrows, m, nvec, basis, vstride, h, w,
-                     partial);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16), dim3(256), 0, st, nblk, nout,
-                     partial, out, 0);
+  launch_cols_update_dots_b(st, single_group(), nrows, m, nvec, basis, vstride, 0, h, 0, w, 0,
+                            partial, 0, out, 0);
 }
 
 // out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
 // (scale may be NULL = 1; w may be NULL = 0).  Streams nvec panels once.
 __global__ __launch_bounds__(256) void cols_update_kernel(
-    size_t nelem, int m, int nvec, const double* __restrict__ basis, size_t vstride,
-    const double* __restrict__ h, double sign, const double* __restrict__ w,
-    const double* __restrict__ scale, double* __restrict__ out) {
+    GroupTab gt, size_t nelem, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    size_t gsb, const double* __restrict__ h, size_t gsh, double sign,
+    const double* __restrict__ w, size_t gsw, const double* __restrict__ scale,
+    double* __restrict__ out, size_t gso) {
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  if (w) w += (size_t)grp * gsw;
+  if (scale) scale += (size_t)grp * m;
+  out += (size_t)grp * gso;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nelem;
        e += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % m);
@@ -623,14 +719,21 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
     out[e] = v;
   }
 }
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const double* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso) {
+  size_t nelem = (size_t)nrows * m;
+  if (!nelem || gt.ng <= 0) return;
+  int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
+  hipLaunchKernelGGL(cols_update_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nelem, m, nvec,
+                     basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso);
+}
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
                         const double* scale, double* out) {
-  size_t nelem = (size_t)nrows * m;
-  if (!nelem) return;
-  int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
-  hipLaunchKernelGGL(cols_update_kernel, dim3(grid), dim3(256), 0, st, nelem, m, nvec, basis,
-                     vstride, h, sign, w, scale, out);
+  launch_cols_update_b(st, single_group(), nrows, m, nvec, basis, vstride, 0, h, 0, sign, w, 0, scale,
+                       out, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -647,11 +750,24 @@ void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double
 // the sequential rotation chain out of LDS instead of a chain of dependent
 // global loads.
 __global__ __launch_bounds__(64) void gmres_hess_kernel(
-    int m, int j, int restart, const double* __restrict__ h1, const double* __restrict__ h2,
-    double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
-    double* __restrict__ g, double* __restrict__ scale, double* __restrict__ resid,
-    const double* __restrict__ bnorm, double tol) {
+    GroupTab gt, int m, int j, int restart, const double* __restrict__ h1,
+    const double* __restrict__ h2, double* __restrict__ H, double* __restrict__ cs,
+    double* __restrict__ sn, double* __restrict__ g, double* __restrict__ scale,
+    double* __restrict__ resid, const double* __restrict__ bnorm, double tol) {
   extern __shared__ double sh[];       // hcol[restart+2], csl[restart], snl[restart]
+  {
+    // group-major state: every array holds one slab per group
+    const size_t grp = (size_t)gt.gid[blockIdx.z];
+    h1 += grp * (restart + 2) * m;
+    h2 += grp * (restart + 2) * m;
+    H += grp * m * (restart + 1) * restart;
+    cs += grp * m * restart;
+    sn += grp * m * restart;
+    g += grp * m * (restart + 1);
+    scale += grp * m;
+    resid += grp * m;
+    bnorm += grp * m;
+  }
   double* hcol = sh;
   double* csl = sh + restart + 2;
   double* snl = csl + restart;
@@ -709,18 +825,33 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
   scale[c] = (hnext > tiny) ? 1.0 / hnext : 0.0;
   resid[c] = (d > tiny) ? fabs(sj * gj) : 0.0;
 }
+void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
+                         const double* h1, const double* h2, double* H, double* cs, double* sn,
+                         double* g, double* scale, double* resid, const double* bnorm, double tol) {
+  if (gt.ng <= 0) return;
+  hipLaunchKernelGGL(gmres_hess_kernel, dim3(m, 1, gt.ng), dim3(64),
+                     (3 * restart + 4) * sizeof(double), st, gt, m, j, restart, h1, h2, H, cs, sn, g,
+                     scale, resid, bnorm, tol);
+}
 void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
                        const double* h2, double* H, double* cs, double* sn, double* g,
                        double* scale, double* resid, const double* bnorm, double tol) {
-  hipLaunchKernelGGL(gmres_hess_kernel, dim3(m), dim3(64), (3 * restart + 4) * sizeof(double), st,
-                     m, j, restart, h1, h2, H, cs, sn, g, scale, resid, bnorm, tol);
+  launch_gmres_hess_b(st, single_group(), m, j, restart, h1, h2, H, cs, sn, g, scale, resid, bnorm,
+                      tol);
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
-__global__ void gmres_backsolve_kernel(int m, int k, int restart, const double* __restrict__ H,
-                                       const double* __restrict__ g, double* __restrict__ y) {
+__global__ void gmres_backsolve_kernel(GroupTab gt, int m, int k, int restart,
+                                       const double* __restrict__ H, const double* __restrict__ g,
+                                       double* __restrict__ y) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
+  {
+    const size_t grp = (size_t)gt.gid[blockIdx.z];
+    H += grp * m * (restart + 1) * restart;
+    g += grp * m * (restart + 1);
+    y += grp * restart * m;
+  }
   const double* Hc = H + (size_t)c * (restart + 1) * restart;
   const double* gc = g + (size_t)c * (restart + 1);
   for (int i = k - 1; i >= 0; --i) {
@@ -729,18 +860,30 @@ __global__ void gmres_backsolve_kernel(int m, int k, int restart, const double* 
     y[i * m + c] = s / Hc[(size_t)i * (restart + 1) + i];
   }
 }
+void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, int k, int restart,
+                              const double* H, const double* g, double* y) {
+  if (gt.ng <= 0) return;
+  hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
+                     k, restart, H, g, y);
+}
 void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
                             const double* g, double* y) {
-  hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, k, restart,
-                     H, g, y);
+  launch_gmres_backsolve_b(st, single_group(), m, k, restart, H, g, y);
 }
 
 // start of a cycle: beta[c] = sqrt(nrm2[c]); g = [beta, 0...]; scale = 1/beta
-__global__ void gmres_start_kernel(int m, int restart, const double* __restrict__ nrm2,
-                                   double* __restrict__ g, double* __restrict__ scale,
-                                   double* __restrict__ resid) {
+__global__ void gmres_start_kernel(GroupTab gt, int m, int restart,
+                                   const double* __restrict__ nrm2, double* __restrict__ g,
+                                   double* __restrict__ scale, double* __restrict__ resid) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
+  {
+    const size_t grp = (size_t)gt.gid[blockIdx.z];
+    nrm2 += grp * m;
+    g += grp * m * (restart + 1);
+    scale += grp * m;
+    resid += grp * m;
+  }
   const double b = sqrt(fmax(nrm2[c], 0.0));
   double* gc = g + (size_t)c * (restart + 1);
   for (int i = 0; i <= restart; ++i) gc[i] = 0.0;
@@ -748,10 +891,15 @@ __global__ void gmres_start_kernel(int m, int restart, const double* __restrict_
   scale[c] = b > 1e-300 ? 1.0 / b : 0.0;
   resid[c] = b;
 }
+void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart,
+                          const double* nrm2, double* g, double* scale, double* resid) {
+  if (gt.ng <= 0) return;
+  hipLaunchKernelGGL(gmres_start_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
+                     restart, nrm2, g, scale, resid);
+}
 void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
                         double* scale, double* resid) {
-  hipLaunchKernelGGL(gmres_start_kernel, dim3((m + 63) / 64), dim3(64), 0, st, m, restart, nrm2, g,
-                     scale, resid);
+  launch_gmres_start_b(st, single_group(), m, restart, nrm2, g, scale, resid);
 }
 
 // ---------------------------------------------------------------------------
@@ -763,9 +911,13 @@ void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, 
 // ---------------------------------------------------------------------------
 template <int BS>
 __global__ __launch_bounds__(256) void block_apply_kernel(
-    int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
-    const double* __restrict__ inv, const double* __restrict__ in, int ldi,
-    double* __restrict__ out, int ldo, int m, int subtract) {
+    GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
+    GroupPtrs invs, const double* __restrict__ in, int ldi, size_t gsi,
+    double* __restrict__ out, int ldo, size_t gso, int m, int subtract) {
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ inv = invs.p[grp];
+  in += (size_t)grp * gsi;
+  out += (size_t)grp * gso;
   // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
   // inv[rows 16*ti.., k] * x[k, cols].  A-operand lane (r = l&15, q = l>>4)
   // holds inv[16*ti + r][k0 + 4q + s] for MFMA s of a 16-wide k chunk (one
@@ -814,25 +966,31 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
       }
   }
 }
+void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                          const int* rows, const GroupPtrs& inv, const double* in, int ldi,
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
+  if (nblocks <= 0 || gt.ng <= 0) return;
+  dim3 grid((nblocks + 3) / 4, 1, gt.ng), block(256);
+  switch (bs) {
+    case 16:
+      hipLaunchKernelGGL(block_apply_kernel<16>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
+                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      break;
+    case 32:
+      hipLaunchKernelGGL(block_apply_kernel<32>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
+                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      break;
+    default:
+      hipLaunchKernelGGL(block_apply_kernel<64>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
+                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      break;
+  }
+}
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
                         const double* inv, const double* in, int ldi, double* out, int ldo,
                         int m, int subtract) {
-  if (nblocks <= 0) return;
-  dim3 grid((nblocks + 3) / 4), block(256);
-  switch (bs) {
-    case 16:
-      hipLaunchKernelGGL(block_apply_kernel<16>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
-                         ldi, out, ldo, m, subtract);
-      break;
-    case 32:
-      hipLaunchKernelGGL(block_apply_kernel<32>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
-                         ldi, out, ldo, m, subtract);
-      break;
-    default:
-      hipLaunchKernelGGL(block_apply_kernel<64>, grid, block, 0, st, nblocks, bptr, rows, inv, in,
-                         ldi, out, ldo, m, subtract);
-      break;
-  }
+  launch_block_apply_b(st, single_group(), bs, nblocks, bptr, rows, same_ptr(inv), in, ldi, 0, out,
+                       ldo, 0, m, subtract);
 }
 
 // blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)
@@ -1049,11 +1207,15 @@ void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows
 // MFMA s; the k index of that MFMA's slot q is column j0+4q+s, so the B operand
 // is rc[j0+4q+s][c].  Partial tiles are summed through LDS.
 typedef double d4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(512) void dense_apply_kernel(int k, int m,
-                                                          const double* __restrict__ Einv,
+__global__ __launch_bounds__(512) void dense_apply_kernel(GroupTab gt, int k, int m,
+                                                          GroupPtrs Einvs,
                                                           const double* __restrict__ rc,
                                                           double* __restrict__ ec) {
   __shared__ double red[8][16][17];
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ Einv = Einvs.p[grp];
+  rc += (size_t)grp * k * m;
+  ec += (size_t)grp * k * m;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int i0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
@@ -1114,16 +1276,24 @@ __global__ __launch_bounds__(512) void dense_apply_kernel(int k, int m,
     if (i0 + rr < k && c0 + cc < m) ec[(size_t)(i0 + rr) * m + c0 + cc] = sum;
   }
 }
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
+                          const double* rc, double* ec) {
+  if (k <= 0 || gt.ng <= 0) return;
+  dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
+  hipLaunchKernelGGL(dense_apply_kernel, grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
+}
 void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
                         double* ec) {
-  if (k <= 0) return;
-  dim3 grid((k + 15) / 16, (m + 15) / 16);
-  hipLaunchKernelGGL(dense_apply_kernel, grid, dim3(512), 0, st, k, m, Einv, rc, ec);
+  launch_dense_apply_b(st, single_group(), k, m, same_ptr(Einv), rc, ec);
 }
 
 // z[r, :] += ec[aggof[r], :]
-__global__ void prolong_add_kernel(int nrows, int m, const int* __restrict__ aggof,
-                                   const double* __restrict__ ec, double* __restrict__ z) {
+__global__ void prolong_add_kernel(GroupTab gt, int nrows, int m, const int* __restrict__ aggof,
+                                   const double* __restrict__ ec, size_t gse,
+                                   double* __restrict__ z, size_t gsz) {
+  const int grp = gt.gid[blockIdx.z];
+  ec += (size_t)grp * gse;
+  z += (size_t)grp * gsz;
   size_t n = (size_t)nrows * m;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
        e += (size_t)gridDim.x * blockDim.x) {
@@ -1132,12 +1302,17 @@ __global__ void prolong_add_kernel(int nrows, int m, const int* __restrict__ agg
     z[e] += ec[(size_t)aggof[r] * m + c];
   }
 }
+void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
+                          const double* ec, size_t gse, double* z, size_t gsz) {
+  size_t n = (size_t)nrows * m;
+  if (!n || gt.ng <= 0) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(prolong_add_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nrows, m, aggof,
+                     ec, gse, z, gsz);
+}
 void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, const double* ec,
                         double* z) {
-  size_t n = (size_t)nrows * m;
-  if (!n) return;
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(prolong_add_kernel, dim3(grid), dim3(256), 0, st, nrows, m, aggof, ec, z);
+  launch_prolong_add_b(st, single_group(), nrows, m, aggof, ec, 0, z, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1151,17 +1326,24 @@ void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, cons
 // added with FP64 atomics (C must be zeroed by the caller).
 // ---------------------------------------------------------------------------
 template <int TI, int TJ>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GroupTab gt, int ptiles, int n, int p, int q,
                                                       const double* __restrict__ A, int lda,
                                                       const double* __restrict__ B, int ldb,
-                                                      double* __restrict__ C, int ldc,
-                                                      int rows_per_wave, int symmetric) {
+                                                      size_t gsB, double* __restrict__ C, int ldc,
+                                                      size_t gsC, int rows_per_wave, int symmetric) {
+  // batched form: blockIdx.y = (active group) * ptiles + (tile row); A is shared
+  const int by = blockIdx.y % ptiles;
+  {
+    const int grp = gt.gid[blockIdx.y / ptiles];
+    B += (size_t)grp * gsB;
+    C += (size_t)grp * gsC;
+  }
   // symmetric (A == B, Gram matrix): only tile blocks on / above the diagonal
   // are computed, the strictly upper ones are mirrored when written
-  if (symmetric && blockIdx.z < blockIdx.y) return;
+  if (symmetric && blockIdx.z < by) return;
   const int lane = threadIdx.x & 63;
   const int wave_in_blk = threadIdx.x >> 6;
-  const int i0 = blockIdx.y * 16 * TI;
+  const int i0 = by * 16 * TI;
   const int j0 = blockIdx.z * 16 * TJ;
   const int rbeg = (blockIdx.x * 4 + wave_in_blk) * rows_per_wave;
   const int rend = min(n, rbeg + rows_per_wave);   // empty range for surplus waves (they still join the barrier)
@@ -1204,7 +1386,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
           const int col = j0 + 16 * b + lc;
           if (rbeg < n && row < p && col < q) {
             atomicAdd(&C[(size_t)row * ldc + col], acc[a][b][e]);
-            if (symmetric && blockIdx.z > blockIdx.y)
+            if (symmetric && blockIdx.z > by)
               atomicAdd(&C[(size_t)col * ldc + row], acc[a][b][e]);
           }
         }
@@ -1234,15 +1416,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(int n, int p, int q,
           const int col = j0 + 16 * b + lc;
           if (row < p && col < q) {
             atomicAdd(&C[(size_t)row * ldc + col], v);
-            if (symmetric && blockIdx.z > blockIdx.y) atomicAdd(&C[(size_t)col * ldc + row], v);
+            if (symmetric && blockIdx.z > by) atomicAdd(&C[(size_t)col * ldc + row], v);
           }
         }
   }
 }
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc) {
-  if (n <= 0 || p <= 0 || q <= 0) return;
-  const int symmetric = (A == B && lda == ldb && p == q) ? 1 : 0;
+  launch_gemm_tn_b(st, single_group(), n, p, q, A, lda, B, ldb, 0, C, ldc, 0);
+}
+void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
+                      int lda, const double* B, int ldb, size_t gsB, double* C, int ldc, size_t gsC) {
+  if (n <= 0 || p <= 0 || q <= 0 || gt.ng <= 0) return;
+  const int symmetric = (gt.ng == 1 && A == B && lda == ldb && p == q) ? 1 : 0;
   // wide products: 64 x 64 output per wave (16 MFMAs per 8 loaded operands);
   // thin ones (low-rank term, gain): 32 x 32
   const bool wide = p >= 128 && q >= 128;
@@ -1255,27 +1441,32 @@ void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int ld
   const int min_rows = wide ? 256 : 64;
   const int target_waves = wide ? 1536 : 8192;
   int slices = std::max(1, std::min((n + min_rows - 1) / min_rows,
-                                    std::max(1, target_waves / std::max(1, tiles))));
+                                    std::max(1, target_waves / std::max(1, tiles * gt.ng))));
   int rows_per_wave = (n + slices - 1) / slices;
   rows_per_wave = (rows_per_wave + 3) & ~3;
   slices = (n + rows_per_wave - 1) / rows_per_wave;
-  dim3 grid((slices + 3) / 4, (p + tp - 1) / tp, (q + tp - 1) / tp), block(256);
+  dim3 grid((slices + 3) / 4, tp_ * gt.ng, tq_), block(256);
   if (wide)
-    hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
-                       rows_per_wave, symmetric);
+    hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, gt, tp_, n, p, q, A, lda, B, ldb,
+                       gsB, C, ldc, gsC, rows_per_wave, symmetric);
   else
-    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, n, p, q, A, lda, B, ldb, C, ldc,
-                       rows_per_wave, symmetric);
+    hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, gt, tp_, n, p, q, A, lda, B, ldb,
+                       gsB, C, ldc, gsC, rows_per_wave, symmetric);
 }
 
 // gemm_nn:  Y (n x q) = alpha * A (n x p) * C (p x q) + beta * Y.
 // A wave owns 16 rows x (16*TJ) columns.  A-operand: A[r0 + (l&15)][k + (l>>4)].
 template <int TJ>
-__global__ __launch_bounds__(256) void gemm_nn_kernel(int n, int p, int q,
+__global__ __launch_bounds__(256) void gemm_nn_kernel(GroupTab gt, int n, int p, int q,
                                                       const double* __restrict__ A, int lda,
                                                       const double* __restrict__ C, int ldc,
-                                                      double* __restrict__ Y, int ldy,
-                                                      double alpha, double beta) {
+                                                      size_t gsC, double* __restrict__ Y, int ldy,
+                                                      size_t gsY, double alpha, double beta) {
+  {
+    const int grp = gt.gid[blockIdx.z];
+    C += (size_t)grp * gsC;
+    Y += (size_t)grp * gsY;
+  }
   const int lane = threadIdx.x & 63;
   const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   const int j0 = blockIdx.y * 16 * TJ;
@@ -1308,12 +1499,17 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(int n, int p, int q,
       }
     }
 }
+void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
+                      int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
+                      double alpha, double beta) {
+  if (n <= 0 || q <= 0 || gt.ng <= 0) return;
+  dim3 grid((n + 63) / 64, (q + 31) / 32, gt.ng), block(256);
+  hipLaunchKernelGGL((gemm_nn_kernel<2>), grid, block, 0, st, gt, n, p, q, A, lda, C, ldc, gsC, Y,
+                     ldy, gsY, alpha, beta);
+}
 void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
                     int ldc, double* Y, int ldy, double alpha, double beta) {
-  if (n <= 0 || q <= 0) return;
-  dim3 grid((n + 63) / 64, (q + 31) / 32), block(256);
-  hipLaunchKernelGGL((gemm_nn_kernel<2>), grid, block, 0, st, n, p, q, A, lda, C, ldc, Y, ldy,
-                     alpha, beta);
+  launch_gemm_nn_b(st, single_group(), n, p, q, A, lda, C, ldc, 0, Y, ldy, 0, alpha, beta);
 }
 
 // ---------------------------------------------------------------------------

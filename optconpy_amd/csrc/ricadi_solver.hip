@@ -69,16 +69,7 @@ struct DArr {
 struct ShiftData {
   double alpha = 0, beta = 0;
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
-  DArr<double> sval, svalb, dinv, bvinv, bpinv, einv;
-  // hipGraph of one GMRES iteration body, keyed by (panel width, Arnoldi step, low-rank width);
-  // valid for one workspace epoch of the owning context
-  long epoch = -1;
-  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
-  void drop_graphs() {
-    for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
-    graphs.clear();
-  }
-  ~ShiftData() { drop_graphs(); }
+  DArr<double> sval, svalb, bvinv, bpinv, einv;
 };
 
 struct DevCsr {
@@ -113,7 +104,6 @@ struct ricadi_ctx {
   DArr<double> dA, dE;
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
   DArr<double> bvA, bvE, jd_val;
-  bool simple_diag = false;   // RICADI_SIMPLE_DIAG=1: diagonal (classical) SIMPLE instead of the consistent one
   DArr<int> agg_ptr, agg_rows, aggof;
   DArr<double> E0, EM, EJ, ones;
   // LDS-tiled SpMM structure
@@ -123,22 +113,22 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx;
   // low rank
   int q = 0;
-  DArr<double> U, V, lrc, scratch;   // lrc is captured in the iteration graphs: never reallocate it elsewhere
+  DArr<double> U, V, lrc, scratch;
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
-  int wm = 0, wrestart = 0;
+  int wcols = 0, wrestart = 0;   // total columns (width x groups) and restart length the workspace holds
   DArr<double> basis, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
-  double* h_resid = nullptr;  // pinned: [0,M) bnorm scratch, then two residual slots
+  DArr<double*> eptrs;
+  double* h_resid = nullptr;  // pinned, 4 slots of MAX_GROUPS*MAX_M: norms, rhs norms, two residual slots
   hipEvent_t ev_res[2] = {nullptr, nullptr};
   // factor
   DArr<double> Z;
   int zc = 0, zld = 0;
   // stats
   long total_iters = 0, total_solves = 0;
-  long work_epoch = 0;   // bumped whenever a buffer captured in the iteration graphs is reallocated
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
@@ -151,11 +141,15 @@ struct ricadi_ctx {
 
 namespace ricadi {
 
-static void ensure_work(ricadi_ctx* c, int m) {
+// Workspace for batches of up to `groups` panels of width m (group-major: every
+// buffer holds one slab per group; basis is vector-major, i.e. Krylov vector j of
+// all groups is contiguous).
+static void ensure_work(ricadi_ctx* c, int m, int groups = 1) {
   const int restart = c->opts.gmres_restart;
-  if (m <= c->wm && restart == c->wrestart) return;
-  const int mm = std::max(m, c->wm);
-  const size_t nm = (size_t)c->n * mm;
+  // every buffer scales with the total number of columns m * groups
+  if (m * groups <= c->wcols && restart == c->wrestart) return;
+  const size_t gm = (size_t)std::max(m * groups, c->wcols);
+  const size_t nm = (size_t)c->n * gm;
   c->basis.alloc((size_t)(restart + 1) * nm);
   c->wv.alloc(nm);
   c->zv.alloc(nm);
@@ -164,297 +158,433 @@ static void ensure_work(ricadi_ctx* c, int m) {
   c->bvec.alloc(nm);
   c->pw1.alloc(nm);
   c->pw2.alloc(nm);
-  c->tp.alloc((size_t)std::max(c->np, 1) * mm);
-  c->rc.alloc((size_t)std::max(c->kc, 1) * mm);
-  c->ec.alloc((size_t)std::max(c->kc, 1) * mm);
-  c->partial.alloc((size_t)dots_num_blocks(c->n) * (restart + 2) * mm);
-  c->h1.alloc((size_t)(restart + 2) * mm);
-  c->h2.alloc((size_t)(restart + 2) * mm);
-  c->H.alloc((size_t)mm * (restart + 1) * restart);
-  c->cs.alloc((size_t)mm * restart);
-  c->sn.alloc((size_t)mm * restart);
-  c->g.alloc((size_t)mm * (restart + 1));
-  c->scale.alloc(mm);
-  c->resid.alloc(mm);
-  c->yv.alloc((size_t)restart * mm);
-  c->bnorm2.alloc(mm);
-  c->nrm2.alloc(mm);
-  c->lrc.alloc((size_t)64 * mm + 64);
+  c->tp.alloc((size_t)std::max(c->np, 1) * gm);
+  c->rc.alloc((size_t)std::max(c->kc, 1) * gm);
+  c->ec.alloc((size_t)std::max(c->kc, 1) * gm);
+  c->partial.alloc((size_t)dots_num_blocks(c->n) * (restart + 2) * gm);
+  c->h1.alloc((size_t)(restart + 2) * gm);
+  c->h2.alloc((size_t)(restart + 2) * gm);
+  c->H.alloc(gm * (restart + 1) * restart);
+  c->cs.alloc(gm * restart);
+  c->sn.alloc(gm * restart);
+  c->g.alloc(gm * (restart + 1));
+  c->scale.alloc(gm);
+  c->resid.alloc(gm);
+  c->yv.alloc((size_t)restart * gm);
+  c->bnorm2.alloc(gm);
+  c->nrm2.alloc(gm);
+  c->lrc.alloc((size_t)64 * gm + 64);
   if (!c->h_resid) {
-    HIPCHK(hipHostMalloc((void**)&c->h_resid, sizeof(double) * 4 * RICADI_MAX_M));
+    HIPCHK(hipHostMalloc((void**)&c->h_resid,
+                         sizeof(double) * 4 * RICADI_MAX_M * RICADI_MAX_GROUPS));
     for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_res[i], hipEventDisableTiming));
   }
-  c->wm = mm;
+  c->wcols = (int)gm;
   c->wrestart = restart;
-  ++c->work_epoch;
 }
 
 // ---- per-shift setup ---------------------------------------------------------
 template <class T>
 static void stable_alloc(DArr<T>& a, size_t n) {
-  if (a.n != n) a.alloc(n);   // same size: keep the pointer (it is baked into captured graphs)
+  if (a.n != n) a.alloc(n);
 }
 
-static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
-  auto key = std::make_pair(alpha, beta);
-  auto it = c->cache.find(key);
-  if (it != c->cache.end() && it->second->valid) return it->second.get();
-  if (it == c->cache.end()) it = c->cache.emplace(key, std::unique_ptr<ShiftData>(new ShiftData)).first;
-  ShiftData* sd = it->second.get();
-  sd->alpha = alpha;
-  sd->beta = beta;
+// Per-shift data for the given (alpha, beta) pairs; whatever is missing is built for
+// all of them together: the element-wise / block kernels per shift, the dense coarse
+// inverses in ONE batched rocSOLVER factorisation + inversion (its many small
+// panel kernels then serve all shifts of a sweep per launch instead of one).
+static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas, int ng,
+                       ShiftData** out) {
   hipStream_t st = c->st;
-  stable_alloc(sd->sval, c->snnz);
-  launch_assemble_shift(st, (int)c->snnz, c->srcA.p, c->srcE.p, c->srcJ.p, alpha, beta,
-                        sd->sval.p);
-  if (c->sb_ok) {
-    stable_alloc(sd->svalb, c->snnz);
-    launch_gather_vals(st, (int)c->snnz, c->sb_perm.p, sd->sval.p, sd->svalb.p);
+  std::vector<ShiftData*> todo;
+  for (int g = 0; g < ng; ++g) {
+    auto key = std::make_pair(alphas[g], betas[g]);
+    auto it = c->cache.find(key);
+    if (it == c->cache.end()) it = c->cache.emplace(key, std::unique_ptr<ShiftData>(new ShiftData)).first;
+    ShiftData* sd = it->second.get();
+    out[g] = sd;
+    if (sd->valid || std::find(todo.begin(), todo.end(), sd) != todo.end()) continue;
+    sd->alpha = alphas[g];
+    sd->beta = betas[g];
+    todo.push_back(sd);
   }
-  stable_alloc(sd->dinv, (size_t)c->nv);
-  launch_diag_inv(st, c->nv, c->dA.p, c->dE.p, alpha, beta, sd->dinv.p);
+  if (todo.empty()) return;
   HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
   const size_t bsz = (size_t)c->bs * c->bs;
-  stable_alloc(sd->bvinv, (size_t)c->nbv * bsz);
-  launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
-  launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
-  if (c->nbp > 0) {
-    stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
-    if (c->simple_diag)
-      launch_schur_blocks(st, c->nbp, c->bs, c->bp_ptr.p, c->bp_rows.p, c->J.rp.p, c->J.ci.p,
-                          c->J.v.p, sd->dinv.p, sd->bpinv.p);
-    else
+  const int k = c->kc;
+  for (ShiftData* sd : todo) {
+    const double alpha = sd->alpha, beta = sd->beta;
+    stable_alloc(sd->sval, c->snnz);
+    launch_assemble_shift(st, (int)c->snnz, c->srcA.p, c->srcE.p, c->srcJ.p, alpha, beta,
+                          sd->sval.p);
+    if (c->sb_ok) {
+      stable_alloc(sd->svalb, c->snnz);
+      launch_gather_vals(st, (int)c->snnz, c->sb_perm.p, sd->sval.p, sd->svalb.p);
+    }
+    stable_alloc(sd->bvinv, (size_t)c->nbv * bsz);
+    launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
+    launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
+    if (c->nbp > 0) {
+      stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
       launch_schur_blocks_bj(st, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p, c->jd_val.p,
                              sd->bvinv.p, sd->bpinv.p);
-    launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
+      launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
+    }
+    if (k > 0) {
+      stable_alloc(sd->einv, (size_t)k * k);
+      launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
+    }
   }
-  if (c->kc > 0) {
-    const int k = c->kc;
-    stable_alloc(sd->einv, (size_t)k * k);
-    launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
-    c->ipiv.ensure(k);
+  const int nb = (int)todo.size();
+  std::vector<int> info(nb, 0);
+  if (k > 0) {
     // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
-    RBCHK(rocsolver_dgetrf(c->rb, k, k, sd->einv.p, k, c->ipiv.p, c->info.p));
-    int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, c->info.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (info != 0) throw HipError{"coarse matrix singular (dgetrf info " + std::to_string(info) + ")"};
-    RBCHK(rocsolver_dgetri(c->rb, k, sd->einv.p, k, c->ipiv.p, c->info.p));
+    c->ipiv.ensure((size_t)k * nb);
+    c->info.ensure(nb);
+    if (nb == 1) {
+      RBCHK(rocsolver_dgetrf(c->rb, k, k, todo[0]->einv.p, k, c->ipiv.p, c->info.p));
+      RBCHK(rocsolver_dgetri(c->rb, k, todo[0]->einv.p, k, c->ipiv.p, c->info.p));
+    } else {
+      std::vector<double*> hp(nb);
+      for (int i = 0; i < nb; ++i) hp[i] = todo[i]->einv.p;
+      c->eptrs.ensure(nb);
+      HIPCHK(hipMemcpyAsync(c->eptrs.p, hp.data(), sizeof(double*) * nb, hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));   // hp is a stack object
+      RBCHK(rocsolver_dgetrf_batched(c->rb, k, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
+      RBCHK(rocsolver_dgetri_batched(c->rb, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
+    }
+    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
   }
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  for (int i = 0; i < nb; ++i)
+    if (info[i] != 0)
+      throw HipError{"coarse matrix singular (getrf/getri info " + std::to_string(info[i]) + ")"};
   if (flag) throw HipError{"singular block-Jacobi block"};
-  sd->valid = true;
+  for (ShiftData* sd : todo) sd->valid = true;
+}
+
+static ShiftData* get_shift(ricadi_ctx* c, double alpha, double beta) {
+  ShiftData* sd = nullptr;
+  get_shifts(c, &alpha, &beta, 1, &sd);
   return sd;
 }
+
+// ---- batches -----------------------------------------------------------------------
+// The shifts of one batched solve: per group id the shift-dependent operands, and
+// the table of groups a launch works on (ricadi_internal.h).  All workspace
+// buffers are group-major with the strides below.
+struct Batch {
+  int G = 0;                 // groups in the solve (ids 0 .. G-1)
+  int m = 0;                 // panel width of every group
+  GroupTab tab;              // groups the next launches act on
+  GroupPtrs sval, svalb, bvinv, bpinv, einv;
+  size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
+
+  void all() {
+    tab.ng = G;
+    for (int g = 0; g < G; ++g) tab.gid[g] = g;
+  }
+  void only(int g) {
+    tab.ng = 1;
+    tab.gid[0] = g;
+  }
+  void set(const std::vector<int>& ids) {
+    tab.ng = (int)ids.size();
+    for (int i = 0; i < tab.ng; ++i) tab.gid[i] = ids[i];
+  }
+};
+
+static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
+  Batch bt;
+  bt.G = G;
+  bt.m = m;
+  bt.tab = GroupTab{};
+  bt.sval = bt.svalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr(nullptr);
+  for (int g = 0; g < G; ++g) {
+    bt.sval.p[g] = sds[g]->sval.p;
+    bt.svalb.p[g] = sds[g]->svalb.p;
+    bt.bvinv.p[g] = sds[g]->bvinv.p;
+    bt.bpinv.p[g] = sds[g]->bpinv.p;
+    bt.einv.p[g] = sds[g]->einv.p;
+  }
+  bt.gs = (size_t)c->n * m;
+  bt.gsp = (size_t)c->np * m;
+  bt.gsc = (size_t)c->kc * m;
+  bt.gsq = (size_t)std::max(c->q, 1) * m;
+  bt.all();
+  return bt;
+}
+static Batch make_batch(ricadi_ctx* c, ShiftData* sd, int m) { return make_batch(c, &sd, 1, m); }
 
 // ---- operator and preconditioner on device panels ---------------------------------
 // y = beta_r * r + alpha * S x on the saddle operator (optionally through the
 // prolongation map): LDS-tiled kernel when the block tiles fit, else the CSR one.
-static void saddle_spmm(ricadi_ctx* c, const ShiftData* sd, const double* x, const int* xmap,
-                        double* y, const double* r, double alpha, double beta_r, int m) {
+// gsx / gsy / gsr: group strides of x, y, r.
+static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx,
+                        const int* xmap, double* y, size_t gsy, const double* r, size_t gsr,
+                        double alpha, double beta_r) {
   static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
+  const int m = bt.m;
   const bool fits =
       c->sb_ok && !force_csr &&
       spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
   if (fits)
-    launch_spmm_blocked(c->st, c->sb_nblk, c->sb_rowptr.p, c->sb_rows.p, c->sb_rp.p, c->sb_cptr.p,
-                        c->sb_cols.p, c->sb_lidx.p, sd->svalb.p, x, m, xmap, y, m, r, m, alpha,
-                        beta_r, m, c->sb_max_cols, c->sb_max_nnz);
+    launch_spmm_blocked_b(c->st, bt.tab, c->sb_nblk, c->sb_rowptr.p, c->sb_rows.p, c->sb_rp.p,
+                          c->sb_cptr.p, c->sb_cols.p, c->sb_lidx.p, bt.svalb, x, m, gsx, xmap, y, m,
+                          gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, c->sb_max_nnz);
   else
-    launch_spmm(c->st, c->n, c->s_rp.p, c->s_ci.p, sd->sval.p, x, m, xmap, y, m, r, m, alpha,
-                beta_r, nullptr, m);
+    launch_spmm_b(c->st, bt.tab, c->n, c->s_rp.p, c->s_ci.p, bt.sval, x, m, gsx, xmap, y, m, gsy, r,
+                  m, gsr, alpha, beta_r, m);
 }
 
-// y = S(alpha,beta) x   (n x m panels, ld = m); optional low-rank  - U V^T x_v
-static void op_apply(ricadi_ctx* c, const ShiftData* sd, const double* x, double* y, int m,
+// y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
+// bt.gs); optional low-rank  - U V^T x_v  (U, V shared by the groups)
+static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx, double* y,
                      bool lowrank) {
   hipStream_t st = c->st;
-  saddle_spmm(c, sd, x, nullptr, y, nullptr, 1.0, 0.0, m);
+  const int m = bt.m;
+  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0);
   if (lowrank && c->q > 0) {
-    HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * c->q * m, st));
-    launch_gemm_tn(st, c->nv, c->q, m, c->V.p, c->q, x, m, c->lrc.p, m);
-    launch_gemm_nn(st, c->nv, c->q, m, c->U.p, c->q, c->lrc.p, m, y, m, -1.0, 1.0);
+    HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * bt.gsq * bt.G, st));
+    launch_gemm_tn_b(st, bt.tab, c->nv, c->q, m, c->V.p, c->q, x, m, gsx, c->lrc.p, m, bt.gsq);
+    launch_gemm_nn_b(st, bt.tab, c->nv, c->q, m, c->U.p, c->q, c->lrc.p, m, bt.gsq, y, m, bt.gs, -1.0,
+                     1.0);
   }
 }
 
-// z = P^-1 r : multiplicative two-level, coarse correction first, then one
-// SIMPLE-type block-Jacobi sweep on the updated residual.
-static void precond_apply(ricadi_ctx* c, const ShiftData* sd, const double* r, double* z, int m) {
+// z = P^-1 r for every active group: multiplicative two-level, coarse correction
+// first, then one consistent SIMPLE block-Jacobi sweep on the updated residual.
+// r has group stride gsr; z lives in a workspace buffer (stride bt.gs).
+static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z) {
   hipStream_t st = c->st;
-  const int nv = c->nv, np = c->np;
+  const int nv = c->nv, np = c->np, m = bt.m;
+  const GroupTab& gt = bt.tab;
+  const GroupPtrs ones = same_ptr(c->ones.p), jv = same_ptr(c->J.v.p), jtv = same_ptr(c->JT.v.p);
   const double* rr = r;
+  size_t gsrr = gsr;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
-    launch_spmm(st, c->kc, c->agg_ptr.p, c->agg_rows.p, c->ones.p, r, m, nullptr, c->rc.p, m, nullptr,
-                0, 1.0, 0.0, nullptr, m);
-    launch_dense_apply(st, c->kc, m, sd->einv.p, c->rc.p, c->ec.p);
+    launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
+                  bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
+    launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
     // r2 = r - S * (Y ec), prolongation folded into the gather
-    saddle_spmm(c, sd, c->ec.p, c->aggof.p, c->r2.p, r, -1.0, 1.0, m);
+    saddle_spmm(c, bt, c->ec.p, bt.gsc, c->aggof.p, c->r2.p, bt.gs, r, gsr, -1.0, 1.0);
     rr = c->r2.p;
+    gsrr = bt.gs;
   }
-  launch_block_apply(st, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, sd->bvinv.p, rr, m, z, m, m);
+  launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, rr, m, gsrr, z, m,
+                       bt.gs, m, 0);
   if (np > 0) {
     // t = J z_v - r_p
-    launch_spmm(st, np, c->J.rp.p, c->J.ci.p, c->J.v.p, z, m, nullptr, c->tp.p, m,
-                rr + (size_t)nv * m, m, 1.0, -1.0, nullptr, m);
+    launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
+                  rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
-    launch_block_apply(st, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, sd->bpinv.p, c->tp.p, m, zp,
-                       m, m);
-    if (c->simple_diag) {
-      // z_v -= Dinv * J^T z_p
-      launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, z, m, z, m, -1.0, 1.0,
-                  sd->dinv.p, m);
-    } else {
-      // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks
-      double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
-      launch_spmm(st, nv, c->JT.rp.p, c->JT.ci.p, c->JT.v.p, zp, m, nullptr, tmp, m, nullptr, 0, 1.0,
-                  0.0, nullptr, m);
-      launch_block_apply(st, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, sd->bvinv.p, tmp, m, z, m, m, 1);
-    }
+    launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->tp.p, m,
+                         bt.gsp, zp, m, bt.gs, m, 0);
+    // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks
+    double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
+    launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
+                  nullptr, 0, 0, 1.0, 0.0, m);
+    launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, tmp, m, bt.gs, z,
+                         m, bt.gs, m, 1);
   }
-  if (c->kc > 0) launch_prolong_add(st, c->n, m, c->aggof.p, c->ec.p, z);
+  if (c->kc > 0) launch_prolong_add_b(st, gt, c->n, m, c->aggof.p, c->ec.p, bt.gsc, z, bt.gs);
+}
+
+static void op_apply(ricadi_ctx* c, ShiftData* sd, const double* x, double* y, int m, bool lowrank) {
+  const Batch bt = make_batch(c, sd, m);
+  op_apply(c, bt, x, bt.gs, y, lowrank);
+}
+static void precond_apply(ricadi_ctx* c, ShiftData* sd, const double* r, double* z, int m) {
+  const Batch bt = make_batch(c, sd, m);
+  precond_apply(c, bt, r, bt.gs, z);
 }
 
 static void col_norms2(ricadi_ctx* c, const double* w, int nrows, int m, double* out) {
   launch_cols_dots(c->st, nrows, m, 0, nullptr, 0, w, 1, c->partial.p, out);
 }
 
-// ---- panel GMRES ------------------------------------------------------------------
-// Solves S x = b for the m columns of the n x m panel b (device), x (device) is
-// overwritten.  Right preconditioning, CGS2, per-column Givens QR.
+// ---- batched panel GMRES --------------------------------------------------------------
+// Solves S(shift_g) x_g = b_g for the m columns of every group's n x m panel:
+// one Arnoldi process per column, all groups in lockstep inside ONE sequence of
+// launches (grid.z = active groups).  At n ~ 3e4 a single panel leaves most of
+// the chip idle and the launch path dominates; batching the shifts of a sweep
+// fills it.  Right preconditioning, CGS2, per-column Givens QR.  A group whose
+// columns have all converged leaves the active table; its correction is formed
+// at the end of the restart cycle from the basis vectors it had by then.
+//   b: group stride gsb (0 = one right-hand side shared by all groups);
+//   x: group stride n*m, overwritten.
 struct GmresResult {
   int iters = 0;
   bool converged = false;
   double max_relres = 0.0;
 };
 
-static GmresResult gmres_solve(ricadi_ctx* c, ShiftData* sd, const double* b, double* x,
-                               int m, bool lowrank, double* relres_host) {
-  ensure_work(c, m);
+static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
+                              size_t gsb, double* x, int m, bool lowrank, double* relres_host,
+                              GmresResult* res) {
+  ensure_work(c, m, G);
   hipStream_t st = c->st;
   const int n = c->n, restart = c->opts.gmres_restart, maxit = c->opts.gmres_maxit;
   const double tol = c->opts.gmres_tol;
-  const size_t nm = (size_t)n * m;
+  Batch bt = make_batch(c, sds, G, m);
+  const size_t nm = bt.gs;             // one panel
+  const size_t vs = nm * G;            // one Krylov vector of all groups
+  const size_t gsh = (size_t)(restart + 2) * m;
+  const size_t gspart = (size_t)dots_num_blocks(n) * (restart + 2) * m;
+  const int GM = G * m;
   double* V = c->basis.p;
-  double* hb = c->h_resid;            // [0..m) resid, [m..2m) bnorm
-  GmresResult res;
+  double* hb = c->h_resid;
+  const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
+  for (int g = 0; g < G; ++g) res[g] = GmresResult();
 
-  col_norms2(c, b, n, m, c->bnorm2.p);
-  HIPCHK(hipMemcpyAsync(hb + m, c->bnorm2.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+  auto norms2 = [&](const double* w, size_t gsw, double* out) {
+    launch_cols_dots_b(st, bt.tab, n, m, 0, nullptr, 0, 0, w, gsw, 1, c->partial.p, gspart, out,
+                       (size_t)m);
+  };
+  bt.all();
+  norms2(b, gsb, c->bnorm2.p);
+  HIPCHK(hipMemcpyAsync(hb + slot, c->bnorm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  std::vector<double> bn(m);
-  for (int j = 0; j < m; ++j) bn[j] = std::sqrt(std::max(hb[m + j], 0.0));
+  std::vector<double> bn(GM);
+  for (int j = 0; j < GM; ++j) bn[j] = std::sqrt(std::max(hb[slot + j], 0.0));
   // device copy of the norms (not squared) for the hess kernel
-  HIPCHK(hipMemcpyAsync(c->bnorm2.p, bn.data(), sizeof(double) * m, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * nm, st));
+  HIPCHK(hipMemcpyAsync(c->bnorm2.p, bn.data(), sizeof(double) * GM, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * vs, st));
 
-  auto all_converged = [&](const double* r) {
+  auto group_converged = [&](const double* r, int g) {
     double worst = 0.0;
     bool ok = true;
-    for (int j = 0; j < m; ++j) {
+    for (int j = g * m; j < (g + 1) * m; ++j) {
       const double rel = bn[j] > 0.0 ? r[j] / bn[j] : 0.0;
       worst = std::max(worst, rel);
       if (!(r[j] <= tol * bn[j])) ok = false;
     }
-    res.max_relres = worst;
+    res[g].max_relres = worst;
     return ok;
   };
 
+  std::vector<char> done(G, 0);
+  std::vector<int> act, live, kk(G, 0);
+  for (int g = 0; g < G; ++g) act.push_back(g);
   bool first = true;
-  while (true) {
-    // residual of the current iterate
+  // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
+  // iteration: three passes over it) small; a cycle that gains less than a factor 10
+  // on some column lengthens the following ones, up to gmres_restart.
+  int cyc = std::min(restart, 12);
+  std::vector<double> rstart(GM, 0.0);
+  while (!act.empty()) {
+    bt.set(act);
+    // residual of the current iterates
     if (first) {
-      HIPCHK(hipMemcpyAsync(c->wv.p, b, sizeof(double) * nm, hipMemcpyDeviceToDevice, st));
+      if (gsb == nm) {
+        HIPCHK(hipMemcpyAsync(c->wv.p, b, sizeof(double) * vs, hipMemcpyDeviceToDevice, st));
+      } else {
+        for (int g = 0; g < G; ++g)
+          HIPCHK(hipMemcpyAsync(c->wv.p + (size_t)g * nm, b + (size_t)g * gsb, sizeof(double) * nm,
+                                hipMemcpyDeviceToDevice, st));
+      }
     } else {
-      op_apply(c, sd, x, c->wv.p, m, lowrank);
-      launch_axpby(st, nm, 1.0, b, -1.0, c->wv.p);
+      op_apply(c, bt, x, nm, c->wv.p, lowrank);
+      launch_axpby_b(st, bt.tab, nm, 1.0, b, gsb, -1.0, c->wv.p, nm);
     }
     first = false;
-    col_norms2(c, c->wv.p, n, m, c->nrm2.p);
-    launch_gmres_start(st, m, restart, c->nrm2.p, c->g.p, c->scale.p, c->resid.p);
-    HIPCHK(hipMemcpyAsync(hb, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    norms2(c->wv.p, nm, c->nrm2.p);
+    launch_gmres_start_b(st, bt.tab, m, restart, c->nrm2.p, c->g.p, c->scale.p, c->resid.p);
+    HIPCHK(hipMemcpyAsync(hb, c->resid.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (all_converged(hb)) { res.converged = true; break; }
-    if (res.iters >= maxit) break;
-    launch_colscale(st, n, m, c->scale.p, c->wv.p, 0.0, V);
-    int k = 0;
-    for (int j = 0; j < restart; ++j) {
-      // One iteration body = ~15 dependent launches.  With RICADI_GRAPH=1 it is
-      // captured once per (shift, panel width, step j, low-rank width) into a
-      // hipGraph and replayed with a single call.  Measured (cfg2, 8 streams):
-      // 94.6 vs 97.2 shift-solves/s without -- no gain, the kernels themselves
-      // (each fills the chip with latency-bound waves) are the limit, not the host
-      // launch path -- so direct launches stay the default.
-      auto body = [&]() {
-        const double* vj = V + (size_t)j * nm;
-        precond_apply(c, sd, vj, c->zv.p, m);
-        op_apply(c, sd, c->zv.p, c->wv.p, m, lowrank);
-        launch_cols_dots(st, n, m, j + 1, V, nm, c->wv.p, 0, c->partial.p, c->h1.p);
-        // first update fused with the dot products of the second pass
-        launch_cols_update_dots(st, n, m, j + 1, V, nm, c->h1.p, c->wv.p, c->partial.p, c->h2.p);
-        launch_gmres_hess(st, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p, c->g.p,
-                          c->scale.p, c->resid.p, c->bnorm2.p, tol);
-        launch_cols_update(st, n, m, j + 1, V, nm, c->h2.p, -1.0, c->wv.p, c->scale.p,
-                           V + (size_t)(j + 1) * nm);
-      };
-      static const bool use_graph = getenv("RICADI_GRAPH") != nullptr;
-      if (use_graph) {
-        if (sd->epoch != c->work_epoch) {
-          sd->drop_graphs();
-          sd->epoch = c->work_epoch;
-        }
-        const auto gkey = std::make_tuple(m, j, (lowrank && c->q > 0) ? c->q : 0);
-        auto git = sd->graphs.find(gkey);
-        if (git == sd->graphs.end()) {
-          hipGraph_t gr = nullptr;
-          hipGraphExec_t ex = nullptr;
-          HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-          body();
-          HIPCHK(hipStreamEndCapture(st, &gr));
-          HIPCHK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
-          (void)hipGraphDestroy(gr);
-          git = sd->graphs.emplace(gkey, ex).first;
-        }
-        HIPCHK(hipGraphLaunch(git->second, st));
+    std::vector<int> next;
+    bool slow = false;
+    for (int g : act) {
+      if (group_converged(hb, g)) {
+        res[g].converged = true;
+        done[g] = 1;
+      } else if (res[g].iters >= maxit) {
+        done[g] = 1;
       } else {
-        body();
+        next.push_back(g);
+        for (int j = g * m; j < (g + 1) * m; ++j) {
+          if (rstart[j] > 0.0 && hb[j] > tol * bn[j] && hb[j] > 0.1 * rstart[j]) slow = true;
+          rstart[j] = hb[j];
+        }
       }
+    }
+    if (slow) cyc = std::min(restart, cyc + (cyc + 1) / 2);
+    act.swap(next);
+    if (act.empty()) break;
+    bt.set(act);
+    launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
+    live = act;
+    for (int g : act) kk[g] = 0;
+    for (int j = 0; j < cyc && !live.empty(); ++j) {
+      bt.set(live);
+      const double* vj = V + (size_t)j * vs;
+      precond_apply(c, bt, vj, nm, c->zv.p);
+      op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank);
+      launch_cols_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
+                         c->h1.p, gsh);
+      // first update fused with the dot products of the second pass
+      launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h1.p, gsh, c->wv.p, nm,
+                                c->partial.p, gspart, c->h2.p, gsh);
+      launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p,
+                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol);
+      launch_cols_update_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
+                           c->scale.p, V + (size_t)(j + 1) * vs, nm);
       // Residual estimates travel to a pinned slot behind an event; the host
       // looks at the PREVIOUS iteration's slot, so it never drains the stream
-      // (one iteration of lag: at most one surplus Arnoldi step per solve).
-      double* slot = hb + 2 * RICADI_MAX_M + (size_t)(j & 1) * RICADI_MAX_M;
-      HIPCHK(hipMemcpyAsync(slot, c->resid.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+      // (one iteration of lag: at most one surplus Arnoldi step per group).
+      double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
+      HIPCHK(hipMemcpyAsync(cur, c->resid.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
       HIPCHK(hipEventRecord(c->ev_res[j & 1], st));
-      ++res.iters;
-      k = j + 1;
-      bool stop = res.iters >= maxit;
+      for (int g : live) {
+        ++res[g].iters;
+        kk[g] = j + 1;
+      }
+      std::vector<int> still;
       if (j >= 1) {
         HIPCHK(hipEventSynchronize(c->ev_res[(j - 1) & 1]));
-        const double* prev = hb + 2 * RICADI_MAX_M + (size_t)((j - 1) & 1) * RICADI_MAX_M;
-        if (all_converged(prev)) stop = true;
+        const double* prev = hb + 2 * slot + (size_t)((j - 1) & 1) * slot;
+        for (int g : live)
+          if (!group_converged(prev, g) && res[g].iters < maxit) still.push_back(g);
+      } else {
+        for (int g : live)
+          if (res[g].iters < maxit) still.push_back(g);
       }
-      if (stop) break;
+      live.swap(still);
     }
-    launch_gmres_backsolve(st, m, k, restart, c->H.p, c->g.p, c->yv.p);
-    launch_cols_update(st, n, m, k, V, nm, c->yv.p, 1.0, nullptr, nullptr, c->wv.p);
-    precond_apply(c, sd, c->wv.p, c->zv.p, m);
-    launch_axpby(st, nm, 1.0, c->zv.p, 1.0, x);
+    // corrections: x_g += P^-1 (V_g y_g) with the k_g basis vectors group g built
+    for (int g : act) {
+      bt.only(g);
+      launch_gmres_backsolve_b(st, bt.tab, m, kk[g], restart, c->H.p, c->g.p, c->yv.p);
+      launch_cols_update_b(st, bt.tab, n, m, kk[g], V, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
+                           nullptr, 0, nullptr, c->wv.p, nm);
+    }
+    bt.set(act);
+    precond_apply(c, bt, c->wv.p, nm, c->zv.p);
+    launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
   }
   if (relres_host) {
-    // true residual
-    op_apply(c, sd, x, c->wv.p, m, lowrank);
-    launch_axpby(st, nm, 1.0, b, -1.0, c->wv.p);
-    col_norms2(c, c->wv.p, n, m, c->nrm2.p);
-    HIPCHK(hipMemcpyAsync(hb, c->nrm2.p, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    // true residuals
+    bt.all();
+    op_apply(c, bt, x, nm, c->wv.p, lowrank);
+    launch_axpby_b(st, bt.tab, nm, 1.0, b, gsb, -1.0, c->wv.p, nm);
+    norms2(c->wv.p, nm, c->nrm2.p);
+    HIPCHK(hipMemcpyAsync(hb, c->nrm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int j = 0; j < m; ++j)
+    for (int j = 0; j < GM; ++j)
       relres_host[j] = bn[j] > 0.0 ? std::sqrt(std::max(hb[j], 0.0)) / bn[j] : 0.0;
   }
-  c->total_iters += res.iters;
-  c->total_solves += 1;
-  return res;
+  for (int g = 0; g < G; ++g) c->total_iters += res[g].iters;
+  c->total_solves += G;
+}
+
+static GmresResult gmres_solve(ricadi_ctx* c, ShiftData* sd, const double* b, double* x, int m,
+                               bool lowrank, double* relres_host) {
+  GmresResult r;
+  gmres_solve_batch(c, &sd, 1, b, (size_t)c->n * m, x, m, lowrank, relres_host, &r);
+  return r;
 }
 
 // rhs panel (n x m) from an NV x m device block (pressure rows zero)
@@ -541,6 +671,17 @@ static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double
   const long it0 = c->total_iters;
   double znorm2 = 0.0;
   int zc_last = c->zc;
+  {
+    // per-shift data of the whole shift cycle up front: the coarse inverses then come
+    // out of batched factorisations (16 shifts each) instead of one at a time
+    const int nuse = std::min(ns, prm.adi_max_steps);
+    std::vector<double> al(shifts, shifts + nuse), be(nuse, 1.0);
+    std::vector<ShiftData*> sds(nuse);
+    for (int s0 = 0; s0 < nuse; s0 += RICADI_MAX_GROUPS) {
+      const int cnt = std::min(RICADI_MAX_GROUPS, nuse - s0);
+      get_shifts(c, al.data() + s0, be.data() + s0, cnt, sds.data() + s0);
+    }
+  }
   for (int step = 1; step <= prm.adi_max_steps; ++step) {
     const double p = shifts[(step - 1) % ns];
     ShiftData* sd = get_shift(c, p, 1.0);
@@ -833,7 +974,7 @@ int ricadi_version(void) { return 100; }
 void ricadi_default_opts(ricadi_opts* o) {
   if (!o) return;
   o->gmres_tol = 1e-10;
-  o->gmres_restart = 20;
+  o->gmres_restart = 30;
   o->gmres_maxit = 3000;
   o->bj_block = 32;
   o->agg_v = 16;
@@ -969,7 +1110,6 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->jd_ptr.upload(hs.jd_ptr, st);
   c->jd_vblk.upload(hs.jd_vblk, st);
   c->jd_val.upload(hs.jd_val, st);
-  c->simple_diag = getenv("RICADI_SIMPLE_DIAG") != nullptr;
   c->agg_ptr.upload(hs.agg_ptr, st);
   c->agg_rows.upload(hs.agg_rows, st);
   c->aggof.upload(hs.aggof, st);
@@ -989,7 +1129,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->sb_lidx.upload(hs.sb_lidx, st);
   c->sb_ok = hs.sb_nblk > 0 && hs.sb_max_cols < 65536;
   c->q = 0;
-  c->wm = 0;  // workspaces depend on n
+  c->wcols = 0;  // workspaces depend on n
   c->zc = 0;
   c->has_op = true;
   if (c->opts.verbose)
@@ -1017,7 +1157,7 @@ int ricadi_set_dims(ricadi_ctx* c, int nv) {
   c->n = nv;
   c->q = 0;
   c->zc = 0;
-  c->wm = 0;
+  c->wcols = 0;
   return RICADI_OK;
 }
 
@@ -1029,7 +1169,6 @@ int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
   c->q = q;
   if (q > 0) {
     const size_t cnt = (size_t)c->nv * q;
-    if (cnt > c->U.n || cnt > c->V.n) ++c->work_epoch;
     c->U.ensure(cnt);
     c->V.ensure(cnt);
     HIPCHK(hipMemcpyAsync(c->U.p, U, cnt * sizeof(double), hipMemcpyHostToDevice, c->st));
@@ -1098,6 +1237,39 @@ int ricadi_shift_solve_dev(ricadi_ctx* c, double alpha, double beta, const doubl
     if (!r.converged) {
       ricadi::set_error("GMRES did not reach the tolerance");
       status = RICADI_ENOCONV;
+    }
+  } catch (const ricadi::HipError& e) {
+    ricadi::set_error(e.msg);
+    return RICADI_EHIP;
+  }
+  return status;
+}
+
+int ricadi_shift_solve_batch_dev(ricadi_ctx* c, int ng, const double* alphas, const double* betas,
+                                 const double* dR, int64_t r_stride, int m, double* dX,
+                                 int* iters_out, double* relres_out) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dR && dX && alphas && betas, RICADI_EINVAL, "NULL argument");
+  REQUIRE(ng >= 1 && ng <= RICADI_MAX_GROUPS && (size_t)ng * m <= 2048, RICADI_EINVAL,
+          "1 <= ng <= 16 and ng*m <= 2048 required");
+  REQUIRE(r_stride == 0 || r_stride >= (int64_t)c->nv * m, RICADI_EINVAL, "bad r_stride");
+  int status = RICADI_OK;
+  try {
+    std::vector<ShiftData*> sds(ng);
+    get_shifts(c, alphas, betas, ng, sds.data());
+    ensure_work(c, m, ng);
+    const size_t nm = (size_t)c->n * m;
+    const int nload = r_stride == 0 ? 1 : ng;
+    for (int g = 0; g < nload; ++g) load_rhs(c, dR + (size_t)g * r_stride, m, c->bvec.p + (size_t)g * nm);
+    std::vector<GmresResult> res(ng);
+    gmres_solve_batch(c, sds.data(), ng, c->bvec.p, r_stride == 0 ? 0 : nm, dX, m, true, relres_out,
+                      res.data());
+    for (int g = 0; g < ng; ++g) {
+      if (iters_out) iters_out[g] = res[g].iters;
+      if (!res[g].converged) {
+        ricadi::set_error("GMRES did not reach the tolerance");
+        status = RICADI_ENOCONV;
+      }
     }
   } catch (const ricadi::HipError& e) {
     ricadi::set_error(e.msg);
@@ -1195,7 +1367,8 @@ int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double*
   HIPCHK(hipEventCreate(&e1));
   // plain assembled-CSR saddle SpMM only (no low-rank term): the roofline kernel
   HIPCHK(hipEventRecord(e0, c->st));
-  for (int i = 0; i < reps; ++i) saddle_spmm(c, sd, dX, nullptr, dY, nullptr, 1.0, 0.0, m);
+  const Batch bt = make_batch(c, sd, m);
+  for (int i = 0; i < reps; ++i) saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
   HIPCHK(hipEventRecord(e1, c->st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -1332,7 +1505,6 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     const bool lr = (kk > 0) || oldB;
     c->q = lr ? nb : 0;
     if (lr) {
-      if ((size_t)nv * nb > c->U.n || (size_t)nv * nb > c->V.n) ++c->work_epoch;
       c->U.ensure((size_t)nv * nb);
       c->V.ensure((size_t)nv * nb);
       HIPCHK(hipMemcpyAsync(c->U.p, dKall.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));

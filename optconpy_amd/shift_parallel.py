@@ -65,16 +65,32 @@ class HipOps:
         ctx.synchronize()
         return X[:ctx.nv].contiguous(), its
 
+    MAX_BATCH = 16
+
     def solve_many(self, ps, W):
-        """Solve the same panel ``W`` against several shifts; concurrent when
-        more than one context is available.  Shift ``i`` of the list always goes
-        to context ``i % len(ctxs)`` so that per-shift data stay cached there.
-        (Splitting the panel's columns over streams as well was tried and is
-        slower on one GPU: every sub-panel repeats the per-shift setup and the
-        full launch sequence, and the host launch path is the limiter.)"""
+        """Solve the same panel ``W`` against several shifts.  Default: ONE batched
+        solve (``ricadi_shift_solve_batch_dev``) -- all shifts advance in lockstep
+        inside one launch sequence, grid.z = shifts still iterating.  With extra
+        contexts (``extra_ctxs``) the shifts are instead spread over host threads and
+        HIP streams, one solve each (the older scheme, kept for comparison)."""
         nctx = len(self.ctxs)
-        if nctx == 1 or len(ps) <= 1:
+        if len(ps) <= 1:
             return [self.solve(p, W) for p in ps]
+        if nctx == 1:
+            self._sync_in()
+            ctx = self.ctx
+            m = W.shape[1]
+            out = []
+            for c0 in range(0, len(ps), self.MAX_BATCH):
+                chunk = [float(p) for p in ps[c0:c0 + self.MAX_BATCH]]
+                X = self.empty(len(chunk), ctx.n, m)
+                its, _ = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
+                                                   X.data_ptr(), strict=False)
+                ctx.synchronize()
+                out.extend(X[g, :ctx.nv].contiguous() for g in range(len(chunk)))
+                self.gmres_iters += int(sum(its))
+                self.shift_solves += len(chunk)
+            return out
         from concurrent.futures import ThreadPoolExecutor
         if self._pool is None:
             self._pool = ThreadPoolExecutor(max_workers=nctx)

@@ -467,3 +467,34 @@ def test_newton_parity_other_ordering_and_viscosity():
                                           nwtn_adi_dict=d)
         assert info["nwtn_steps"] == ref["nwtn_steps"]
         assert rel(K, -opru.get_mTzzTtb(pr.M.T, ref["zfac"], tb)) < K_TOL
+
+
+def test_batched_shift_solve_matches_single():
+    """ricadi_shift_solve_batch_dev: all shifts of a sweep in one lockstep launch sequence give
+    the same solutions as one solve per shift -- shared and per-group right-hand sides, with
+    the low-rank term.  (Iteration counts are close but not equal: the restart-cycle length
+    adapts to the slowest group of the batch.)"""
+    import torch
+    pr = pb.ricc_problem(15, 0.05)
+    ctx = _lib.Context(0)
+    ctx.set_operator((-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr(), pr.J)
+    rng = np.random.default_rng(5)
+    ctx.set_lowrank(0.1 * rng.standard_normal((pr.NV, 3)), rng.standard_normal((pr.NV, 3)))
+    m = 7
+    ps = [-0.7, -3.0, -40.0, -900.0, -12.0]
+    dev = torch.device("cuda", 0)
+    for shared in (True, False):
+        R = rng.standard_normal((1 if shared else len(ps), pr.NV, m))
+        Rd = torch.as_tensor(R).to(dev)
+        X = torch.empty(len(ps), ctx.n, m, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), Rd.data_ptr(),
+                                            0 if shared else pr.NV * m, m, X.data_ptr())
+        ctx.synchronize()
+        assert rr.max() < 1e-9
+        Xh = X.cpu().numpy()
+        for g, p in enumerate(ps):
+            Xs, it1, rr1 = ctx.shift_solve(p, 1.0, R[0 if shared else g])
+            assert abs(it1 - its[g]) <= max(2, 0.4 * it1)
+            assert rel(Xh[g], Xs) < 1e-8
+    ctx.close()

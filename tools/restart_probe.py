@@ -1,0 +1,20 @@
+"""GMRES restart length vs iteration count on easy and hard operators.  python tools/restart_probe.py"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from optconpy_amd import _lib, problems as pb
+rng = np.random.default_rng(0)
+for N, nu in ((15, 0.005), (30, 0.005), (30, 0.05), (58, 0.05), (58, 0.01)):
+    pr = pb.ricc_problem(N, nu)
+    R = rng.standard_normal((pr.NV, 16))
+    for restart in (8, 12, 16, 20, 30):
+        ctx = _lib.Context(0, gmres_restart=restart, gmres_maxit=3000)
+        ctx.set_operator((-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr(), pr.J)
+        out = []
+        for p in (-1.0, -30.0, -1000.0):
+            ctx.shift_solve(p, 1.0, R, strict=False)
+            t0 = time.time()
+            X, its, rr = ctx.shift_solve(p, 1.0, R, strict=False)
+            out.append("p=%g: %d its %.1f ms (%.0e)" % (p, its, 1e3 * (time.time() - t0), rr.max()))
+        print("N=%d nu=%g restart %2d | %s" % (N, nu, restart, " | ".join(out)), flush=True)
+        ctx.close()
