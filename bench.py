@@ -242,6 +242,11 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
+    if use_sp:
+        ops.t_solve = 0.0
+
+    def ops_t_solve():
+        return ops.t_solve
     t0 = time.perf_counter()
     units = 0
     iters = 0
@@ -254,6 +259,9 @@ def main():
         local_solves += ls
     barrier()
     elapsed = time.perf_counter() - t0
+    if use_sp and rank == 0:
+        log("[bench] rank 0: %.1f %% of the timed region inside the batched shift-solves "
+            "(incl. per-shift setup)" % (100.0 * ops_t_solve() / max(elapsed, 1e-9)))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -79,16 +79,20 @@ struct GroupTab {
   int ng;
   int gid[RICADI_MAX_GROUPS];
 };
-struct GroupPtrs {
-  const double* p[RICADI_MAX_GROUPS];
+template <class T>
+struct GroupPtrsT {
+  const T* p[RICADI_MAX_GROUPS];
 };
+typedef GroupPtrsT<double> GroupPtrs;
+typedef GroupPtrsT<float> GroupPtrsF;   // FP32-stored preconditioner operands
 inline GroupTab single_group() {
   GroupTab t{};
   t.ng = 1;
   return t;
 }
-inline GroupPtrs same_ptr(const double* q) {
-  GroupPtrs g;
+template <class T>
+inline GroupPtrsT<T> same_ptr(const T* q) {
+  GroupPtrsT<T> g;
   for (int i = 0; i < RICADI_MAX_GROUPS; ++i) g.p[i] = q;
   return g;
 }
@@ -109,7 +113,20 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
                     size_t gsx, double b, double* y, size_t gsy);
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
-                       const double* x, size_t gsx, double b, double* y, size_t gsy);
+                       const double* x, size_t gsx, double b, double* y, size_t gsy,
+                       float* yf = nullptr, size_t gsf = 0);
+// FP32-stored Krylov basis (arithmetic stays FP64): overloads reading `const float* basis`
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const float* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                        int want_self, double* partial, size_t gsp, double* out, size_t gso);
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const float* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso);
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const float* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso, float* outf, size_t gsf);
 void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                         const double* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
                         int want_self, double* partial, size_t gsp, double* out, size_t gso);
@@ -133,6 +150,14 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract);
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
                           const double* rc, double* ec);
+// FP32-stored inverses (leading dimension ldf = k rounded up to 4; bs x bs blocks)
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
+                          int ldf, const double* rc, double* ec);
+void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                          const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract);
+void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
+                   int ldd);
 void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
                           const double* ec, size_t gse, double* z, size_t gsz);
 void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,

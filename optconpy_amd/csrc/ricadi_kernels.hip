@@ -479,28 +479,39 @@ void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 }
 
 // y[r, c] = a[c] * x[r, c] + b * y[r, c]   (per-column scale, contiguous panel)
+// yf (optional): FP32 copy of the result; y then holds the SAME rounded values.
 __global__ void colscale_kernel(GroupTab gt, size_t n, int m, const double* __restrict__ a,
                                 const double* __restrict__ x, size_t gsx, double b,
-                                double* __restrict__ y, size_t gsy) {
+                                double* __restrict__ y, size_t gsy, float* __restrict__ yf,
+                                size_t gsf) {
   const int grp = gt.gid[blockIdx.z];
   a += (size_t)grp * m;
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
+  if (yf) yf += (size_t)grp * gsf;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    y[i] = a[i % m] * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+       i += (size_t)gridDim.x * blockDim.x) {
+    double v = a[i % m] * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
+    if (yf) {
+      const float f = (float)v;
+      yf[i] = f;
+      v = (double)f;
+    }
+    y[i] = v;
+  }
 }
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
-                       const double* x, size_t gsx, double b, double* y, size_t gsy) {
+                       const double* x, size_t gsx, double b, double* y, size_t gsy, float* yf,
+                       size_t gsf) {
   size_t n = nrows * m;
   if (!n || gt.ng <= 0) return;
   int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(colscale_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, n, m, a, x, gsx,
-                     b, y, gsy);
+                     b, y, gsy, yf, gsf);
 }
 void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
                      double b, double* y) {
-  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0);
+  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0, nullptr, 0);
 }
 
 // copy a strided block of columns: dst[r, dc0 + c] = scale * src[r, sc0 + c], c < w
@@ -536,8 +547,9 @@ void launch_copy_cols(hipStream_t st, int nrows, int w, const double* src, int l
 // ---------------------------------------------------------------------------
 constexpr int DOT_ROWS = 64;
 
+template <class BT>
 __global__ __launch_bounds__(256) void cols_dots_kernel(
-    GroupTab gt, int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    GroupTab gt, int nrows, int m, int nvec, const BT* __restrict__ basis, size_t vstride,
     size_t gsb, const double* __restrict__ w, size_t gsw, int want_self,
     double* __restrict__ partial, size_t gsp) {
   extern __shared__ double wl[];  // DOT_ROWS x m
@@ -553,15 +565,18 @@ __global__ __launch_bounds__(256) void cols_dots_kernel(
   const int nout = ntot * m;
   for (int o = threadIdx.x; o < nout; o += blockDim.x) {
     const int i = o / m, c = o - i * m;
-    const double* v = (i < nvec) ? basis + (size_t)i * vstride + (size_t)r0 * m + c
-                                 : w + (size_t)r0 * m + c;
     double s0 = 0.0, s1 = 0.0;
     int r = 0;
-    for (; r + 1 < nr; r += 2) {
-      s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
-      s1 = fma(v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+    if (i < nvec) {
+      const BT* v = basis + (size_t)i * vstride + (size_t)r0 * m + c;
+      for (; r + 1 < nr; r += 2) {
+        s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+        s1 = fma((double)v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+      }
+      if (r < nr) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+    } else {
+      for (; r < nr; ++r) s0 = fma(wl[r * m + c], wl[r * m + c], s0);
     }
-    if (r < nr) s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
     partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
   }
 }
@@ -600,17 +615,30 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GroupTab gt, int n
 
 int dots_num_blocks(int nrows) { return (nrows + DOT_ROWS - 1) / DOT_ROWS; }
 
-void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
-                        const double* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
-                        int want_self, double* partial, size_t gsp, double* out, size_t gso) {
+template <class BT>
+static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                           const BT* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                           int want_self, double* partial, size_t gsp, double* out, size_t gso) {
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + (want_self ? 1 : 0)) * m;
   if (nout == 0 || gt.ng <= 0) return;
-  hipLaunchKernelGGL(cols_dots_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+  hipLaunchKernelGGL(cols_dots_kernel<BT>, dim3(nblk, 1, gt.ng), dim3(256),
                      DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, w,
                      gsw, want_self, partial, gsp);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                      nblk, nout, partial, gsp, out, gso, 0);
+}
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const double* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                        int want_self, double* partial, size_t gsp, double* out, size_t gso) {
+  cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
+                 gso);
+}
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const float* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
+                        int want_self, double* partial, size_t gsp, double* out, size_t gso) {
+  cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
+                 gso);
 }
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
@@ -626,8 +654,9 @@ void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* 
 // right after its slice of w' -- the basis slice it has just read is still in
 // L1/L2 -- which saves one launch and one pass over the Krylov basis per
 // iteration compared with separate update and dots kernels.
+template <class BT>
 __global__ __launch_bounds__(256) void cols_update_dots_kernel(
-    GroupTab gt, int nrows, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    GroupTab gt, int nrows, int m, int nvec, const BT* __restrict__ basis, size_t vstride,
     size_t gsb, const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
     double* __restrict__ partial, size_t gsp) {
   extern __shared__ double wl[];  // DOT_ROWS x m
@@ -644,10 +673,10 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
     double s0 = 0.0, s1 = 0.0;
     int i = 0;
     for (; i + 1 < nvec; i += 2) {
-      s0 = fma(h[i * m + c], basis[(size_t)i * vstride + base + e], s0);
-      s1 = fma(h[(i + 1) * m + c], basis[(size_t)(i + 1) * vstride + base + e], s1);
+      s0 = fma(h[i * m + c], (double)basis[(size_t)i * vstride + base + e], s0);
+      s1 = fma(h[(i + 1) * m + c], (double)basis[(size_t)(i + 1) * vstride + base + e], s1);
     }
-    if (i < nvec) s0 = fma(h[i * m + c], basis[(size_t)i * vstride + base + e], s0);
+    if (i < nvec) s0 = fma(h[i * m + c], (double)basis[(size_t)i * vstride + base + e], s0);
     const double v = w[base + e] - (s0 + s1);
     wl[e] = v;
     w[base + e] = v;
@@ -658,31 +687,46 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
     const int i = o / m, c = o - i * m;
     double s0 = 0.0, s1 = 0.0;
     if (i < nvec) {
-      const double* v = basis + (size_t)i * vstride + base + c;
+      const BT* v = basis + (size_t)i * vstride + base + c;
       int r = 0;
       for (; r + 1 < nr; r += 2) {
-        s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
-        s1 = fma(v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+        s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+        s1 = fma((double)v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
       }
-      if (r < nr) s0 = fma(v[(size_t)r * m], wl[r * m + c], s0);
+      if (r < nr) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
     } else {
       for (int r = 0; r < nr; ++r) s0 = fma(wl[r * m + c], wl[r * m + c], s0);
     }
     partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
   }
 }
-void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
-                               const double* basis, size_t vstride, size_t gsb, const double* h,
-                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
-                               double* out, size_t gso) {
+template <class BT>
+static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                                  const BT* basis, size_t vstride, size_t gsb, const double* h,
+                                  size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                                  double* out, size_t gso) {
   if (gt.ng <= 0) return;
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + 1) * m;
-  hipLaunchKernelGGL(cols_update_dots_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+  hipLaunchKernelGGL(cols_update_dots_kernel<BT>, dim3(nblk, 1, gt.ng), dim3(256),
                      DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, h,
                      gsh, w, gsw, partial, gsp);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                      nblk, nout, partial, gsp, out, gso, 0);
+}
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const double* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso) {
+  cols_update_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, w, gsw, partial, gsp, out,
+                        gso);
+}
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const float* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso) {
+  cols_update_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, w, gsw, partial, gsp, out,
+                        gso);
 }
 void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                              size_t vstride, const double* h, double* w, double* partial,
@@ -693,41 +737,66 @@ void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const d
 
 // out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
 // (scale may be NULL = 1; w may be NULL = 0).  Streams nvec panels once.
+// outf (optional): FP32 copy of the result (the stored Krylov vector); out then
+// holds the same rounded values, so the vector the next operator application
+// sees IS the stored one.
+template <class BT>
 __global__ __launch_bounds__(256) void cols_update_kernel(
-    GroupTab gt, size_t nelem, int m, int nvec, const double* __restrict__ basis, size_t vstride,
+    GroupTab gt, size_t nelem, int m, int nvec, const BT* __restrict__ basis, size_t vstride,
     size_t gsb, const double* __restrict__ h, size_t gsh, double sign,
     const double* __restrict__ w, size_t gsw, const double* __restrict__ scale,
-    double* __restrict__ out, size_t gso) {
+    double* __restrict__ out, size_t gso, float* __restrict__ outf, size_t gsf) {
   const int grp = gt.gid[blockIdx.z];
   basis += (size_t)grp * gsb;
   h += (size_t)grp * gsh;
   if (w) w += (size_t)grp * gsw;
   if (scale) scale += (size_t)grp * m;
   out += (size_t)grp * gso;
+  if (outf) outf += (size_t)grp * gsf;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nelem;
        e += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % m);
     double s0 = 0.0, s1 = 0.0;
     int i = 0;
     for (; i + 1 < nvec; i += 2) {
-      s0 = fma(h[i * m + c], basis[(size_t)i * vstride + e], s0);
-      s1 = fma(h[(i + 1) * m + c], basis[(size_t)(i + 1) * vstride + e], s1);
+      s0 = fma(h[i * m + c], (double)basis[(size_t)i * vstride + e], s0);
+      s1 = fma(h[(i + 1) * m + c], (double)basis[(size_t)(i + 1) * vstride + e], s1);
     }
-    if (i < nvec) s0 = fma(h[i * m + c], basis[(size_t)i * vstride + e], s0);
+    if (i < nvec) s0 = fma(h[i * m + c], (double)basis[(size_t)i * vstride + e], s0);
     double v = (w ? w[e] : 0.0) + sign * (s0 + s1);
     if (scale) v *= scale[c];
+    if (outf) {
+      const float f = (float)v;
+      outf[e] = f;
+      v = (double)f;
+    }
     out[e] = v;
   }
+}
+template <class BT>
+static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                             const BT* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                             double sign, const double* w, size_t gsw, const double* scale,
+                             double* out, size_t gso, float* outf, size_t gsf) {
+  size_t nelem = (size_t)nrows * m;
+  if (!nelem || gt.ng <= 0) return;
+  int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
+  hipLaunchKernelGGL(cols_update_kernel<BT>, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nelem, m,
+                     nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso, outf, gsf);
 }
 void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                           const double* basis, size_t vstride, size_t gsb, const double* h,
                           size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
                           double* out, size_t gso) {
-  size_t nelem = (size_t)nrows * m;
-  if (!nelem || gt.ng <= 0) return;
-  int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
-  hipLaunchKernelGGL(cols_update_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nelem, m, nvec,
-                     basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso);
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso,
+                   (float*)nullptr, 0);
+}
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const float* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso, float* outf, size_t gsf) {
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso,
+                   outf, gsf);
 }
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
@@ -909,13 +978,23 @@ void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, 
 // output rows s, s+4, ...
 //   out[rows[il], :] = sum_jl inv[b][il][jl] * in[rows[jl], :]
 // ---------------------------------------------------------------------------
-template <int BS>
+// four consecutive entries of a stored inverse (FP64: two 16-B loads, FP32: one)
+__device__ __forceinline__ void load4(const double* p, double (&a)[4]) {
+  const double2 u = reinterpret_cast<const double2*>(p)[0], v = reinterpret_cast<const double2*>(p)[1];
+  a[0] = u.x; a[1] = u.y; a[2] = v.x; a[3] = v.y;
+}
+__device__ __forceinline__ void load4(const float* p, double (&a)[4]) {
+  const float4 u = reinterpret_cast<const float4*>(p)[0];
+  a[0] = (double)u.x; a[1] = (double)u.y; a[2] = (double)u.z; a[3] = (double)u.w;
+}
+
+template <int BS, class T>
 __global__ __launch_bounds__(256) void block_apply_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
-    GroupPtrs invs, const double* __restrict__ in, int ldi, size_t gsi,
+    GroupPtrsT<T> invs, const double* __restrict__ in, int ldi, size_t gsi,
     double* __restrict__ out, int ldo, size_t gso, int m, int subtract) {
   const int grp = gt.gid[blockIdx.z];
-  const double* __restrict__ inv = invs.p[grp];
+  const T* __restrict__ inv = invs.p[grp];
   in += (size_t)grp * gsi;
   out += (size_t)grp * gso;
   // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
@@ -928,7 +1007,7 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
   const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
-  const double* Bi = inv + (size_t)wave * BS * BS;
+  const T* Bi = inv + (size_t)wave * BS * BS;
   constexpr int NT = BS / 16;
   for (int c0 = 0; c0 < m; c0 += 16) {
     const int col = c0 + r;
@@ -945,13 +1024,12 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const double2* p =
-            reinterpret_cast<const double2*>(Bi + (size_t)(16 * t + r) * BS + kc * 16 + 4 * q);
-        const double2 u = p[0], v = p[1];
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.x, xb[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(u.y, xb[1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, xb[2], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, xb[3], acc[t], 0, 0, 0);
+        double a4[4];
+        load4(Bi + (size_t)(16 * t + r) * BS + kc * 16 + 4 * q, a4);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xb[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xb[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xb[2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xb[3], acc[t], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -966,25 +1044,36 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
       }
   }
 }
-void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
-                          const int* rows, const GroupPtrs& inv, const double* in, int ldi,
-                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
+template <class T>
+static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                             const int* rows, const GroupPtrsT<T>& inv, const double* in, int ldi,
+                             size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
   if (nblocks <= 0 || gt.ng <= 0) return;
   dim3 grid((nblocks + 3) / 4, 1, gt.ng), block(256);
   switch (bs) {
     case 16:
-      hipLaunchKernelGGL(block_apply_kernel<16>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
-                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      hipLaunchKernelGGL((block_apply_kernel<16, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
       break;
     case 32:
-      hipLaunchKernelGGL(block_apply_kernel<32>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
-                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      hipLaunchKernelGGL((block_apply_kernel<32, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
       break;
     default:
-      hipLaunchKernelGGL(block_apply_kernel<64>, grid, block, 0, st, gt, nblocks, bptr, rows, inv,
-                         in, ldi, gsi, out, ldo, gso, m, subtract);
+      hipLaunchKernelGGL((block_apply_kernel<64, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
       break;
   }
+}
+void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                          const int* rows, const GroupPtrs& inv, const double* in, int ldi,
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+}
+void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                          const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract);
 }
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
                         const double* inv, const double* in, int ldi, double* out, int ldo,
@@ -1207,13 +1296,15 @@ void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows
 // MFMA s; the k index of that MFMA's slot q is column j0+4q+s, so the B operand
 // is rc[j0+4q+s][c].  Partial tiles are summed through LDS.
 typedef double d4v __attribute__((ext_vector_type(4)));
+// `ld`: leading dimension of the stored inverse (k for FP64, k rounded up to 4 for FP32)
+template <class T>
 __global__ __launch_bounds__(512) void dense_apply_kernel(GroupTab gt, int k, int m,
-                                                          GroupPtrs Einvs,
+                                                          GroupPtrsT<T> Einvs, int ld,
                                                           const double* __restrict__ rc,
                                                           double* __restrict__ ec) {
   __shared__ double red[8][16][17];
   const int grp = gt.gid[blockIdx.z];
-  const double* __restrict__ Einv = Einvs.p[grp];
+  const T* __restrict__ Einv = Einvs.p[grp];
   rc += (size_t)grp * k * m;
   ec += (size_t)grp * k * m;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1229,13 +1320,13 @@ __global__ __launch_bounds__(512) void dense_apply_kernel(GroupTab gt, int k, in
   // and the 4 matching rows of rc
   auto fetch = [&](int ch, double (&a)[4], double (&bb)[4]) {
     const int j = ch * 16 + 4 * q;
-    if (row < k && j + 3 < k && ((size_t)row * k + j) % 2 == 0) {
-      const double2* p = reinterpret_cast<const double2*>(Einv + (size_t)row * k + j);
-      const double2 u = p[0], v = p[1];
-      a[0] = u.x; a[1] = u.y; a[2] = v.x; a[3] = v.y;
+    // vector load when the 4 entries exist and are aligned to the vector size
+    if (row < k && j + 3 < k && ((size_t)row * ld + j) % (sizeof(T) == 4 ? 4 : 2) == 0) {
+      load4(Einv + (size_t)row * ld + j, a);
     } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = (row < k && j + t < k) ? Einv[(size_t)row * k + j + t] : 0.0;
+      for (int t = 0; t < 4; ++t)
+        a[t] = (row < k && j + t < k) ? (double)Einv[(size_t)row * ld + j + t] : 0.0;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1280,7 +1371,32 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
                           const double* rc, double* ec) {
   if (k <= 0 || gt.ng <= 0) return;
   dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
-  hipLaunchKernelGGL(dense_apply_kernel, grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
+  hipLaunchKernelGGL(dense_apply_kernel<double>, grid, dim3(512), 0, st, gt, k, m, Einv, k, rc, ec);
+}
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
+                          int ldf, const double* rc, double* ec) {
+  if (k <= 0 || gt.ng <= 0) return;
+  dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
+  hipLaunchKernelGGL(dense_apply_kernel<float>, grid, dim3(512), 0, st, gt, k, m, Einv, ldf, rc, ec);
+}
+
+// dst (FP32, leading dimension ldd) = src (FP64, leading dimension lds_)
+__global__ void to_f32_kernel(int nrows, int ncols, const double* __restrict__ src, int lds_,
+                              float* __restrict__ dst, int ldd) {
+  const size_t n = (size_t)nrows * ldd;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / ldd;
+    const int c = (int)(i - r * ldd);
+    dst[i] = c < ncols ? (float)src[r * lds_ + c] : 0.f;
+  }
+}
+void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
+                   int ldd) {
+  const size_t n = (size_t)nrows * ldd;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(to_f32_kernel, dim3(grid), dim3(256), 0, st, nrows, ncols, src, lds_, dst, ldd);
 }
 void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
                         double* ec) {

@@ -70,6 +70,10 @@ struct ShiftData {
   double alpha = 0, beta = 0;
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
   DArr<double> sval, svalb, bvinv, bpinv, einv;
+  // FP32 copies of the inverses, the ones the preconditioner applies (a fixed linear
+  // operator either way; halves its HBM traffic).  einvf has leading dimension kc
+  // rounded up to 4.  RICADI_PRECOND64=1 applies the FP64 originals instead.
+  DArr<float> bvinvf, bpinvf, einvf;
 };
 
 struct DevCsr {
@@ -118,7 +122,10 @@ struct ricadi_ctx {
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
   int wcols = 0, wrestart = 0;   // total columns (width x groups) and restart length the workspace holds
-  DArr<double> basis, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
+  DArr<double> basis, vcur, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
+  DArr<float> basisf;
+  bool basis32 = true;
+  bool precond32 = true;
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
   DArr<double*> eptrs;
@@ -150,7 +157,19 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1) {
   if (m * groups <= c->wcols && restart == c->wrestart) return;
   const size_t gm = (size_t)std::max(m * groups, c->wcols);
   const size_t nm = (size_t)c->n * gm;
-  c->basis.alloc((size_t)(restart + 1) * nm);
+  // Krylov basis: stored in FP32 by default (all arithmetic stays FP64) -- its three
+  // passes per iteration are the largest share of the HBM traffic.  The current
+  // vector is also kept in FP64 (vcur, holding the same rounded values) for the
+  // operator / preconditioner application.  RICADI_BASIS64=1 keeps an FP64 basis.
+  c->basis32 = getenv("RICADI_BASIS64") == nullptr;
+  if (c->basis32) {
+    c->basisf.alloc((size_t)(restart + 1) * nm);
+    c->vcur.alloc(nm);
+    c->basis.release();
+  } else {
+    c->basis.alloc((size_t)(restart + 1) * nm);
+    c->basisf.release();
+  }
   c->wv.alloc(nm);
   c->zv.alloc(nm);
   c->r2.alloc(nm);
@@ -262,6 +281,23 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     if (info[i] != 0)
       throw HipError{"coarse matrix singular (getrf/getri info " + std::to_string(info[i]) + ")"};
   if (flag) throw HipError{"singular block-Jacobi block"};
+  if (c->precond32) {
+    const int bs2 = c->bs * c->bs;
+    for (ShiftData* sd : todo) {
+      if (sd->bvinvf.n != sd->bvinv.n) sd->bvinvf.alloc(sd->bvinv.n);
+      launch_to_f32(st, c->nbv, bs2, sd->bvinv.p, bs2, sd->bvinvf.p, bs2);
+      if (c->nbp > 0) {
+        if (sd->bpinvf.n != sd->bpinv.n) sd->bpinvf.alloc(sd->bpinv.n);
+        launch_to_f32(st, c->nbp, bs2, sd->bpinv.p, bs2, sd->bpinvf.p, bs2);
+      }
+      if (k > 0) {
+        const int ldf = (k + 3) & ~3;
+        if (sd->einvf.n != (size_t)k * ldf) sd->einvf.alloc((size_t)k * ldf);
+        launch_to_f32(st, k, k, sd->einv.p, k, sd->einvf.p, ldf);
+      }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+  }
   for (ShiftData* sd : todo) sd->valid = true;
 }
 
@@ -280,6 +316,7 @@ struct Batch {
   int m = 0;                 // panel width of every group
   GroupTab tab;              // groups the next launches act on
   GroupPtrs sval, svalb, bvinv, bpinv, einv;
+  GroupPtrsF bvinvf, bpinvf, einvf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
   void all() {
@@ -301,8 +338,12 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.G = G;
   bt.m = m;
   bt.tab = GroupTab{};
-  bt.sval = bt.svalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr(nullptr);
+  bt.sval = bt.svalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
+  bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   for (int g = 0; g < G; ++g) {
+    bt.bvinvf.p[g] = sds[g]->bvinvf.p;
+    bt.bpinvf.p[g] = sds[g]->bpinvf.p;
+    bt.einvf.p[g] = sds[g]->einvf.p;
     bt.sval.p[g] = sds[g]->sval.p;
     bt.svalb.p[g] = sds[g]->svalb.p;
     bt.bvinv.p[g] = sds[g]->bvinv.p;
@@ -368,27 +409,40 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
                   bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
-    launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
+    if (c->precond32)
+      launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
+    else
+      launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
     // r2 = r - S * (Y ec), prolongation folded into the gather
     saddle_spmm(c, bt, c->ec.p, bt.gsc, c->aggof.p, c->r2.p, bt.gs, r, gsr, -1.0, 1.0);
     rr = c->r2.p;
     gsrr = bt.gs;
   }
-  launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, rr, m, gsrr, z, m,
-                       bt.gs, m, 0);
+  auto vel_apply = [&](const double* in, size_t gsi, int subtract) {
+    if (c->precond32)
+      launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, in, m, gsi, z,
+                           m, bt.gs, m, subtract);
+    else
+      launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, in, m, gsi, z,
+                           m, bt.gs, m, subtract);
+  };
+  vel_apply(rr, gsrr, 0);
   if (np > 0) {
     // t = J z_v - r_p
     launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
                   rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
-    launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->tp.p, m,
-                         bt.gsp, zp, m, bt.gs, m, 0);
+    if (c->precond32)
+      launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
+                           bt.gsp, zp, m, bt.gs, m, 0);
+    else
+      launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->tp.p, m,
+                           bt.gsp, zp, m, bt.gs, m, 0);
     // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks
     double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
     launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
                   nullptr, 0, 0, 1.0, 0.0, m);
-    launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, tmp, m, bt.gs, z,
-                         m, bt.gs, m, 1);
+    vel_apply(tmp, bt.gs, 1);
   }
   if (c->kc > 0) launch_prolong_add_b(st, gt, c->n, m, c->aggof.p, c->ec.p, bt.gsc, z, bt.gs);
 }
@@ -435,13 +489,15 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   const size_t gsh = (size_t)(restart + 2) * m;
   const size_t gspart = (size_t)dots_num_blocks(n) * (restart + 2) * m;
   const int GM = G * m;
-  double* V = c->basis.p;
+  double* V = c->basis.p;          // FP64 basis (RICADI_BASIS64) ...
+  float* Vf = c->basisf.p;         // ... or the FP32-stored one
+  const bool b32 = c->basis32;
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
   for (int g = 0; g < G; ++g) res[g] = GmresResult();
 
   auto norms2 = [&](const double* w, size_t gsw, double* out) {
-    launch_cols_dots_b(st, bt.tab, n, m, 0, nullptr, 0, 0, w, gsw, 1, c->partial.p, gspart, out,
+    launch_cols_dots_b(st, bt.tab, n, m, 0, (const double*)nullptr, 0, 0, w, gsw, 1, c->partial.p, gspart, out,
                        (size_t)m);
   };
   bt.all();
@@ -515,23 +571,37 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     act.swap(next);
     if (act.empty()) break;
     bt.set(act);
-    launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
+    if (b32)
+      launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, c->vcur.p, nm, Vf, nm);
+    else
+      launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
     live = act;
     for (int g : act) kk[g] = 0;
     for (int j = 0; j < cyc && !live.empty(); ++j) {
       bt.set(live);
-      const double* vj = V + (size_t)j * vs;
+      const double* vj = b32 ? c->vcur.p : V + (size_t)j * vs;
       precond_apply(c, bt, vj, nm, c->zv.p);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank);
-      launch_cols_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
-                         c->h1.p, gsh);
-      // first update fused with the dot products of the second pass
-      launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h1.p, gsh, c->wv.p, nm,
-                                c->partial.p, gspart, c->h2.p, gsh);
+      if (b32) {
+        launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
+                           c->h1.p, gsh);
+        launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm,
+                                  c->partial.p, gspart, c->h2.p, gsh);
+      } else {
+        launch_cols_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
+                           c->h1.p, gsh);
+        // first update fused with the dot products of the second pass
+        launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h1.p, gsh, c->wv.p, nm,
+                                  c->partial.p, gspart, c->h2.p, gsh);
+      }
       launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p,
                           c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol);
-      launch_cols_update_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
-                           c->scale.p, V + (size_t)(j + 1) * vs, nm);
+      if (b32)
+        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
+                             c->scale.p, c->vcur.p, nm, Vf + (size_t)(j + 1) * vs, nm);
+      else
+        launch_cols_update_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
+                             c->scale.p, V + (size_t)(j + 1) * vs, nm);
       // Residual estimates travel to a pinned slot behind an event; the host
       // looks at the PREVIOUS iteration's slot, so it never drains the stream
       // (one iteration of lag: at most one surplus Arnoldi step per group).
@@ -558,8 +628,12 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     for (int g : act) {
       bt.only(g);
       launch_gmres_backsolve_b(st, bt.tab, m, kk[g], restart, c->H.p, c->g.p, c->yv.p);
-      launch_cols_update_b(st, bt.tab, n, m, kk[g], V, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
-                           nullptr, 0, nullptr, c->wv.p, nm);
+      if (b32)
+        launch_cols_update_b(st, bt.tab, n, m, kk[g], Vf, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
+                             nullptr, 0, nullptr, c->wv.p, nm, nullptr, 0);
+      else
+        launch_cols_update_b(st, bt.tab, n, m, kk[g], V, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
+                             nullptr, 0, nullptr, c->wv.p, nm);
     }
     bt.set(act);
     precond_apply(c, bt, c->wv.p, nm, c->zv.p);
@@ -1010,6 +1084,7 @@ int ricadi_create(int device_id, ricadi_ctx** out) {
   std::unique_ptr<ricadi_ctx> c(new ricadi_ctx);
   c->dev = device_id;
   ricadi_default_opts(&c->opts);
+  c->precond32 = getenv("RICADI_PRECOND64") == nullptr;
   HIPCHK(hipStreamCreate(&c->st));
   RBCHK(rocblas_create_handle(&c->rb));
   RBCHK(rocblas_set_stream(c->rb, c->st));

@@ -48,6 +48,7 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.gmres_iters = 0
         self.shift_solves = 0
+        self.t_solve = 0.0          # wall seconds inside solve_many / solve (synchronised)
         self._pool = None
 
     def set_lowrank(self, U=None, V=None):
@@ -73,11 +74,13 @@ class HipOps:
         inside one launch sequence, grid.z = shifts still iterating.  With extra
         contexts (``extra_ctxs``) the shifts are instead spread over host threads and
         HIP streams, one solve each (the older scheme, kept for comparison)."""
+        import time
         nctx = len(self.ctxs)
         if len(ps) <= 1:
             return [self.solve(p, W) for p in ps]
         if nctx == 1:
             self._sync_in()
+            t0 = time.perf_counter()
             ctx = self.ctx
             m = W.shape[1]
             out = []
@@ -90,6 +93,7 @@ class HipOps:
                 out.extend(X[g, :ctx.nv].contiguous() for g in range(len(chunk)))
                 self.gmres_iters += int(sum(its))
                 self.shift_solves += len(chunk)
+            self.t_solve += time.perf_counter() - t0
             return out
         from concurrent.futures import ThreadPoolExecutor
         if self._pool is None:
