@@ -58,29 +58,39 @@ def build_inputs(N, nu, nshifts):
     return pr, tb, trct, ms
 
 
-def spmm_roofline(ctx, nnz_s, n, m, reps=200):
-    """K1 roofline: algorithmic bytes (12 nnz + 4 (n+1) + 16 n m) over
-    the kernel's average duration measured with HIP events on the ctx stream."""
+def spmm_roofline(ctx, nnz_s, n, m, shifts, reps=200):
+    """K1 roofline on the launch the hot path issues: ONE batched tile-SpMM launch over
+    the G = len(shifts) panels of a sweep (grid.z = G).  Algorithmic bytes per unit
+    (12 nnz + 4 (n+1) + 16 n m) x G units per launch, over the launch's
+    average duration measured with HIP events on the ctx stream.  The single-panel launch
+    (sequential path) is reported next to it."""
     import torch
-    x = torch.randn(n, m, dtype=torch.float64, device="cuda")
+    G = len(shifts)
+    x = torch.randn(G, n, m, dtype=torch.float64, device="cuda")
     y = torch.empty_like(x)
     torch.cuda.synchronize()
-    ctx.time_spmm_dev(-3.0, 1.0, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
-    ms = ctx.time_spmm_dev(-3.0, 1.0, x.data_ptr(), m, y.data_ptr(), reps)
-    nbytes = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
+    al, be = [float(p) for p in shifts], [1.0] * G
+    ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
+    ms = ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), reps)
+    ms1 = ctx.time_spmm_dev(al[0], 1.0, x.data_ptr(), m, y.data_ptr(), reps)
+    unit = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
+    nbytes = unit * G
     gbs = nbytes / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed PMC passes of this kernel and shape
     # (profiles/r01_spmm_traffic.json); None for shapes that were not profiled
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")) as f:
-            traffic = json.load(f).get("%dx%d" % (n, m), {}).get("hbm_bytes")
+            traffic = json.load(f).get("%dx%dx%d" % (G, n, m), {}).get("hbm_bytes")
     except (OSError, ValueError):
         pass
     return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic,
                 kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(ms * 1e3, 2),
-                algorithmic_bytes=int(nbytes), n=int(n), m=int(m), nnz=int(nnz_s))
+                units_per_launch=G, algorithmic_bytes=int(nbytes),
+                algorithmic_bytes_per_unit=int(unit), n=int(n), m=int(m), nnz=int(nnz_s),
+                single_panel_us_per_launch=round(ms1 * 1e3, 2),
+                single_panel_frac=round(unit / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
 
 
 def gram_mfma(ctx, nv, c, reps=20):
@@ -223,7 +233,8 @@ def main():
 
         def one_step():
             ops.clear_cache()
-            ops.set_lowrank(Kk, tb)
+            if not os.environ.get('BENCH_NO_LR'):     # developer probe: open-loop operator
+                ops.set_lowrank(Kk, tb)
             ops.gmres_iters = 0
             ops.shift_solves = 0
             blocks, info = lyap_adi_shift_parallel(ops, ms, rhs, adi_max_steps=200,
@@ -296,7 +307,9 @@ def main():
                 "K_rel_diff_vs_converged": k_err,
             },
         }
-        out["roofline"] = spmm_roofline(ctx, nnz_s, n, m)
+        # the launch of the hot path: the sweep's shifts of one rank in one batched launch
+        gsh = [float(p) for p in ms[:max(1, (G if use_sp else 1) // world)]]
+        out["roofline"] = spmm_roofline(ctx, nnz_s, n, m, gsh)
         out["roofline_gram_mfma"] = gram_mfma(ctx, pr.NV, 512)
         if world == 1 and not args.no_large_roofline:
             # the HBM-resident instance (BASELINE cfg5 pattern, n ~ 5e5)
@@ -306,7 +319,7 @@ def main():
                 cl.set_operator((-prl.A - prl.Nc).T.tocsr(), prl.M.T.tocsr(), prl.J)
                 nl = prl.NV + prl.NP
                 nnzl = (prl.A + prl.Nc + prl.M).nnz + 2 * prl.J.nnz
-                out["roofline_cfg5"] = spmm_roofline(cl, nnzl, nl, 16, reps=100)
+                out["roofline_cfg5"] = spmm_roofline(cl, nnzl, nl, 16, gsh, reps=50)
                 cl.close()
             except Exception as e:                   # never lose the headline line
                 out["roofline_cfg5"] = {"error": str(e)}

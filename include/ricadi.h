@@ -238,6 +238,11 @@ int ricadi_panel_norms_dev(ricadi_ctx* ctx, const double* dW, int nrows, int m,
  * events on the context stream: which = 0 SpMM.                            */
 int ricadi_time_spmm_dev(ricadi_ctx* ctx, double alpha, double beta, const double* dX,
                          int m, double* dY, int reps, double* ms_per_launch);
+/* The same for the batched launch of the hot path: ng panels (dX + g*n*m ->
+ * dY + g*n*m), shift g = (alphas[g], betas[g]); one launch covers all of them. */
+int ricadi_time_spmm_batch_dev(ricadi_ctx* ctx, int ng, const double* alphas,
+                               const double* betas, const double* dX, int m,
+                               double* dY, int reps, double* ms_per_launch);
 
 /* K5: thin QR factorisation Z = Q R of an NV x c host matrix (c <= NV) by block
  * Gram-Schmidt with re-orthogonalisation over 32-column panels, each panel

@@ -75,6 +75,8 @@ SIGNATURES = {
                                          C.POINTER(C.c_int), _dp]),
     "ricadi_shift_solve_batch_dev": (C.c_int, [_vp, C.c_int, _dp, _dp, _vp, C.c_int64, C.c_int, _vp,
                                                C.POINTER(C.c_int), _dp]),
+    "ricadi_time_spmm_batch_dev": (C.c_int, [_vp, C.c_int, _dp, _dp, _vp, C.c_int, _vp, C.c_int,
+                                             C.POINTER(C.c_double)]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
@@ -446,6 +448,15 @@ class Context:
                                                     int(r_stride), m, x_ptr, its, _d(rr))
         _chk(rc, allow_noconv=not strict)
         return list(its), rr
+
+    def time_spmm_batch_dev(self, alphas, betas, x_ptr, m, y_ptr, reps):
+        """Milliseconds per batched saddle-SpMM launch (ng panels, one shift each)."""
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        ms = C.c_double(0.0)
+        _chk(self._lib.ricadi_time_spmm_batch_dev(self._h, al.size, _d(al), _d(be), x_ptr, m, y_ptr,
+                                                  reps, C.byref(ms)))
+        return ms.value
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):
         _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))

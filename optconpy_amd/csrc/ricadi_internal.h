@@ -97,19 +97,38 @@ inline GroupPtrsT<T> same_ptr(const T* q) {
   return g;
 }
 
+// Coarse-level prolongation fused into a block-Jacobi sweep: every row the sweep
+// writes gets  + ec[aggof[row], :]  (ec: kc x m per group, stride gse), and surplus
+// waves do the same for rows [row0, row0 + nextra) outside the blocks.
+struct ProlongArgs {
+  const int* aggof = nullptr;
+  const double* ec = nullptr;
+  size_t gse = 0;
+  int row0 = 0, nextra = 0;
+};
+
+// Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for
+// row < nrows, with c = V^T x (q x m per group, stride gsc) reduced beforehand.
+struct LowRankArgs {
+  const double* U = nullptr;
+  const double* c = nullptr;
+  size_t gsc = 0;
+  int q = 0, nrows = 0;
+};
+
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
 // The *_b launchers are the batched forms (GroupTab + group strides `gs*`, in
 // doubles); the plain ones run a single panel.
 void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
-                   double alpha, double beta_r, int m);
+                   double alpha, double beta_r, int m, const LowRankArgs& lr = LowRankArgs());
 void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rowptr,
                            const int* rows, const int* rp, const int* cptr, const int* cols,
                            const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
                            size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
                            const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
-                           int max_cols, int max_nnz);
+                           int max_cols, int max_nnz, const LowRankArgs& lr = LowRankArgs());
 void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
                     size_t gsx, double b, double* y, size_t gsy);
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
@@ -140,14 +159,16 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
                           double* out, size_t gso);
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
-                         double* g, double* scale, double* resid, const double* bnorm, double tol);
+                         double* g, double* scale, double* resid, const double* bnorm, double tol,
+                         double* host_resid = nullptr);
 void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, int k, int restart,
                               const double* H, const double* g, double* y);
 void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart,
                           const double* nrm2, double* g, double* scale, double* resid);
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrs& inv, const double* in, int ldi,
-                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract);
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
+                          const ProlongArgs& pa = ProlongArgs());
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
                           const double* rc, double* ec);
 // FP32-stored inverses (leading dimension ldf = k rounded up to 4; bs x bs blocks)
@@ -155,7 +176,8 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
                           int ldf, const double* rc, double* ec);
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
-                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract);
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
+                          const ProlongArgs& pa = ProlongArgs());
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
 void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,

@@ -43,18 +43,29 @@ __device__ __forceinline__ double bc16d(double v) {
 // (col,val) loads are group-uniform (one request), the x-row load is one
 // coalesced 128-B line per 16 columns.
 // ---------------------------------------------------------------------------
+// Low-rank epilogue shared by the SpMM kernels:  (U (V^T x))[row, col] with the
+// q x m coefficients V^T x already reduced (lrc).  q is small (the number of inputs).
+__device__ __forceinline__ double lowrank_term(const LowRankArgs& lr, const double* __restrict__ lrc,
+                                               int row, int col, int m) {
+  const double* __restrict__ u = lr.U + (size_t)row * lr.q;
+  double s = 0.0;
+  for (int k = 0; k < lr.q; ++k) s = fma(u[k], lrc[k * m + col], s);
+  return s;
+}
+
 template <int CPL>
 __global__ __launch_bounds__(256) void spmm_kernel(
     GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
     GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
     const int* __restrict__ xmap, double* __restrict__ y, int ldy, size_t gsy,
     const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
-    const double* __restrict__ rowscale, int m) {
+    const double* __restrict__ rowscale, int m, LowRankArgs lr) {
   const int grp = gt.gid[blockIdx.z];
   const double* __restrict__ val = vals.p[grp];
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
   if (r) r += (size_t)grp * gsr;
+  const double* __restrict__ lrc = lr.c + (size_t)grp * lr.gsc;
   const int g = threadIdx.x & 15;
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (row >= nrows) return;
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(
     if (col < m) {
       double out = sc * acc[c];
       if (r) out += beta_r * r[(size_t)row * ldr + col];
+      if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, col, m);
       y[(size_t)row * ldy + col] = out;
     }
   }
@@ -115,12 +127,13 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
     GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
     const int* __restrict__ xmap, double* __restrict__ y, int ldy, size_t gsy,
     const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
-    const double* __restrict__ rowscale, int m) {
+    const double* __restrict__ rowscale, int m, LowRankArgs lr) {
   const int grp = gt.gid[blockIdx.z];
   const double* __restrict__ val = vals.p[grp];
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
   if (r) r += (size_t)grp * gsr;
+  const double* __restrict__ lrc = lr.c + (size_t)grp * lr.gsc;
   // bijective XCD remap of the block index (cdna guide, T1)
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -169,6 +182,7 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
     if (col < m) {
       double out = sc * acc[c];
       if (r) out += beta_r * r[(size_t)row * ldr + col];
+      if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, col, m);
       y[(size_t)row * ldy + col] = out;
     }
   }
@@ -187,7 +201,7 @@ static void spmm_dispatch(hipStream_t st, const GroupTab& gt, int nrows, const i
                           const int* ci, const GroupPtrs& vals, const double* x, int ldx,
                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
                           const double* r, int ldr, size_t gsr, double alpha, double beta_r,
-                          const double* rowscale, int m) {
+                          const double* rowscale, int m, const LowRankArgs& lr = LowRankArgs()) {
   if (nrows <= 0 || m <= 0 || gt.ng <= 0) return;
   dim3 grid((nrows + 15) / 16, 1, gt.ng), block(256);
   const int cpl = (m + 15) / 16;
@@ -197,11 +211,11 @@ static void spmm_dispatch(hipStream_t st, const GroupTab& gt, int nrows, const i
     if (v2)                                                                              \
       hipLaunchKernelGGL(spmm_kernel_v2<C>, grid, block, 0, st, gt, nrows, rp, ci, vals, \
                          x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r,     \
-                         rowscale, m);                                                   \
+                         rowscale, m, lr);                                               \
     else                                                                                 \
       hipLaunchKernelGGL(spmm_kernel<C>, grid, block, 0, st, gt, nrows, rp, ci, vals, x, \
                          ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r,        \
-                         rowscale, m);                                                   \
+                         rowscale, m, lr);                                               \
     break;
   switch (cpl) {
     RICADI_SPMM_CASE(1)
@@ -227,9 +241,9 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
 void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
-                   double alpha, double beta_r, int m) {
+                   double alpha, double beta_r, int m, const LowRankArgs& lr) {
   spmm_dispatch(st, gt, nrows, rp, ci, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha,
-                beta_r, nullptr, m);
+                beta_r, nullptr, m, lr);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,13 +269,19 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
     const double* __restrict__ x, int ldx, size_t gsx, const int* __restrict__ xmap,
     double* __restrict__ y, int ldy, size_t gsy, const double* __restrict__ r, int ldr,
-    size_t gsr, double alpha, double beta_r, int m, int max_cols, int max_nnz) {
+    size_t gsr, double alpha, double beta_r, int m, int max_cols, int max_nnz, LowRankArgs lr) {
   extern __shared__ double xs[];                             // max_cols x m
+  // Groups ride in grid.z (group-major dispatch: consecutive workgroups are
+  // neighbouring row blocks of ONE panel, whose gathered x rows overlap -- walking
+  // the groups fastest instead, to share the matrix slice in L2, measured 13 %
+  // slower, and building the values from shared (beta*A + J, E) arrays another 10 %:
+  // the kernel is bound by the latency of its dependent gathers, not by HBM bytes).
   const int grp = gt.gid[blockIdx.z];
   const double* __restrict__ val = vals.p[grp];
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
   if (r) r += (size_t)grp * gsr;
+  const double* __restrict__ lrc = lr.c + (size_t)grp * lr.gsc;
   // XCD-contiguous block ranges (bijective remap, cdna guide T1)
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -386,6 +406,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
         const int row = rows[q0 + q];
         double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (r) out += beta_r * r[(size_t)row * ldr + cc];
+        if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, cc, m);
         y[(size_t)row * ldy + cc] = out;
       }
     }
@@ -401,12 +422,12 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
                            const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
                            size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
                            const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
-                           int max_cols, int max_nnz) {
+                           int max_cols, int max_nnz, const LowRankArgs& lr) {
   if (nblk <= 0 || gt.ng <= 0) return;
   hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk, 1, gt.ng), dim3(256),
                      spmm_blocked_lds_bytes(m, max_cols, max_nnz), st, rowptr, rows, rp, cptr, cols,
                      lidx, gt, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m,
-                     max_cols, max_nnz);
+                     max_cols, max_nnz, lr);
 }
 void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
                          const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
@@ -414,7 +435,8 @@ void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int*
                          int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
                          int max_cols, int max_nnz) {
   launch_spmm_blocked_b(st, single_group(), nblk, rowptr, rows, rp, cptr, cols, lidx, same_ptr(val),
-                        x, ldx, 0, xmap, y, ldy, 0, r, ldr, 0, alpha, beta_r, m, max_cols, max_nnz);
+                        x, ldx, 0, xmap, y, ldy, 0, r, ldr, 0, alpha, beta_r, m, max_cols, max_nnz,
+                        LowRankArgs());
 }
 
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)
@@ -822,8 +844,10 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     GroupTab gt, int m, int j, int restart, const double* __restrict__ h1,
     const double* __restrict__ h2, double* __restrict__ H, double* __restrict__ cs,
     double* __restrict__ sn, double* __restrict__ g, double* __restrict__ scale,
-    double* __restrict__ resid, const double* __restrict__ bnorm, double tol) {
+    double* __restrict__ resid, const double* __restrict__ bnorm, double tol,
+    double* __restrict__ host_resid) {
   extern __shared__ double sh[];       // hcol[restart+2], csl[restart], snl[restart]
+  if (host_resid) host_resid += (size_t)gt.gid[blockIdx.z] * m;
   {
     // group-major state: every array holds one slab per group
     const size_t grp = (size_t)gt.gid[blockIdx.z];
@@ -892,21 +916,25 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     gc[j] = 0.0;
   }
   scale[c] = (hnext > tiny) ? 1.0 / hnext : 0.0;
-  resid[c] = (d > tiny) ? fabs(sj * gj) : 0.0;
+  const double rnew = (d > tiny) ? fabs(sj * gj) : 0.0;
+  resid[c] = rnew;
+  // pinned host copy for the (lagged) convergence check: saves a D2H copy per iteration
+  if (host_resid) host_resid[c] = rnew;
 }
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
-                         double* g, double* scale, double* resid, const double* bnorm, double tol) {
+                         double* g, double* scale, double* resid, const double* bnorm, double tol,
+                         double* host_resid) {
   if (gt.ng <= 0) return;
   hipLaunchKernelGGL(gmres_hess_kernel, dim3(m, 1, gt.ng), dim3(64),
                      (3 * restart + 4) * sizeof(double), st, gt, m, j, restart, h1, h2, H, cs, sn, g,
-                     scale, resid, bnorm, tol);
+                     scale, resid, bnorm, tol, host_resid);
 }
 void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
                        const double* h2, double* H, double* cs, double* sn, double* g,
                        double* scale, double* resid, const double* bnorm, double tol) {
   launch_gmres_hess_b(st, single_group(), m, j, restart, h1, h2, H, cs, sn, g, scale, resid, bnorm,
-                      tol);
+                      tol, nullptr);
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
@@ -992,20 +1020,31 @@ template <int BS, class T>
 __global__ __launch_bounds__(256) void block_apply_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
     GroupPtrsT<T> invs, const double* __restrict__ in, int ldi, size_t gsi,
-    double* __restrict__ out, int ldo, size_t gso, int m, int subtract) {
+    double* __restrict__ out, int ldo, size_t gso, int m, int subtract, ProlongArgs pa) {
   const int grp = gt.gid[blockIdx.z];
   const T* __restrict__ inv = invs.p[grp];
   in += (size_t)grp * gsi;
   out += (size_t)grp * gso;
+  const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
   // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
   // inv[rows 16*ti.., k] * x[k, cols].  A-operand lane (r = l&15, q = l>>4)
   // holds inv[16*ti + r][k0 + 4q + s] for MFMA s of a 16-wide k chunk (one
   // 32-B load per lane and chunk); the matching B operand is the gathered
   // input row rows[k0 + 4q + s], column c0 + r.
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wave >= nblocks) return;
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, q = lane >> 4;
+  if (wave >= nblocks) {
+    // surplus waves: coarse-level prolongation of the rows outside the blocks
+    // (the pressure rows when this is the last velocity sweep), 32 rows per wave
+    const int e0 = (wave - nblocks) * 32;
+    for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
+      const int row = pa.row0 + rr;
+      for (int col = r; col < m; col += 16)
+        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+    }
+    return;
+  }
   const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
   const T* Bi = inv + (size_t)wave * BS * BS;
   constexpr int NT = BS / 16;
@@ -1038,8 +1077,11 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
       for (int e = 0; e < 4; ++e) {
         const int il = 16 * t + q + 4 * e;
         if (il < nb && col < m) {
-          double* o = &out[(size_t)rows[b0 + il] * ldo + col];
-          *o = subtract ? *o - acc[t][e] : acc[t][e];
+          const int row = rows[b0 + il];
+          double* o = &out[(size_t)row * ldo + col];
+          double v = subtract ? *o - acc[t][e] : acc[t][e];
+          if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
+          *o = v;
         }
       }
   }
@@ -1047,39 +1089,43 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
 template <class T>
 static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                              const int* rows, const GroupPtrsT<T>& inv, const double* in, int ldi,
-                             size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
+                             size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
+                             const ProlongArgs& pa) {
   if (nblocks <= 0 || gt.ng <= 0) return;
-  dim3 grid((nblocks + 3) / 4, 1, gt.ng), block(256);
+  const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
+  dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
   switch (bs) {
     case 16:
       hipLaunchKernelGGL((block_apply_kernel<16, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
       break;
     case 32:
       hipLaunchKernelGGL((block_apply_kernel<32, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
       break;
     default:
       hipLaunchKernelGGL((block_apply_kernel<64, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
       break;
   }
 }
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrs& inv, const double* in, int ldi,
-                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
-  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
+                          const ProlongArgs& pa) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
 }
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
-                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract) {
-  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract);
+                          size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
+                          const ProlongArgs& pa) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
 }
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
                         const double* inv, const double* in, int ldi, double* out, int ldo,
                         int m, int subtract) {
   launch_block_apply_b(st, single_group(), bs, nblocks, bptr, rows, same_ptr(inv), in, ldi, 0, out,
-                       ldo, 0, m, subtract);
+                       ldo, 0, m, subtract, ProlongArgs());
 }
 
 // blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)

@@ -365,7 +365,7 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* sd, int m) { return make_batch
 // gsx / gsy / gsr: group strides of x, y, r.
 static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx,
                         const int* xmap, double* y, size_t gsy, const double* r, size_t gsr,
-                        double alpha, double beta_r) {
+                        double alpha, double beta_r, const LowRankArgs& lr = LowRankArgs()) {
   static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
   const int m = bt.m;
   const bool fits =
@@ -374,10 +374,10 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
   if (fits)
     launch_spmm_blocked_b(c->st, bt.tab, c->sb_nblk, c->sb_rowptr.p, c->sb_rows.p, c->sb_rp.p,
                           c->sb_cptr.p, c->sb_cols.p, c->sb_lidx.p, bt.svalb, x, m, gsx, xmap, y, m,
-                          gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, c->sb_max_nnz);
+                          gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, c->sb_max_nnz, lr);
   else
     launch_spmm_b(c->st, bt.tab, c->n, c->s_rp.p, c->s_ci.p, bt.sval, x, m, gsx, xmap, y, m, gsy, r,
-                  m, gsr, alpha, beta_r, m);
+                  m, gsr, alpha, beta_r, m, lr);
 }
 
 // y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
@@ -386,13 +386,18 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
                      bool lowrank) {
   hipStream_t st = c->st;
   const int m = bt.m;
-  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0);
+  LowRankArgs lr;
   if (lowrank && c->q > 0) {
+    // coefficients V^T x first; the product with U rides in the SpMM's epilogue
     HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * bt.gsq * bt.G, st));
     launch_gemm_tn_b(st, bt.tab, c->nv, c->q, m, c->V.p, c->q, x, m, gsx, c->lrc.p, m, bt.gsq);
-    launch_gemm_nn_b(st, bt.tab, c->nv, c->q, m, c->U.p, c->q, c->lrc.p, m, bt.gsq, y, m, bt.gs, -1.0,
-                     1.0);
+    lr.U = c->U.p;
+    lr.c = c->lrc.p;
+    lr.gsc = bt.gsq;
+    lr.q = c->q;
+    lr.nrows = c->nv;
   }
+  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0, lr);
 }
 
 // z = P^-1 r for every active group: multiplicative two-level, coarse correction
@@ -418,15 +423,26 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     rr = c->r2.p;
     gsrr = bt.gs;
   }
-  auto vel_apply = [&](const double* in, size_t gsi, int subtract) {
+  // the LAST velocity sweep also adds the coarse correction Y ec to all of z
+  // (its surplus waves take the pressure rows)
+  ProlongArgs pro;
+  if (c->kc > 0) {
+    pro.aggof = c->aggof.p;
+    pro.ec = c->ec.p;
+    pro.gse = bt.gsc;
+    pro.row0 = nv;
+    pro.nextra = np;
+  }
+  auto vel_apply = [&](const double* in, size_t gsi, int subtract, bool last) {
+    const ProlongArgs pa = last ? pro : ProlongArgs();
     if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, in, m, gsi, z,
-                           m, bt.gs, m, subtract);
+                           m, bt.gs, m, subtract, pa);
     else
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, in, m, gsi, z,
-                           m, bt.gs, m, subtract);
+                           m, bt.gs, m, subtract, pa);
   };
-  vel_apply(rr, gsrr, 0);
+  vel_apply(rr, gsrr, 0, np == 0);
   if (np > 0) {
     // t = J z_v - r_p
     launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
@@ -442,9 +458,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
     launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
                   nullptr, 0, 0, 1.0, 0.0, m);
-    vel_apply(tmp, bt.gs, 1);
+    vel_apply(tmp, bt.gs, 1, true);
   }
-  if (c->kc > 0) launch_prolong_add_b(st, gt, c->n, m, c->aggof.p, c->ec.p, bt.gsc, z, bt.gs);
 }
 
 static void op_apply(ricadi_ctx* c, ShiftData* sd, const double* x, double* y, int m, bool lowrank) {
@@ -594,8 +609,11 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
         launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, V, vs, nm, c->h1.p, gsh, c->wv.p, nm,
                                   c->partial.p, gspart, c->h2.p, gsh);
       }
+      // the residual estimates also go straight to a pinned host slot (read one
+      // iteration later, behind the event below)
+      double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
       launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p,
-                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol);
+                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur);
       if (b32)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, c->vcur.p, nm, Vf + (size_t)(j + 1) * vs, nm);
@@ -605,8 +623,6 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       // Residual estimates travel to a pinned slot behind an event; the host
       // looks at the PREVIOUS iteration's slot, so it never drains the stream
       // (one iteration of lag: at most one surplus Arnoldi step per group).
-      double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
-      HIPCHK(hipMemcpyAsync(cur, c->resid.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
       HIPCHK(hipEventRecord(c->ev_res[j & 1], st));
       for (int g : live) {
         ++res[g].iters;
@@ -1443,6 +1459,32 @@ int ricadi_time_spmm_dev(ricadi_ctx* c, double alpha, double beta, const double*
   // plain assembled-CSR saddle SpMM only (no low-rank term): the roofline kernel
   HIPCHK(hipEventRecord(e0, c->st));
   const Batch bt = make_batch(c, sd, m);
+  for (int i = 0; i < reps; ++i) saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
+  HIPCHK(hipEventRecord(e1, c->st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  API_END
+}
+
+int ricadi_time_spmm_batch_dev(ricadi_ctx* c, int ng, const double* alphas, const double* betas,
+                               const double* dX, int m, double* dY, int reps, double* ms_per_launch) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dX && dY && alphas && betas && reps > 0 && ms_per_launch, RICADI_EINVAL, "bad argument");
+  REQUIRE(ng >= 1 && ng <= RICADI_MAX_GROUPS, RICADI_EINVAL, "1 <= ng <= 16 required");
+  API_BEGIN
+  std::vector<ShiftData*> sds(ng);
+  get_shifts(c, alphas, betas, ng, sds.data());
+  const Batch bt = make_batch(c, sds.data(), ng, m);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  // the saddle SpMM exactly as the batched GMRES launches it (no low-rank term)
+  saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
+  HIPCHK(hipEventRecord(e0, c->st));
   for (int i = 0; i < reps; ++i) saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
   HIPCHK(hipEventRecord(e1, c->st));
   HIPCHK(hipEventSynchronize(e1));

@@ -1,5 +1,5 @@
 """Batched vs per-shift solves at cfg2: wall time of one sweep of G shifts.  python tools/batch_probe.py [N]"""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
 from optconpy_amd import _lib, problems as pb
@@ -21,6 +21,10 @@ for G in ([int(a) for a in sys.argv[2:]] or [1, 2, 4, 8, 16]):
         its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * G, W.data_ptr(), 0, m, X.data_ptr(), strict=False)
         ctx.synchronize()
         dt = time.time() - t0
+    if os.environ.get("BATCH_ONLY"):
+        print("G=%2d: batched %.1f ms (its %s, max relres %.1e) | %.1f us per group-iteration, %.0f us per lockstep iteration"
+              % (G, 1e3 * dt, its, rr.max(), 1e6 * dt / max(sum(its), 1), 1e6 * dt / max(its)), flush=True)
+        continue
     t0 = time.time()
     it1 = 0
     Y = torch.empty(ctx.n, m, dtype=torch.float64, device=dev)
