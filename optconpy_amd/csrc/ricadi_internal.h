@@ -123,12 +123,12 @@ void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
                    double alpha, double beta_r, int m, const LowRankArgs& lr = LowRankArgs());
-void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rowptr,
-                           const int* rows, const int* rp, const int* cptr, const int* cols,
-                           const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
-                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
-                           const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
-                           int max_cols, int max_nnz, const LowRankArgs& lr = LowRankArgs());
+void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2,
+                           const int* rp2, const int* cols2, const uint16_t* lidx,
+                           const GroupPtrs& vals, const double* x, int ldx, size_t gsx, double* y,
+                           int ldy, size_t gsy, const double* r, int ldr, size_t gsr, double alpha,
+                           double beta_r, int m, int max_cols,
+                           const LowRankArgs& lr = LowRankArgs());
 void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
                     size_t gsx, double b, double* y, size_t gsy);
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
@@ -190,11 +190,6 @@ void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, c
 void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const double* val,
                  const double* x, int ldx, const int* xmap, double* y, int ldy, const double* r,
                  int ldr, double alpha, double beta_r, const double* rowscale, int m);
-void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
-                         const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
-                         const double* val, const double* x, int ldx, const int* xmap, double* y,
-                         int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
-                         int max_cols, int max_nnz);
 size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz);
 void launch_gather_vals(hipStream_t st, int nnz, const int* perm, const double* src, double* dst);
 void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const double* srcE,

@@ -263,13 +263,18 @@ void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
 // A row of x is thus read from L2/HBM once per block instead of once per
 // non-zero (the v2 kernel re-gathers every row ~28 times through the vector L1).
 // ---------------------------------------------------------------------------
+// Block metadata comes PADDED to fixed strides -- rows2[b][32] (global row, -1 =
+// none), rp2[b][33] (entry ranges in block order), cols2[b][max_cols] (gathered x
+// row per tile slot, -1 = none; for the coarse-residual launch the aggregate map is
+// already applied) -- so every address of the first round of loads follows from
+// the block index alone: the kernel is bound by the latency of its dependent
+// loads, and this removes one full round trip (block pointers -> row/column lists).
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ rows, const int* __restrict__ rp,
-    const int* __restrict__ cptr, const int* __restrict__ cols,
+    const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
-    const double* __restrict__ x, int ldx, size_t gsx, const int* __restrict__ xmap,
+    const double* __restrict__ x, int ldx, size_t gsx,
     double* __restrict__ y, int ldy, size_t gsy, const double* __restrict__ r, int ldr,
-    size_t gsr, double alpha, double beta_r, int m, int max_cols, int max_nnz, LowRankArgs lr) {
+    size_t gsr, double alpha, double beta_r, int m, int max_cols, LowRankArgs lr) {
   extern __shared__ double xs[];                             // max_cols x m
   // Groups ride in grid.z (group-major dispatch: consecutive workgroups are
   // neighbouring row blocks of ONE panel, whose gathered x rows overlap -- walking
@@ -287,20 +292,20 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
   const int b = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
   const int g = threadIdx.x & 15, gq = threadIdx.x >> 4;
-  const int c0 = cptr[b], nc = cptr[b + 1] - c0;
-  const int q0 = rowptr[b], nr = rowptr[b + 1] - q0;
+  const int* __restrict__ bcols = cols2 + (size_t)b * max_cols;
   // phase 0: the (value, local index) pairs of this group's two rows (blocks
   // hold <= 32 rows) are requested FIRST, 16 per lane-row and chunk, so that
   // they are in flight together with the x-tile gathers of phase 1.
   constexpr int NR = 2, NCH = 3;               // rows per group, 16-entry chunks held in registers
-  int ka[NR], kb[NR];
+  int ka[NR], kb[NR], grow[NR];
   double myv[NR][NCH];
   int myl[NR][NCH];
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
     const int q = gq + 16 * rr;
-    ka[rr] = (q < nr) ? rp[q0 + q] : 0;
-    kb[rr] = (q < nr) ? rp[q0 + q + 1] : 0;
+    ka[rr] = rp2[b * 33 + q];
+    kb[rr] = rp2[b * 33 + q + 1];
+    grow[rr] = rows2[b * 32 + q];
   }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr)
@@ -316,22 +321,20 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   // its own ds_write makes hipcc wait vmcnt(0) per row).
   constexpr int XJ = 5;                        // 16 groups x 5 = 80 tile rows per pass
   for (int cc = g; cc < m; cc += 16) {
-    for (int jb = 0; jb < nc; jb += 16 * XJ) {
+    for (int jb = 0; jb < max_cols; jb += 16 * XJ) {
       int cidx[XJ];
       double xv[XJ];
 #pragma unroll
       for (int t = 0; t < XJ; ++t) {
         const int j = jb + gq + 16 * t;
-        int c = (j < nc) ? cols[c0 + j] : -1;
-        if (xmap && c >= 0) c = xmap[c];
-        cidx[t] = c;
+        cidx[t] = (j < max_cols) ? bcols[j] : -1;
       }
 #pragma unroll
       for (int t = 0; t < XJ; ++t) xv[t] = (cidx[t] >= 0) ? x[(size_t)cidx[t] * ldx + cc] : 0.0;
 #pragma unroll
       for (int t = 0; t < XJ; ++t) {
         const int j = jb + gq + 16 * t;
-        if (j < nc) xs[j * m + cc] = xv[t];
+        if (cidx[t] >= 0) xs[j * m + cc] = xv[t];
       }
     }
   }
@@ -370,8 +373,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr) {
-    const int q = gq + 16 * rr;
-    const bool live = q < nr;
+    const bool live = grow[rr] >= 0;
     // chunks needed by any of the wave's four groups (DPP needs all lanes)
     int nch = (kb[rr] - ka[rr] + 15) >> 4;
     nch = max(nch, __shfl_xor(nch, 16, 64));
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
         RICADI_FOR16(RICADI_TILE_STEP)
       }
       if (live && cc < m) {
-        const int row = rows[q0 + q];
+        const int row = grow[rr];
         double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (r) out += beta_r * r[(size_t)row * ldr + cc];
         if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, cc, m);
@@ -417,26 +419,15 @@ size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz) {
   (void)max_nnz;
   return (size_t)max_cols * m * sizeof(double) + 16;
 }
-void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rowptr,
-                           const int* rows, const int* rp, const int* cptr, const int* cols,
-                           const uint16_t* lidx, const GroupPtrs& vals, const double* x, int ldx,
-                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
-                           const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
-                           int max_cols, int max_nnz, const LowRankArgs& lr) {
+void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2,
+                           const int* rp2, const int* cols2, const uint16_t* lidx,
+                           const GroupPtrs& vals, const double* x, int ldx, size_t gsx, double* y,
+                           int ldy, size_t gsy, const double* r, int ldr, size_t gsr, double alpha,
+                           double beta_r, int m, int max_cols, const LowRankArgs& lr) {
   if (nblk <= 0 || gt.ng <= 0) return;
   hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk, 1, gt.ng), dim3(256),
-                     spmm_blocked_lds_bytes(m, max_cols, max_nnz), st, rowptr, rows, rp, cptr, cols,
-                     lidx, gt, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m,
-                     max_cols, max_nnz, lr);
-}
-void launch_spmm_blocked(hipStream_t st, int nblk, const int* rowptr, const int* rows,
-                         const int* rp, const int* cptr, const int* cols, const uint16_t* lidx,
-                         const double* val, const double* x, int ldx, const int* xmap, double* y,
-                         int ldy, const double* r, int ldr, double alpha, double beta_r, int m,
-                         int max_cols, int max_nnz) {
-  launch_spmm_blocked_b(st, single_group(), nblk, rowptr, rows, rp, cptr, cols, lidx, same_ptr(val),
-                        x, ldx, 0, xmap, y, ldy, 0, r, ldr, 0, alpha, beta_r, m, max_cols, max_nnz,
-                        LowRankArgs());
+                     spmm_blocked_lds_bytes(m, max_cols, 0), st, rows2, rp2, cols2, lidx, gt, vals, x,
+                     ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, lr);
 }
 
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)

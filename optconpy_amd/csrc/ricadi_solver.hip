@@ -113,7 +113,10 @@ struct ricadi_ctx {
   // LDS-tiled SpMM structure
   int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
   bool sb_ok = false;
-  DArr<int> sb_rowptr, sb_rows, sb_rp, sb_cptr, sb_cols, sb_perm;
+  DArr<int> sb_perm;
+  // block metadata padded to fixed strides (see spmm_blocked_kernel): rows2 [nblk][32],
+  // rp2 [nblk][33], cols2 [nblk][sb_max_cols], colsm2 = cols2 through the aggregate map
+  DArr<int> sb_rows2, sb_rp2, sb_cols2, sb_colsm2;
   DArr<uint16_t> sb_lidx;
   // low rank
   int q = 0;
@@ -372,9 +375,9 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
       c->sb_ok && !force_csr &&
       spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
   if (fits)
-    launch_spmm_blocked_b(c->st, bt.tab, c->sb_nblk, c->sb_rowptr.p, c->sb_rows.p, c->sb_rp.p,
-                          c->sb_cptr.p, c->sb_cols.p, c->sb_lidx.p, bt.svalb, x, m, gsx, xmap, y, m,
-                          gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, c->sb_max_nnz, lr);
+    launch_spmm_blocked_b(c->st, bt.tab, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
+                          xmap ? c->sb_colsm2.p : c->sb_cols2.p, c->sb_lidx.p, bt.svalb, x, m, gsx, y,
+                          m, gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, lr);
   else
     launch_spmm_b(c->st, bt.tab, c->n, c->s_rp.p, c->s_ci.p, bt.sval, x, m, gsx, xmap, y, m, gsy, r,
                   m, gsr, alpha, beta_r, m, lr);
@@ -1211,11 +1214,41 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->sb_nblk = hs.sb_nblk;
   c->sb_max_cols = hs.sb_max_cols;
   c->sb_max_nnz = hs.sb_max_nnz;
-  c->sb_rowptr.upload(hs.sb_rowptr, st);
-  c->sb_rows.upload(hs.sb_rows, st);
-  c->sb_rp.upload(hs.sb_rp, st);
-  c->sb_cptr.upload(hs.sb_cptr, st);
-  c->sb_cols.upload(hs.sb_cols, st);
+  {
+    const int nb = hs.sb_nblk, mc = std::max(hs.sb_max_cols, 1);
+    std::vector<int> rows2((size_t)nb * 32, -1), rp2((size_t)nb * 33, 0), cols2((size_t)nb * mc, -1),
+        colsm2((size_t)nb * mc, -1);
+    for (int b = 0; b < nb; ++b) {
+      const int q0 = hs.sb_rowptr[b], nr = hs.sb_rowptr[b + 1] - q0;
+      for (int q = 0; q <= 32; ++q) rp2[(size_t)b * 33 + q] = hs.sb_rp[q0 + std::min(q, nr)];
+      for (int q = 0; q < nr; ++q) rows2[(size_t)b * 32 + q] = hs.sb_rows[q0 + q];
+      const int c0 = hs.sb_cptr[b], nc = hs.sb_cptr[b + 1] - c0;
+      for (int j = 0; j < nc; ++j) {
+        cols2[(size_t)b * mc + j] = hs.sb_cols[c0 + j];
+        colsm2[(size_t)b * mc + j] = hs.kc > 0 ? hs.aggof[hs.sb_cols[c0 + j]] : -1;
+      }
+    }
+    // developer ablations of the tile SpMM (wrong results, timing only):
+    //   RICADI_ABL=c: every block gathers the same x rows; =v: every block reads block 0's
+    //   matrix slice; =r: every block writes the same y rows
+    if (const char* e = getenv("RICADI_ABL")) {
+      for (int b = 0; b < nb; ++b) {
+        if (strchr(e, 'c'))
+          for (int j = 0; j < mc; ++j)
+            if (cols2[(size_t)b * mc + j] >= 0) cols2[(size_t)b * mc + j] = j;
+        if (strchr(e, 'v'))
+          for (int q = 0; q <= 32; ++q)
+            rp2[(size_t)b * 33 + q] = std::min(rp2[q], rp2[32]);
+        if (strchr(e, 'r'))
+          for (int q = 0; q < 32; ++q)
+            if (rows2[(size_t)b * 32 + q] >= 0) rows2[(size_t)b * 32 + q] = q;
+      }
+    }
+    c->sb_rows2.upload(rows2, st);
+    c->sb_rp2.upload(rp2, st);
+    c->sb_cols2.upload(cols2, st);
+    c->sb_colsm2.upload(colsm2, st);
+  }
   c->sb_perm.upload(hs.sb_perm, st);
   c->sb_lidx.upload(hs.sb_lidx, st);
   c->sb_ok = hs.sb_nblk > 0 && hs.sb_max_cols < 65536;
