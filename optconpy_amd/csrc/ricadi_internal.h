@@ -184,6 +184,10 @@ void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
                           const double* ec, size_t gse, double* z, size_t gsz);
 void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
                       int lda, const double* B, int ldb, size_t gsB, double* C, int ldc, size_t gsC);
+// A given per group (A[g] is n x p, leading dimension lda)
+void launch_gemm_nn_bp(hipStream_t st, const GroupTab& gt, int n, int p, int q, const GroupPtrs& A,
+                       int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
+                       double alpha, double beta);
 void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
                       int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
                       double alpha, double beta);

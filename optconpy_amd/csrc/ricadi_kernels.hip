@@ -1611,12 +1611,14 @@ void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, c
 // A wave owns 16 rows x (16*TJ) columns.  A-operand: A[r0 + (l&15)][k + (l>>4)].
 template <int TJ>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GroupTab gt, int n, int p, int q,
-                                                      const double* __restrict__ A, int lda,
+                                                      GroupPtrs As, int lda,
                                                       const double* __restrict__ C, int ldc,
                                                       size_t gsC, double* __restrict__ Y, int ldy,
                                                       size_t gsY, double alpha, double beta) {
+  const double* __restrict__ A;
   {
     const int grp = gt.gid[blockIdx.z];
+    A = As.p[grp];
     C += (size_t)grp * gsC;
     Y += (size_t)grp * gsY;
   }
@@ -1652,13 +1654,18 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GroupTab gt, int n, int p,
       }
     }
 }
-void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
-                      int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
-                      double alpha, double beta) {
+void launch_gemm_nn_bp(hipStream_t st, const GroupTab& gt, int n, int p, int q, const GroupPtrs& A,
+                       int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
+                       double alpha, double beta) {
   if (n <= 0 || q <= 0 || gt.ng <= 0) return;
   dim3 grid((n + 63) / 64, (q + 31) / 32, gt.ng), block(256);
   hipLaunchKernelGGL((gemm_nn_kernel<2>), grid, block, 0, st, gt, n, p, q, A, lda, C, ldc, gsC, Y,
                      ldy, gsY, alpha, beta);
+}
+void launch_gemm_nn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
+                      int lda, const double* C, int ldc, size_t gsC, double* Y, int ldy, size_t gsY,
+                      double alpha, double beta) {
+  launch_gemm_nn_bp(st, gt, n, p, q, same_ptr(A), lda, C, ldc, gsC, Y, ldy, gsY, alpha, beta);
 }
 void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
                     int ldc, double* Y, int ldy, double alpha, double beta) {

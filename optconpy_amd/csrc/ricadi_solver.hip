@@ -74,6 +74,10 @@ struct ShiftData {
   // operator either way; halves its HBM traffic).  einvf has leading dimension kc
   // rounded up to 4.  RICADI_PRECOND64=1 applies the FP64 originals instead.
   DArr<float> bvinvf, bpinvf, einvf;
+  // Sherman-Morrison-Woodbury data for the current low-rank term (ctx->lr_epoch):
+  // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
+  DArr<double> smw_w;
+  long smw_epoch = -1;
 };
 
 struct DevCsr {
@@ -121,6 +125,9 @@ struct ricadi_ctx {
   // low rank
   int q = 0;
   DArr<double> U, V, lrc, scratch;
+  long lr_epoch = 0;          // bumped whenever U / V change
+  bool smw = true;            // RICADI_SMW=0: keep the low-rank term inside the Krylov operator
+  DArr<double> smw_rhs, smw_x, smw_cap;
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
@@ -154,11 +161,16 @@ namespace ricadi {
 // Workspace for batches of up to `groups` panels of width m (group-major: every
 // buffer holds one slab per group; basis is vector-major, i.e. Krylov vector j of
 // all groups is contiguous).
-static void ensure_work(ricadi_ctx* c, int m, int groups = 1) {
+// `extra` columns per group are reserved on top of m (default: the low-rank width, for
+// the augmented Sherman-Morrison-Woodbury solves) so that a nested, wider solve never
+// reallocates buffers the caller has already filled.
+static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   const int restart = c->opts.gmres_restart;
-  // every buffer scales with the total number of columns m * groups
-  if (m * groups <= c->wcols && restart == c->wrestart) return;
-  const size_t gm = (size_t)std::max(m * groups, c->wcols);
+  if (extra < 0) extra = std::max(c->q, 0);
+  // every buffer scales with the total number of columns (m + extra) * groups
+  const int want = (m + extra) * groups;
+  if (want <= c->wcols && restart == c->wrestart) return;
+  const size_t gm = (size_t)std::max(want, c->wcols);
   const size_t nm = (size_t)c->n * gm;
   // Krylov basis: stored in FP32 by default (all arithmetic stays FP64) -- its three
   // passes per iteration are the largest share of the HBM traffic.  The current
@@ -228,6 +240,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     if (sd->valid || std::find(todo.begin(), todo.end(), sd) != todo.end()) continue;
     sd->alpha = alphas[g];
     sd->beta = betas[g];
+    sd->smw_epoch = -1;
     todo.push_back(sd);
   }
   if (todo.empty()) return;
@@ -497,7 +510,7 @@ struct GmresResult {
 static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
                               size_t gsb, double* x, int m, bool lowrank, double* relres_host,
                               GmresResult* res) {
-  ensure_work(c, m, G);
+  ensure_work(c, m, G, 0);
   hipStream_t st = c->st;
   const int n = c->n, restart = c->opts.gmres_restart, maxit = c->opts.gmres_maxit;
   const double tol = c->opts.gmres_tol;
@@ -673,10 +686,179 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   c->total_solves += G;
 }
 
+// In-place inverse of a small dense matrix on the host (Gauss-Jordan, partial pivoting).
+static bool host_invert(std::vector<double>& a, int q) {
+  std::vector<double> inv((size_t)q * q, 0.0);
+  for (int i = 0; i < q; ++i) inv[(size_t)i * q + i] = 1.0;
+  double amax = 0.0;
+  for (double v : a) amax = std::max(amax, std::fabs(v));
+  for (int k = 0; k < q; ++k) {
+    int p = k;
+    for (int i = k + 1; i < q; ++i)
+      if (std::fabs(a[(size_t)i * q + k]) > std::fabs(a[(size_t)p * q + k])) p = i;
+    const double piv = a[(size_t)p * q + k];
+    if (!(std::fabs(piv) > 1e-12 * amax)) return false;
+    if (p != k)
+      for (int j = 0; j < q; ++j) {
+        std::swap(a[(size_t)k * q + j], a[(size_t)p * q + j]);
+        std::swap(inv[(size_t)k * q + j], inv[(size_t)p * q + j]);
+      }
+    for (int j = 0; j < q; ++j) {
+      a[(size_t)k * q + j] /= piv;
+      inv[(size_t)k * q + j] /= piv;
+    }
+    for (int i = 0; i < q; ++i) {
+      if (i == k) continue;
+      const double f = a[(size_t)i * q + k];
+      if (f == 0.0) continue;
+      for (int j = 0; j < q; ++j) {
+        a[(size_t)i * q + j] -= f * a[(size_t)k * q + j];
+        inv[(size_t)i * q + j] -= f * inv[(size_t)k * q + j];
+      }
+    }
+  }
+  a.swap(inv);
+  return true;
+}
+
+// Relative true residuals ||b - (S - U V^T) x|| / ||b|| per column (G*m values, host);
+// the residual panels are left in c->wv.
+static void true_relres(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, size_t gsb,
+                        const double* x, int m, bool lowrank, double* out) {
+  hipStream_t st = c->st;
+  Batch bt = make_batch(c, sds, G, m);
+  const size_t nm = bt.gs;
+  const size_t gspart = (size_t)dots_num_blocks(c->n) * (c->opts.gmres_restart + 2) * m;
+  const int GM = G * m;
+  double* hb = c->h_resid;
+  op_apply(c, bt, x, nm, c->wv.p, lowrank);
+  launch_axpby_b(st, bt.tab, nm, 1.0, b, gsb, -1.0, c->wv.p, nm);
+  launch_cols_dots_b(st, bt.tab, c->n, m, 0, (const double*)nullptr, 0, 0, c->wv.p, nm, 1, c->partial.p,
+                     gspart, c->nrm2.p, (size_t)m);
+  launch_cols_dots_b(st, bt.tab, c->n, m, 0, (const double*)nullptr, 0, 0, b, gsb, 1, c->partial.p,
+                     gspart, c->bnorm2.p, (size_t)m);
+  HIPCHK(hipMemcpyAsync(hb, c->nrm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(hb + GM, c->bnorm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (int j = 0; j < GM; ++j)
+    out[j] = hb[GM + j] > 0.0 ? std::sqrt(std::max(hb[j], 0.0) / hb[GM + j]) : 0.0;
+}
+
+// Batched solve with the low-rank term  (S_g - U V^T) x_g = b_g.
+//
+// Default: Sherman-Morrison-Woodbury, as the reference's lau.solve_sadpnt_smw does --
+// GMRES runs on the plain saddle operator (no thin GEMMs inside the iteration), and
+//   x = y + W (V^T y),   y = S^-1 b,   W = S^-1 [U;0] (I - V^T S^-1 U)^-1 .
+// W_g is cached per shift and low-rank term; a batch that meets a shift without it
+// solves the augmented panels [b_g, U] (m + q columns) once.  The closed-loop residual
+// is then verified in FP64; columns above the tolerance (ill-conditioned capacitance
+// matrix) are refined by one GMRES on the closed-loop operator itself.
+static void solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, size_t gsb,
+                        double* x, int m, bool lowrank, double* relres_host, GmresResult* res) {
+  const int q = c->q;
+  if (!lowrank || q <= 0 || !c->smw || m + q > RICADI_MAX_M) {
+    gmres_solve_batch(c, sds, G, b, gsb, x, m, lowrank && q > 0, relres_host, res);
+    return;
+  }
+  hipStream_t st = c->st;
+  const int n = c->n, nv = c->nv, np = c->np;
+  const size_t nm = (size_t)n * m;
+  const double tol = c->opts.gmres_tol;
+  bool need = false;
+  for (int g = 0; g < G; ++g) need = need || sds[g]->smw_epoch != c->lr_epoch;
+  GroupTab all{};
+  all.ng = G;
+  for (int g = 0; g < G; ++g) all.gid[g] = g;
+  bool bad = false;
+  if (need) {
+    const int ma = m + q;
+    const size_t nma = (size_t)n * ma;
+    c->smw_rhs.ensure(nma * G);
+    c->smw_x.ensure(nma * G);
+    double* ra = c->smw_rhs.p;
+    double* xa = c->smw_x.p;
+    for (int g = 0; g < G; ++g) {
+      launch_copy_cols(st, n, m, b + (size_t)g * gsb, m, 0, ra + g * nma, ma, 0, 1.0);
+      launch_copy_cols(st, nv, q, c->U.p, q, 0, ra + g * nma, ma, m, 1.0);
+      if (np > 0)
+        HIPCHK(hipMemset2DAsync(ra + g * nma + (size_t)nv * ma + m, sizeof(double) * ma, 0,
+                                sizeof(double) * q, np, st));
+    }
+    gmres_solve_batch(c, sds, G, ra, nma, xa, ma, false, nullptr, res);
+    // capacitance matrices I - V^T (S^-1 U)
+    c->smw_cap.ensure((size_t)G * q * q);
+    HIPCHK(hipMemsetAsync(c->smw_cap.p, 0, sizeof(double) * G * q * q, st));
+    launch_gemm_tn_b(st, all, nv, q, q, c->V.p, q, xa + m, ma, nma, c->smw_cap.p, q, (size_t)q * q);
+    std::vector<double> caps((size_t)G * q * q);
+    HIPCHK(hipMemcpyAsync(caps.data(), c->smw_cap.p, sizeof(double) * caps.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int g = 0; g < G && !bad; ++g) {
+      std::vector<double> cap((size_t)q * q);
+      for (int i = 0; i < q; ++i)
+        for (int j = 0; j < q; ++j)
+          cap[(size_t)i * q + j] = (i == j ? 1.0 : 0.0) - caps[(size_t)g * q * q + (size_t)i * q + j];
+      if (!host_invert(cap, q) || !res[g].converged) bad = true;
+      std::copy(cap.begin(), cap.end(), caps.begin() + (size_t)g * q * q);
+    }
+    for (int g = 0; g < G; ++g)
+      launch_copy_cols(st, n, m, xa + g * nma, ma, 0, x + g * nm, m, 0, 1.0);
+    if (!bad) {
+      HIPCHK(hipMemcpyAsync(c->smw_cap.p, caps.data(), sizeof(double) * caps.size(), hipMemcpyHostToDevice, st));
+      for (int g = 0; g < G; ++g) {
+        ShiftData* sd = sds[g];
+        if (sd->smw_w.n != (size_t)n * q) sd->smw_w.alloc((size_t)n * q);
+        launch_gemm_nn(st, n, q, q, xa + g * nma + m, ma, c->smw_cap.p + (size_t)g * q * q, q,
+                       sd->smw_w.p, q, 1.0, 0.0);
+        sd->smw_epoch = c->lr_epoch;
+      }
+      HIPCHK(hipStreamSynchronize(st));   // caps is a stack object
+    }
+  } else {
+    gmres_solve_batch(c, sds, G, b, gsb, x, m, false, nullptr, res);
+  }
+  const size_t gsq = (size_t)q * m;
+  if (!bad) {
+    // x_g += W_g (V^T x_g)
+    GroupPtrs W = same_ptr((const double*)nullptr);
+    for (int g = 0; g < G; ++g) W.p[g] = sds[g]->smw_w.p;
+    HIPCHK(hipMemsetAsync(c->lrc.p, 0, sizeof(double) * gsq * G, st));
+    launch_gemm_tn_b(st, all, nv, q, m, c->V.p, q, x, m, nm, c->lrc.p, m, gsq);
+    launch_gemm_nn_bp(st, all, n, q, m, W, q, c->lrc.p, m, gsq, x, m, nm, 1.0, 1.0);
+  }
+  // verification on the closed-loop operator, refinement where needed
+  std::vector<double> rr((size_t)G * m);
+  true_relres(c, sds, G, b, gsb, x, m, true, rr.data());
+  bool ok = true;
+  for (double v : rr) ok = ok && v <= tol;
+  if (!ok) {
+    c->smw_rhs.ensure(nm * G);
+    c->smw_x.ensure(nm * G);
+    HIPCHK(hipMemcpyAsync(c->smw_rhs.p, c->wv.p, sizeof(double) * nm * G, hipMemcpyDeviceToDevice, st));
+    std::vector<GmresResult> r2(G);
+    // residual equation on the closed-loop operator; its tolerance is relative to ||r||
+    const double save_tol = c->opts.gmres_tol;
+    double worst = 0.0;
+    for (double v : rr) worst = std::max(worst, v);
+    c->opts.gmres_tol = std::min(0.5, std::max(1e-14, 0.5 * tol / worst));
+    gmres_solve_batch(c, sds, G, c->smw_rhs.p, nm, c->smw_x.p, m, true, nullptr, r2.data());
+    c->opts.gmres_tol = save_tol;
+    launch_axpby_b(st, all, nm, 1.0, c->smw_x.p, nm, 1.0, x, nm);
+    for (int g = 0; g < G; ++g) res[g].iters += r2[g].iters;
+    true_relres(c, sds, G, b, gsb, x, m, true, rr.data());
+  }
+  for (int g = 0; g < G; ++g) {
+    double w = 0.0;
+    for (int j = 0; j < m; ++j) w = std::max(w, rr[(size_t)g * m + j]);
+    res[g].max_relres = w;
+    res[g].converged = w <= tol * 1.0000001;
+  }
+  if (relres_host) std::copy(rr.begin(), rr.end(), relres_host);
+}
+
 static GmresResult gmres_solve(ricadi_ctx* c, ShiftData* sd, const double* b, double* x, int m,
                                bool lowrank, double* relres_host) {
   GmresResult r;
-  gmres_solve_batch(c, &sd, 1, b, (size_t)c->n * m, x, m, lowrank, relres_host, &r);
+  solve_batch(c, &sd, 1, b, (size_t)c->n * m, x, m, lowrank, relres_host, &r);
   return r;
 }
 
@@ -1104,6 +1286,7 @@ int ricadi_create(int device_id, ricadi_ctx** out) {
   c->dev = device_id;
   ricadi_default_opts(&c->opts);
   c->precond32 = getenv("RICADI_PRECOND64") == nullptr;
+  if (const char* e = getenv("RICADI_SMW")) c->smw = e[0] != '0';
   HIPCHK(hipStreamCreate(&c->st));
   RBCHK(rocblas_create_handle(&c->rb));
   RBCHK(rocblas_set_stream(c->rb, c->st));
@@ -1291,6 +1474,7 @@ int ricadi_set_lowrank(ricadi_ctx* c, const double* U, const double* V, int q) {
   REQUIRE(q == 0 || (U && V), RICADI_EINVAL, "NULL low-rank factor");
   API_BEGIN
   c->q = q;
+  ++c->lr_epoch;
   if (q > 0) {
     const size_t cnt = (size_t)c->nv * q;
     c->U.ensure(cnt);
@@ -1386,8 +1570,8 @@ int ricadi_shift_solve_batch_dev(ricadi_ctx* c, int ng, const double* alphas, co
     const int nload = r_stride == 0 ? 1 : ng;
     for (int g = 0; g < nload; ++g) load_rhs(c, dR + (size_t)g * r_stride, m, c->bvec.p + (size_t)g * nm);
     std::vector<GmresResult> res(ng);
-    gmres_solve_batch(c, sds.data(), ng, c->bvec.p, r_stride == 0 ? 0 : nm, dX, m, true, relres_out,
-                      res.data());
+    solve_batch(c, sds.data(), ng, c->bvec.p, r_stride == 0 ? 0 : nm, dX, m, true, relres_out,
+                res.data());
     for (int g = 0; g < ng; ++g) {
       if (iters_out) iters_out[g] = res[g].iters;
       if (!res[g].converged) {
@@ -1654,6 +1838,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     if (oldB) launch_axpby(st, (size_t)nv * nb, -1.0, dOld.p, 1.0, dKall.p);
     const bool lr = (kk > 0) || oldB;
     c->q = lr ? nb : 0;
+    ++c->lr_epoch;
     if (lr) {
       c->U.ensure((size_t)nv * nb);
       c->V.ensure((size_t)nv * nb);
