@@ -105,6 +105,8 @@ struct ProlongArgs {
   const double* ec = nullptr;
   size_t gse = 0;
   int row0 = 0, nextra = 0;
+  double* out2 = nullptr;   // if set: the sweep's result before the coarse part is added
+  size_t gs2 = 0;
 };
 
 // Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for
@@ -114,6 +116,17 @@ struct LowRankArgs {
   const double* c = nullptr;
   size_t gsc = 0;
   int q = 0, nrows = 0;
+};
+
+// Input of a block-Jacobi sweep produced on the fly:  in = C * src  with a CSR matrix C
+// (rows = the sweep's rows) and a panel src (group stride gss, same leading dimension
+// as `in` would have).  Saves writing and re-reading the intermediate panel.
+struct CsrInArgs {
+  const int* rp = nullptr;
+  const int* ci = nullptr;
+  const double* v = nullptr;
+  const double* src = nullptr;
+  size_t gss = 0;
 };
 
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
@@ -168,7 +181,7 @@ void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrs& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
-                          const ProlongArgs& pa = ProlongArgs());
+                          const ProlongArgs& pa = ProlongArgs(), const CsrInArgs& ci = CsrInArgs());
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
                           const double* rc, double* ec);
 // FP32-stored inverses (leading dimension ldf = k rounded up to 4; bs x bs blocks)
@@ -177,7 +190,7 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
-                          const ProlongArgs& pa = ProlongArgs());
+                          const ProlongArgs& pa = ProlongArgs(), const CsrInArgs& ci = CsrInArgs());
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
 void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,

@@ -1011,11 +1011,13 @@ template <int BS, class T>
 __global__ __launch_bounds__(256) void block_apply_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
     GroupPtrsT<T> invs, const double* __restrict__ in, int ldi, size_t gsi,
-    double* __restrict__ out, int ldo, size_t gso, int m, int subtract, ProlongArgs pa) {
+    double* __restrict__ out, int ldo, size_t gso, int m, int subtract, ProlongArgs pa,
+    CsrInArgs ci) {
   const int grp = gt.gid[blockIdx.z];
   const T* __restrict__ inv = invs.p[grp];
   in += (size_t)grp * gsi;
   out += (size_t)grp * gso;
+  const double* __restrict__ csrc = ci.rp ? ci.src + (size_t)grp * ci.gss : nullptr;
   const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
   // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
   // inv[rows 16*ti.., k] * x[k, cols].  A-operand lane (r = l&15, q = l>>4)
@@ -1050,7 +1052,24 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
         const int kk = kc * 16 + 4 * q + s2;
-        xb[s2] = (kk < nb && col < m) ? in[(size_t)rows[b0 + kk] * ldi + col] : 0.0;
+        if (!csrc) {
+          xb[s2] = (kk < nb && col < m) ? in[(size_t)rows[b0 + kk] * ldi + col] : 0.0;
+        } else {
+          // input row computed on the fly: (C * src)[row, col] with the CSR matrix C
+          // (the J^T product of the SIMPLE sweep; src = pressure part, L2 resident)
+          double acc0 = 0.0, acc1 = 0.0;
+          if (kk < nb && col < m) {
+            const int row = rows[b0 + kk];
+            int k = ci.rp[row];
+            const int k1 = ci.rp[row + 1];
+            for (; k + 1 < k1; k += 2) {
+              acc0 = fma(ci.v[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
+              acc1 = fma(ci.v[k + 1], csrc[(size_t)ci.ci[k + 1] * ldi + col], acc1);
+            }
+            if (k < k1) acc0 = fma(ci.v[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
+          }
+          xb[s2] = acc0 + acc1;
+        }
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -1071,6 +1090,8 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
           const int row = rows[b0 + il];
           double* o = &out[(size_t)row * ldo + col];
           double v = subtract ? *o - acc[t][e] : acc[t][e];
+          // optional second copy WITHOUT the coarse part (group stride pa.gs2)
+          if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
           *o = v;
         }
@@ -1081,42 +1102,44 @@ template <class T>
 static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                              const int* rows, const GroupPtrsT<T>& inv, const double* in, int ldi,
                              size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
-                             const ProlongArgs& pa) {
+                             const ProlongArgs& pa, const CsrInArgs& ci) {
   if (nblocks <= 0 || gt.ng <= 0) return;
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
   switch (bs) {
     case 16:
       hipLaunchKernelGGL((block_apply_kernel<16, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa, ci);
       break;
     case 32:
       hipLaunchKernelGGL((block_apply_kernel<32, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa, ci);
       break;
     default:
       hipLaunchKernelGGL((block_apply_kernel<64, T>), grid, block, 0, st, gt, nblocks, bptr, rows,
-                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
+                         inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa, ci);
       break;
   }
 }
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrs& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
-                          const ProlongArgs& pa) {
-  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
+                          const ProlongArgs& pa, const CsrInArgs& ci) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa,
+                   ci);
 }
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
-                          const ProlongArgs& pa) {
-  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa);
+                          const ProlongArgs& pa, const CsrInArgs& ci) {
+  block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa,
+                   ci);
 }
 void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
                         const double* inv, const double* in, int ldi, double* out, int ldo,
                         int m, int subtract) {
   launch_block_apply_b(st, single_group(), bs, nblocks, bptr, rows, same_ptr(inv), in, ldi, 0, out,
-                       ldo, 0, m, subtract, ProlongArgs());
+                       ldo, 0, m, subtract, ProlongArgs(), CsrInArgs());
 }
 
 // blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)

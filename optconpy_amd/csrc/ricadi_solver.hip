@@ -449,14 +449,15 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     pro.row0 = nv;
     pro.nextra = np;
   }
-  auto vel_apply = [&](const double* in, size_t gsi, int subtract, bool last) {
+  auto vel_apply = [&](const double* in, size_t gsi, int subtract, bool last,
+                       const CsrInArgs& cin = CsrInArgs()) {
     const ProlongArgs pa = last ? pro : ProlongArgs();
     if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, in, m, gsi, z,
-                           m, bt.gs, m, subtract, pa);
+                           m, bt.gs, m, subtract, pa, cin);
     else
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, in, m, gsi, z,
-                           m, bt.gs, m, subtract, pa);
+                           m, bt.gs, m, subtract, pa, cin);
   };
   vel_apply(rr, gsrr, 0, np == 0);
   if (np > 0) {
@@ -464,17 +465,44 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
                   rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
+    static const bool fuse_jt = getenv("RICADI_NOFUSE_JT") == nullptr;
+    // Fused variant: the pressure sweep writes z_p already WITH its coarse part and keeps
+    // the plain z_p (the operand of the J^T product below) in tp -- in place: a wave
+    // reads its block's rows of tp before it writes them, blocks are disjoint.
+    ProlongArgs ppro;
+    if (fuse_jt) {
+      ppro.out2 = c->tp.p;
+      ppro.gs2 = bt.gsp;
+      if (c->kc > 0) {
+        ppro.aggof = c->aggof.p + nv;
+        ppro.ec = c->ec.p;
+        ppro.gse = bt.gsc;
+      }
+    }
     if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
-                           bt.gsp, zp, m, bt.gs, m, 0);
+                           bt.gsp, zp, m, bt.gs, m, 0, ppro);
     else
       launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->tp.p, m,
-                           bt.gsp, zp, m, bt.gs, m, 0);
-    // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks
-    double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
-    launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
-                  nullptr, 0, 0, 1.0, 0.0, m);
-    vel_apply(tmp, bt.gs, 1, true);
+                           bt.gsp, zp, m, bt.gs, m, 0, ppro);
+    // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks; the
+    // J^T product is formed inside the sweep, row by row as the blocks gather them
+    // (z_p is small and L2 resident), instead of through an intermediate panel
+    if (fuse_jt) {
+      CsrInArgs cin;
+      cin.rp = c->JT.rp.p;
+      cin.ci = c->JT.ci.p;
+      cin.v = c->JT.v.p;
+      cin.src = c->tp.p;
+      cin.gss = bt.gsp;
+      pro.nextra = 0;          // the pressure rows already carry their coarse part
+      vel_apply(nullptr, 0, 1, true, cin);
+    } else {
+      double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
+      launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
+                    nullptr, 0, 0, 1.0, 0.0, m);
+      vel_apply(tmp, bt.gs, 1, true);
+    }
   }
 }
 
