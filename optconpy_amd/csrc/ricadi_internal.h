@@ -85,6 +85,14 @@ struct GroupPtrsT {
 };
 typedef GroupPtrsT<double> GroupPtrs;
 typedef GroupPtrsT<float> GroupPtrsF;   // FP32-stored preconditioner operands
+struct GroupInts {            // one small integer per group id (by value)
+  int v[RICADI_MAX_GROUPS];
+};
+inline GroupInts same_int(int k) {
+  GroupInts g;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) g.v[i] = k;
+  return g;
+}
 inline GroupTab single_group() {
   GroupTab t{};
   t.ng = 1;
@@ -174,8 +182,14 @@ void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int r
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
                          double* g, double* scale, double* resid, const double* bnorm, double tol,
                          double* host_resid = nullptr);
-void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, int k, int restart,
-                              const double* H, const double* g, double* y);
+void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
+                              int restart, const double* H, const double* g, double* y);
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const double* basis, size_t vstride, size_t gsb, const double* h,
+                           size_t gsh, double* out, size_t gso);
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const float* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso);
 void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart,
                           const double* nrm2, double* g, double* scale, double* resid);
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
@@ -193,6 +207,7 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
                           const ProlongArgs& pa = ProlongArgs(), const CsrInArgs& ci = CsrInArgs());
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
+void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst);
 void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
                           const double* ec, size_t gse, double* z, size_t gsz);
 void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,

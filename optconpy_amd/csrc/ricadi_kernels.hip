@@ -755,11 +755,12 @@ void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const d
 // sees IS the stored one.
 template <class BT>
 __global__ __launch_bounds__(256) void cols_update_kernel(
-    GroupTab gt, size_t nelem, int m, int nvec, const BT* __restrict__ basis, size_t vstride,
+    GroupTab gt, size_t nelem, int m, GroupInts nvecs, const BT* __restrict__ basis, size_t vstride,
     size_t gsb, const double* __restrict__ h, size_t gsh, double sign,
     const double* __restrict__ w, size_t gsw, const double* __restrict__ scale,
     double* __restrict__ out, size_t gso, float* __restrict__ outf, size_t gsf) {
   const int grp = gt.gid[blockIdx.z];
+  const int nvec = nvecs.v[grp];
   basis += (size_t)grp * gsb;
   h += (size_t)grp * gsh;
   if (w) w += (size_t)grp * gsw;
@@ -787,8 +788,9 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
   }
 }
 template <class BT>
-static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
-                             const BT* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
+                             const GroupInts& nvec, const BT* basis, size_t vstride, size_t gsb,
+                             const double* h, size_t gsh,
                              double sign, const double* w, size_t gsw, const double* scale,
                              double* out, size_t gso, float* outf, size_t gsf) {
   size_t nelem = (size_t)nrows * m;
@@ -801,15 +803,28 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
                           const double* basis, size_t vstride, size_t gsb, const double* h,
                           size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
                           double* out, size_t gso) {
-  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso,
-                   (float*)nullptr, 0);
+  cols_update_impl(st, gt, nrows, m, same_int(nvec), basis, vstride, gsb, h, gsh, sign, w, gsw, scale,
+                   out, gso, (float*)nullptr, 0);
 }
 void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                           const float* basis, size_t vstride, size_t gsb, const double* h,
                           size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
                           double* out, size_t gso, float* outf, size_t gsf) {
-  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso,
-                   outf, gsf);
+  cols_update_impl(st, gt, nrows, m, same_int(nvec), basis, vstride, gsb, h, gsh, sign, w, gsw, scale,
+                   out, gso, outf, gsf);
+}
+// correction step of a restart cycle: group g combines its first nvec.v[g] vectors
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const double* basis, size_t vstride, size_t gsb, const double* h,
+                           size_t gsh, double* out, size_t gso) {
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                   (const double*)nullptr, out, gso, (float*)nullptr, 0);
+}
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const float* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso) {
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                   (const double*)nullptr, out, gso, (float*)nullptr, 0);
 }
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
@@ -929,11 +944,12 @@ void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* 
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
-__global__ void gmres_backsolve_kernel(GroupTab gt, int m, int k, int restart,
+__global__ void gmres_backsolve_kernel(GroupTab gt, int m, GroupInts ks, int restart,
                                        const double* __restrict__ H, const double* __restrict__ g,
                                        double* __restrict__ y) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
+  const int k = ks.v[gt.gid[blockIdx.z]];
   {
     const size_t grp = (size_t)gt.gid[blockIdx.z];
     H += grp * m * (restart + 1) * restart;
@@ -948,15 +964,15 @@ __global__ void gmres_backsolve_kernel(GroupTab gt, int m, int k, int restart,
     y[i * m + c] = s / Hc[(size_t)i * (restart + 1) + i];
   }
 }
-void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, int k, int restart,
-                              const double* H, const double* g, double* y) {
+void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
+                              int restart, const double* H, const double* g, double* y) {
   if (gt.ng <= 0) return;
   hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
                      k, restart, H, g, y);
 }
 void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
                             const double* g, double* y) {
-  launch_gmres_backsolve_b(st, single_group(), m, k, restart, H, g, y);
+  launch_gmres_backsolve_b(st, single_group(), m, same_int(k), restart, H, g, y);
 }
 
 // start of a cycle: beta[c] = sqrt(nrm2[c]); g = [beta, 0...]; scale = 1/beta
@@ -1433,11 +1449,105 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
   dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
   hipLaunchKernelGGL(dense_apply_kernel<double>, grid, dim3(512), 0, st, gt, k, m, Einv, k, rc, ec);
 }
+// FP32-stored inverse in TILE-MAJOR layout: 16 x 16 tiles of 256 contiguous floats,
+// tile (it, jt) at (it * kp + jt) * 256, kp = ceil(k / 16), zero padded.  The A operand
+// of one MFMA chunk -- lane (r, q) needs Einv[16 it + r][16 jt + 4q .. 4q+3] -- is then
+// ONE fully coalesced 1-KB read per wave (lane offset (16 r + 4 q) floats) instead of
+// sixteen 64-B row segments 4k bytes apart.
+__global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int k, int m,
+                                                                GroupPtrsF Einvs,
+                                                                const double* __restrict__ rc,
+                                                                double* __restrict__ ec) {
+  __shared__ double red[8][16][17];
+  const int grp = gt.gid[blockIdx.z];
+  const float* __restrict__ Einv = Einvs.p[grp];
+  rc += (size_t)grp * k * m;
+  ec += (size_t)grp * k * m;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int it = blockIdx.x, c0 = blockIdx.y * 16;
+  const int kp = (k + 15) / 16;
+  const int per = (kp + 7) / 8;
+  const int ch0 = w * per, ch1 = min(kp, ch0 + per);
+  const int col = c0 + r;
+  const float* __restrict__ trow = Einv + (size_t)it * kp * 256 + r * 16 + 4 * q;
+  d4v acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int ch, float4& a, double (&bb)[4]) {
+    if (ch < ch1) {
+      a = *reinterpret_cast<const float4*>(trow + (size_t)ch * 256);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int jj = ch * 16 + 4 * q + t;
+        bb[t] = (jj < k && col < m) ? rc[(size_t)jj * m + col] : 0.0;
+      }
+    } else {
+      a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bb[t] = 0.0;
+    }
+  };
+  for (int ch = ch0; ch < ch1; ch += 4) {
+    float4 a0, a1, a2, a3;
+    double b0[4], b1[4], b2[4], b3[4];
+    fetch(ch, a0, b0);
+    fetch(ch + 1, a1, b1);
+    fetch(ch + 2, a2, b2);
+    fetch(ch + 3, a3, b3);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.x, b0[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.x, b1[0], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.y, b0[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.y, b1[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.z, b0[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.z, b1[2], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.w, b0[3], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.w, b1[3], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.x, b2[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.x, b3[0], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.y, b2[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.y, b3[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.z, b2[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.z, b3[2], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.w, b2[3], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.w, b3[3], acc2, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][q + 4 * e][r] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum += red[t][rr][cc];
+    if (it * 16 + rr < k && c0 + cc < m) ec[(size_t)(it * 16 + rr) * m + c0 + cc] = sum;
+  }
+}
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
                           int ldf, const double* rc, double* ec) {
+  (void)ldf;   // tile-major storage (launch_to_f32_tiled)
   if (k <= 0 || gt.ng <= 0) return;
   dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
-  hipLaunchKernelGGL(dense_apply_kernel<float>, grid, dim3(512), 0, st, gt, k, m, Einv, ldf, rc, ec);
+  hipLaunchKernelGGL(dense_apply_tiled_kernel, grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
+}
+// dst = FP32 copy of the k x k row-major src in 16 x 16 tile-major layout, zero padded
+__global__ void to_f32_tiled_kernel(int k, const double* __restrict__ src, float* __restrict__ dst) {
+  const int kp = (k + 15) / 16;
+  const size_t n = (size_t)kp * kp * 256;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t tile = i >> 8;
+    const int r = (int)((i >> 4) & 15), cc = (int)(i & 15);
+    const int row = (int)(tile / kp) * 16 + r, col = (int)(tile % kp) * 16 + cc;
+    dst[i] = (row < k && col < k) ? (float)src[(size_t)row * k + col] : 0.f;
+  }
+}
+void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst) {
+  const int kp = (k + 15) / 16;
+  const size_t n = (size_t)kp * kp * 256;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(to_f32_tiled_kernel, dim3(grid), dim3(256), 0, st, k, src, dst);
 }
 
 // dst (FP32, leading dimension ldd) = src (FP64, leading dimension lds_)

@@ -71,8 +71,8 @@ struct ShiftData {
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
   DArr<double> sval, svalb, bvinv, bpinv, einv;
   // FP32 copies of the inverses, the ones the preconditioner applies (a fixed linear
-  // operator either way; halves its HBM traffic).  einvf has leading dimension kc
-  // rounded up to 4.  RICADI_PRECOND64=1 applies the FP64 originals instead.
+  // operator either way; halves its HBM traffic).  einvf is stored in 16 x 16 tiles
+  // (dense_apply_tiled_kernel).  RICADI_PRECOND64=1 applies the FP64 originals instead.
   DArr<float> bvinvf, bpinvf, einvf;
   // Sherman-Morrison-Woodbury data for the current low-rank term (ctx->lr_epoch):
   // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
@@ -307,9 +307,9 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         launch_to_f32(st, c->nbp, bs2, sd->bpinv.p, bs2, sd->bpinvf.p, bs2);
       }
       if (k > 0) {
-        const int ldf = (k + 3) & ~3;
-        if (sd->einvf.n != (size_t)k * ldf) sd->einvf.alloc((size_t)k * ldf);
-        launch_to_f32(st, k, k, sd->einv.p, k, sd->einvf.p, ldf);
+        const size_t kp = (size_t)(k + 15) / 16;
+        if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
+        launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
       }
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -685,15 +685,16 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       live.swap(still);
     }
     // corrections: x_g += P^-1 (V_g y_g) with the k_g basis vectors group g built
-    for (int g : act) {
-      bt.only(g);
-      launch_gmres_backsolve_b(st, bt.tab, m, kk[g], restart, c->H.p, c->g.p, c->yv.p);
+    // (one launch each for all groups of the cycle, k_g per group by value)
+    bt.set(act);
+    {
+      GroupInts ks = same_int(0);
+      for (int g : act) ks.v[g] = kk[g];
+      launch_gmres_backsolve_b(st, bt.tab, m, ks, restart, c->H.p, c->g.p, c->yv.p);
       if (b32)
-        launch_cols_update_b(st, bt.tab, n, m, kk[g], Vf, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
-                             nullptr, 0, nullptr, c->wv.p, nm, nullptr, 0);
+        launch_cols_update_bk(st, bt.tab, n, m, ks, Vf, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
       else
-        launch_cols_update_b(st, bt.tab, n, m, kk[g], V, vs, nm, c->yv.p, (size_t)restart * m, 1.0,
-                             nullptr, 0, nullptr, c->wv.p, nm);
+        launch_cols_update_bk(st, bt.tab, n, m, ks, V, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
     }
     bt.set(act);
     precond_apply(c, bt, c->wv.p, nm, c->zv.p);
