@@ -155,6 +155,24 @@ void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, cons
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
                        const double* x, size_t gsx, double b, double* y, size_t gsy,
                        float* yf = nullptr, size_t gsf = 0);
+void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                       const double* x, size_t gsx, double b, double* y, size_t gsy, _Float16* yf,
+                       size_t gsf);
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const _Float16* basis, size_t vstride, size_t gsb, const double* w,
+                        size_t gsw, int want_self, double* partial, size_t gsp, double* out,
+                        size_t gso);
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso);
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso, _Float16* outf, size_t gsf);
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                           size_t gsh, double* out, size_t gso);
 // FP32-stored Krylov basis (arithmetic stays FP64): overloads reading `const float* basis`
 void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                         const float* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,

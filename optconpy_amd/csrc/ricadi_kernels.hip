@@ -493,9 +493,10 @@ void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b,
 
 // y[r, c] = a[c] * x[r, c] + b * y[r, c]   (per-column scale, contiguous panel)
 // yf (optional): FP32 copy of the result; y then holds the SAME rounded values.
+template <class LP>
 __global__ void colscale_kernel(GroupTab gt, size_t n, int m, const double* __restrict__ a,
                                 const double* __restrict__ x, size_t gsx, double b,
-                                double* __restrict__ y, size_t gsy, float* __restrict__ yf,
+                                double* __restrict__ y, size_t gsy, LP* __restrict__ yf,
                                 size_t gsf) {
   const int grp = gt.gid[blockIdx.z];
   a += (size_t)grp * m;
@@ -506,25 +507,36 @@ __global__ void colscale_kernel(GroupTab gt, size_t n, int m, const double* __re
        i += (size_t)gridDim.x * blockDim.x) {
     double v = a[i % m] * x[i] + (b == 0.0 ? 0.0 : b * y[i]);
     if (yf) {
-      const float f = (float)v;
+      const LP f = (LP)v;
       yf[i] = f;
       v = (double)f;
     }
     y[i] = v;
   }
 }
-void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
-                       const double* x, size_t gsx, double b, double* y, size_t gsy, float* yf,
-                       size_t gsf) {
+template <class LP>
+static void colscale_impl(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                          const double* x, size_t gsx, double b, double* y, size_t gsy, LP* yf,
+                          size_t gsf) {
   size_t n = nrows * m;
   if (!n || gt.ng <= 0) return;
   int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(colscale_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, n, m, a, x, gsx,
-                     b, y, gsy, yf, gsf);
+  hipLaunchKernelGGL(colscale_kernel<LP>, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, n, m, a, x,
+                     gsx, b, y, gsy, yf, gsf);
+}
+void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                       const double* x, size_t gsx, double b, double* y, size_t gsy, float* yf,
+                       size_t gsf) {
+  colscale_impl(st, gt, nrows, m, a, x, gsx, b, y, gsy, yf, gsf);
+}
+void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
+                       const double* x, size_t gsx, double b, double* y, size_t gsy, _Float16* yf,
+                       size_t gsf) {
+  colscale_impl(st, gt, nrows, m, a, x, gsx, b, y, gsy, yf, gsf);
 }
 void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
                      double b, double* y) {
-  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0, nullptr, 0);
+  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0, (float*)nullptr, 0);
 }
 
 // copy a strided block of columns: dst[r, dc0 + c] = scale * src[r, sc0 + c], c < w
@@ -653,6 +665,13 @@ void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, in
   cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
                  gso);
 }
+void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                        const _Float16* basis, size_t vstride, size_t gsb, const double* w,
+                        size_t gsw, int want_self, double* partial, size_t gsp, double* out,
+                        size_t gso) {
+  cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
+                 gso);
+}
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
                       double* out) {
@@ -741,6 +760,13 @@ void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, in
   cols_update_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, w, gsw, partial, gsp, out,
                         gso);
 }
+void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                               const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                               size_t gsh, double* w, size_t gsw, double* partial, size_t gsp,
+                               double* out, size_t gso) {
+  cols_update_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, w, gsw, partial, gsp, out,
+                        gso);
+}
 void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                              size_t vstride, const double* h, double* w, double* partial,
                              double* out) {
@@ -758,7 +784,7 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
     GroupTab gt, size_t nelem, int m, GroupInts nvecs, const BT* __restrict__ basis, size_t vstride,
     size_t gsb, const double* __restrict__ h, size_t gsh, double sign,
     const double* __restrict__ w, size_t gsw, const double* __restrict__ scale,
-    double* __restrict__ out, size_t gso, float* __restrict__ outf, size_t gsf) {
+    double* __restrict__ out, size_t gso, BT* __restrict__ outf, size_t gsf) {
   const int grp = gt.gid[blockIdx.z];
   const int nvec = nvecs.v[grp];
   basis += (size_t)grp * gsb;
@@ -780,7 +806,7 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
     double v = (w ? w[e] : 0.0) + sign * (s0 + s1);
     if (scale) v *= scale[c];
     if (outf) {
-      const float f = (float)v;
+      const BT f = (BT)v;
       outf[e] = f;
       v = (double)f;
     }
@@ -792,7 +818,7 @@ static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int 
                              const GroupInts& nvec, const BT* basis, size_t vstride, size_t gsb,
                              const double* h, size_t gsh,
                              double sign, const double* w, size_t gsw, const double* scale,
-                             double* out, size_t gso, float* outf, size_t gsf) {
+                             double* out, size_t gso, BT* outf, size_t gsf) {
   size_t nelem = (size_t)nrows * m;
   if (!nelem || gt.ng <= 0) return;
   int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
@@ -804,7 +830,7 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
                           size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
                           double* out, size_t gso) {
   cols_update_impl(st, gt, nrows, m, same_int(nvec), basis, vstride, gsb, h, gsh, sign, w, gsw, scale,
-                   out, gso, (float*)nullptr, 0);
+                   out, gso, (double*)nullptr, 0);
 }
 void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                           const float* basis, size_t vstride, size_t gsb, const double* h,
@@ -813,12 +839,25 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
   cols_update_impl(st, gt, nrows, m, same_int(nvec), basis, vstride, gsb, h, gsh, sign, w, gsw, scale,
                    out, gso, outf, gsf);
 }
+void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
+                          const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                          size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
+                          double* out, size_t gso, _Float16* outf, size_t gsf) {
+  cols_update_impl(st, gt, nrows, m, same_int(nvec), basis, vstride, gsb, h, gsh, sign, w, gsw, scale,
+                   out, gso, outf, gsf);
+}
 // correction step of a restart cycle: group g combines its first nvec.v[g] vectors
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
                            const double* basis, size_t vstride, size_t gsb, const double* h,
                            size_t gsh, double* out, size_t gso) {
   cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
-                   (const double*)nullptr, out, gso, (float*)nullptr, 0);
+                   (const double*)nullptr, out, gso, (double*)nullptr, 0);
+}
+void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
+                           const _Float16* basis, size_t vstride, size_t gsb, const double* h,
+                           size_t gsh, double* out, size_t gso) {
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                   (const double*)nullptr, out, gso, (_Float16*)nullptr, 0);
 }
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
                            const float* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,

@@ -135,6 +135,7 @@ struct ricadi_ctx {
   DArr<double> basis, vcur, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
   DArr<float> basisf;
   bool basis32 = true;
+  bool basis16 = false;       // RICADI_BASIS16=1: experimental FP16-stored Krylov basis
   bool precond32 = true;
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
@@ -177,6 +178,7 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   // vector is also kept in FP64 (vcur, holding the same rounded values) for the
   // operator / preconditioner application.  RICADI_BASIS64=1 keeps an FP64 basis.
   c->basis32 = getenv("RICADI_BASIS64") == nullptr;
+  c->basis16 = c->basis32 && getenv("RICADI_BASIS16") != nullptr;
   if (c->basis32) {
     c->basisf.alloc((size_t)(restart + 1) * nm);
     c->vcur.alloc(nm);
@@ -550,7 +552,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   const int GM = G * m;
   double* V = c->basis.p;          // FP64 basis (RICADI_BASIS64) ...
   float* Vf = c->basisf.p;         // ... or the FP32-stored one
-  const bool b32 = c->basis32;
+  const bool b16 = c->basis16;
+  const bool b32 = c->basis32 && !b16;
+  _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
   for (int g = 0; g < G; ++g) res[g] = GmresResult();
@@ -630,7 +634,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     act.swap(next);
     if (act.empty()) break;
     bt.set(act);
-    if (b32)
+    if (b16)
+      launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, c->vcur.p, nm, Vh, nm);
+    else if (b32)
       launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, c->vcur.p, nm, Vf, nm);
     else
       launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
@@ -638,10 +644,15 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     for (int g : act) kk[g] = 0;
     for (int j = 0; j < cyc && !live.empty(); ++j) {
       bt.set(live);
-      const double* vj = b32 ? c->vcur.p : V + (size_t)j * vs;
+      const double* vj = (b32 || b16) ? c->vcur.p : V + (size_t)j * vs;
       precond_apply(c, bt, vj, nm, c->zv.p);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank);
-      if (b32) {
+      if (b16) {
+        launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
+                           c->h1.p, gsh);
+        launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm,
+                                  c->partial.p, gspart, c->h2.p, gsh);
+      } else if (b32) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
                            c->h1.p, gsh);
         launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm,
@@ -658,7 +669,10 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
       launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p,
                           c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur);
-      if (b32)
+      if (b16)
+        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
+                             c->scale.p, c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
+      else if (b32)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, c->vcur.p, nm, Vf + (size_t)(j + 1) * vs, nm);
       else
@@ -691,7 +705,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       GroupInts ks = same_int(0);
       for (int g : act) ks.v[g] = kk[g];
       launch_gmres_backsolve_b(st, bt.tab, m, ks, restart, c->H.p, c->g.p, c->yv.p);
-      if (b32)
+      if (b16)
+        launch_cols_update_bk(st, bt.tab, n, m, ks, Vh, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
+      else if (b32)
         launch_cols_update_bk(st, bt.tab, n, m, ks, Vf, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
       else
         launch_cols_update_bk(st, bt.tab, n, m, ks, V, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
