@@ -242,7 +242,7 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   // greedily into blocks of <= 32 rows whose set of distinct columns stays
   // within kSbMaxCols, so that the x tile of a block fits the LDS budget.
   {
-    int kSbMaxRows = 32, kSbMaxCols = 160;
+    int kSbMaxRows = 32, kSbMaxCols = 152;   // 152 x 16 x 8 B tiles: 8 workgroups per CU fit the 160 KB LDS
     if (const char* e = getenv("RICADI_SB_MAXCOLS")) kSbMaxCols = std::max(48, atoi(e));
     if (const char* e = getenv("RICADI_SB_MAXROWS")) kSbMaxRows = std::max(1, std::min(32, atoi(e)));
     std::vector<int> order;

@@ -269,6 +269,9 @@ void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
 // already applied) -- so every address of the first round of loads follows from
 // the block index alone: the kernel is bound by the latency of its dependent
 // loads, and this removes one full round trip (block pointers -> row/column lists).
+// HAS_R / HAS_LR: compile the residual term / the low-rank epilogue in (the plain
+// operator launch of the GMRES iteration has neither).
+template <bool HAS_R, bool HAS_LR>
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
@@ -285,8 +288,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   const double* __restrict__ val = vals.p[grp];
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
-  if (r) r += (size_t)grp * gsr;
-  const double* __restrict__ lrc = lr.c + (size_t)grp * lr.gsc;
+  if (HAS_R) r += (size_t)grp * gsr;
+  const double* __restrict__ lrc = HAS_LR ? lr.c + (size_t)grp * lr.gsc : nullptr;
   // XCD-contiguous block ranges (bijective remap, cdna guide T1)
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -407,8 +410,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
       if (live && cc < m) {
         const int row = grow[rr];
         double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        if (r) out += beta_r * r[(size_t)row * ldr + cc];
-        if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, cc, m);
+        if (HAS_R) out += beta_r * r[(size_t)row * ldr + cc];
+        if (HAS_LR && row < lr.nrows) out -= lowrank_term(lr, lrc, row, cc, m);
         y[(size_t)row * ldy + cc] = out;
       }
     }
@@ -425,9 +428,17 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
                            int ldy, size_t gsy, const double* r, int ldr, size_t gsr, double alpha,
                            double beta_r, int m, int max_cols, const LowRankArgs& lr) {
   if (nblk <= 0 || gt.ng <= 0) return;
-  hipLaunchKernelGGL(spmm_blocked_kernel, dim3(nblk, 1, gt.ng), dim3(256),
-                     spmm_blocked_lds_bytes(m, max_cols, 0), st, rows2, rp2, cols2, lidx, gt, vals, x,
-                     ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, lr);
+  const dim3 grid(nblk, 1, gt.ng), block(256);
+  const size_t lds = spmm_blocked_lds_bytes(m, max_cols, 0);
+#define RICADI_TILE_LAUNCH(R, L)                                                                  \
+  hipLaunchKernelGGL((spmm_blocked_kernel<R, L>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt, \
+                     vals, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, lr)
+  const bool has_lr = lr.q > 0 && lr.nrows > 0;
+  if (r && has_lr) RICADI_TILE_LAUNCH(true, true);
+  else if (r) RICADI_TILE_LAUNCH(true, false);
+  else if (has_lr) RICADI_TILE_LAUNCH(false, true);
+  else RICADI_TILE_LAUNCH(false, false);
+#undef RICADI_TILE_LAUNCH
 }
 
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)
