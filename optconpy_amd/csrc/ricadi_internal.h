@@ -226,8 +226,6 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
 void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst);
-void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
-                          const double* ec, size_t gse, double* z, size_t gsz);
 void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, const double* A,
                       int lda, const double* B, int ldb, size_t gsB, double* C, int ldc, size_t gsC);
 // A given per group (A[g] is n x p, leading dimension lda)
@@ -244,49 +242,23 @@ size_t spmm_blocked_lds_bytes(int m, int max_cols, int max_nnz);
 void launch_gather_vals(hipStream_t st, int nnz, const int* perm, const double* src, double* dst);
 void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const double* srcE,
                            const double* srcJ, double alpha, double beta, double* out);
-void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, double alpha,
-                     double beta, double* out);
 void launch_axpby(hipStream_t st, size_t n, double a, const double* x, double b, double* y);
-void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
-                     double b, double* y);
 void launch_copy_cols(hipStream_t st, int nrows, int w, const double* src, int lds_, int sc0,
                       double* dst, int ldd, int dc0, double scale);
 int dots_num_blocks(int nrows);
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
                       double* out);
-void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
-                             size_t vstride, const double* h, double* w, double* partial,
-                             double* out);
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
                         const double* scale, double* out);
-void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
-                       const double* h2, double* H, double* cs, double* sn, double* g,
-                       double* scale, double* resid, const double* bnorm, double tol);
-void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
-                            const double* g, double* y);
-void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
-                        double* scale, double* resid);
-void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
-                        const double* inv, const double* in, int ldi, double* out, int ldo, int m,
-                        int subtract = 0);
 void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const double* Be,
                           double alpha, double beta, double* out);
-void launch_schur_blocks(hipStream_t st, int nblocks, int bs, const int* bptr, const int* rows,
-                         const int* jrp, const int* jci, const double* jv, const double* dinv,
-                         double* blocks);
 void launch_schur_blocks_bj(hipStream_t st, int nblocks, int bs, const int* bptr, const int* jd_ptr,
                             const int* jd_vblk, const double* jd_val, const double* bvinv,
                             double* blocks);
 void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
                          int* flag);
-void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows, const double* in,
-                     int ldi, double* rc, int m);
-void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
-                        double* ec);
-void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, const double* ec,
-                        double* z);
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc);
 void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,
@@ -299,7 +271,6 @@ void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, con
 void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);
-void launch_set_identity(hipStream_t st, int k, double* out);
 
 void set_error(const std::string& msg);
 

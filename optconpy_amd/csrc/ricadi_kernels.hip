@@ -467,17 +467,6 @@ void launch_assemble_shift(hipStream_t st, int nnz, const double* srcA, const do
                      alpha, beta, out);
 }
 
-// out[i] = 1 / (alpha*dE[i] + beta*dA[i])
-__global__ void diag_inv_kernel(int n, const double* dA, const double* dE, double alpha,
-                                double beta, double* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = 1.0 / (alpha * dE[i] + beta * dA[i]);
-}
-void launch_diag_inv(hipStream_t st, int n, const double* dA, const double* dE, double alpha,
-                     double beta, double* out) {
-  hipLaunchKernelGGL(diag_inv_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, dA, dE, alpha,
-                     beta, out);
-}
 
 // ---------------------------------------------------------------------------
 // elementwise panel helpers (K4)
@@ -544,10 +533,6 @@ void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, 
                        const double* x, size_t gsx, double b, double* y, size_t gsy, _Float16* yf,
                        size_t gsf) {
   colscale_impl(st, gt, nrows, m, a, x, gsx, b, y, gsy, yf, gsf);
-}
-void launch_colscale(hipStream_t st, size_t nrows, int m, const double* a, const double* x,
-                     double b, double* y) {
-  launch_colscale_b(st, single_group(), nrows, m, a, x, 0, b, y, 0, (float*)nullptr, 0);
 }
 
 // copy a strided block of columns: dst[r, dc0 + c] = scale * src[r, sc0 + c], c < w
@@ -778,12 +763,6 @@ void launch_cols_update_dots_b(hipStream_t st, const GroupTab& gt, int nrows, in
   cols_update_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, w, gsw, partial, gsp, out,
                         gso);
 }
-void launch_cols_update_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
-                             size_t vstride, const double* h, double* w, double* partial,
-                             double* out) {
-  launch_cols_update_dots_b(st, single_group(), nrows, m, nvec, basis, vstride, 0, h, 0, w, 0,
-                            partial, 0, out, 0);
-}
 
 // out[r,c] = scale[c] * ( w[r,c] + sign * sum_{i<nvec} h[i*m+c] * V_i[r,c] )
 // (scale may be NULL = 1; w may be NULL = 0).  Streams nvec panels once.
@@ -986,12 +965,6 @@ void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int r
                      (3 * restart + 4) * sizeof(double), st, gt, m, j, restart, h1, h2, H, cs, sn, g,
                      scale, resid, bnorm, tol, host_resid);
 }
-void launch_gmres_hess(hipStream_t st, int m, int j, int restart, const double* h1,
-                       const double* h2, double* H, double* cs, double* sn, double* g,
-                       double* scale, double* resid, const double* bnorm, double tol) {
-  launch_gmres_hess_b(st, single_group(), m, j, restart, h1, h2, H, cs, sn, g, scale, resid, bnorm,
-                      tol, nullptr);
-}
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
 __global__ void gmres_backsolve_kernel(GroupTab gt, int m, GroupInts ks, int restart,
@@ -1020,10 +993,6 @@ void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const G
   hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
                      k, restart, H, g, y);
 }
-void launch_gmres_backsolve(hipStream_t st, int m, int k, int restart, const double* H,
-                            const double* g, double* y) {
-  launch_gmres_backsolve_b(st, single_group(), m, same_int(k), restart, H, g, y);
-}
 
 // start of a cycle: beta[c] = sqrt(nrm2[c]); g = [beta, 0...]; scale = 1/beta
 __global__ void gmres_start_kernel(GroupTab gt, int m, int restart,
@@ -1050,10 +1019,6 @@ void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart
   if (gt.ng <= 0) return;
   hipLaunchKernelGGL(gmres_start_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
                      restart, nrm2, g, scale, resid);
-}
-void launch_gmres_start(hipStream_t st, int m, int restart, const double* nrm2, double* g,
-                        double* scale, double* resid) {
-  launch_gmres_start_b(st, single_group(), m, restart, nrm2, g, scale, resid);
 }
 
 // ---------------------------------------------------------------------------
@@ -1201,12 +1166,6 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
   block_apply_impl(st, gt, bs, nblocks, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m, subtract, pa,
                    ci);
 }
-void launch_block_apply(hipStream_t st, int bs, int nblocks, const int* bptr, const int* rows,
-                        const double* inv, const double* in, int ldi, double* out, int ldo,
-                        int m, int subtract) {
-  launch_block_apply_b(st, single_group(), bs, nblocks, bptr, rows, same_ptr(inv), in, ldi, 0, out,
-                       ldo, 0, m, subtract, ProlongArgs(), CsrInArgs());
-}
 
 // blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)
 __global__ void block_combine_kernel(size_t n, const double* Ba, const double* Be, double alpha,
@@ -1222,46 +1181,6 @@ void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const doub
                      out);
 }
 
-// Diagonal blocks of the SIMPLE Schur complement  J * Dinv * J^T : entry (il,kl)
-// of block b = sparse dot of J rows (sorted columns) weighted by Dinv.
-__global__ void schur_blocks_kernel(int nblocks, int bs, const int* __restrict__ bptr,
-                                    const int* __restrict__ rows, const int* __restrict__ jrp,
-                                    const int* __restrict__ jci, const double* __restrict__ jv,
-                                    const double* __restrict__ dinv, double* __restrict__ blocks) {
-  const int b = blockIdx.x;
-  const int b0 = bptr[b], nb = bptr[b + 1] - b0;
-  double* Bb = blocks + (size_t)b * bs * bs;
-  for (int e = threadIdx.x; e < bs * bs; e += blockDim.x) {
-    const int il = e / bs, kl = e - il * bs;
-    double s = 0.0;
-    if (il < nb && kl < nb) {
-      const int ri = rows[b0 + il], rk = rows[b0 + kl];
-      int a = jrp[ri], ae = jrp[ri + 1], c = jrp[rk], ce = jrp[rk + 1];
-      while (a < ae && c < ce) {
-        const int ca = jci[a], cc = jci[c];
-        if (ca == cc) {
-          s = fma(jv[a] * dinv[ca], jv[c], s);
-          ++a;
-          ++c;
-        } else if (ca < cc) {
-          ++a;
-        } else {
-          ++c;
-        }
-      }
-    } else if (il == kl) {
-      s = 1.0;
-    }
-    Bb[e] = s;
-  }
-}
-void launch_schur_blocks(hipStream_t st, int nblocks, int bs, const int* bptr, const int* rows,
-                         const int* jrp, const int* jci, const double* jv, const double* dinv,
-                         double* blocks) {
-  if (nblocks <= 0) return;
-  hipLaunchKernelGGL(schur_blocks_kernel, dim3(nblocks), dim3(256), 0, st, nblocks, bs, bptr, rows,
-                     jrp, jci, jv, dinv, blocks);
-}
 
 // Diagonal blocks of the CONSISTENT SIMPLE Schur complement
 //   S_bb = sum_beta J_{b,beta} * Ahat_beta^-1 * J_{b,beta}^T
@@ -1392,27 +1311,6 @@ void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, d
 // ---------------------------------------------------------------------------
 // coarse level: restriction (aggregate sums), dense apply, prolongation-add
 // ---------------------------------------------------------------------------
-// rc[a, :] = sum_{r in aggregate a} in[r, :]   (one 16-lane group per aggregate)
-__global__ __launch_bounds__(256) void restrict_kernel(int nagg, const int* __restrict__ aptr,
-                                                       const int* __restrict__ arows,
-                                                       const double* __restrict__ in, int ldi,
-                                                       double* __restrict__ rc, int m) {
-  const int a = blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (a >= nagg) return;
-  const int g = threadIdx.x & 15;
-  const int r0 = aptr[a], r1 = aptr[a + 1];
-  for (int c = g; c < m; c += 16) {
-    double s = 0.0;
-    for (int r = r0; r < r1; ++r) s += in[(size_t)arows[r] * ldi + c];
-    rc[(size_t)a * m + c] = s;
-  }
-}
-void launch_restrict(hipStream_t st, int nagg, const int* aptr, const int* arows, const double* in,
-                     int ldi, double* rc, int m) {
-  if (nagg <= 0) return;
-  hipLaunchKernelGGL(restrict_kernel, dim3((nagg + 15) / 16), dim3(256), 0, st, nagg, aptr, arows,
-                     in, ldi, rc, m);
-}
 
 // ec = Einv (k x k, row-major) * rc (k x m) on the FP64 matrix cores.
 // A workgroup of 8 waves owns 16 output rows x 16 columns; wave w sweeps the
@@ -1618,38 +1516,7 @@ void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int 
   int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipLaunchKernelGGL(to_f32_kernel, dim3(grid), dim3(256), 0, st, nrows, ncols, src, lds_, dst, ldd);
 }
-void launch_dense_apply(hipStream_t st, int k, int m, const double* Einv, const double* rc,
-                        double* ec) {
-  launch_dense_apply_b(st, single_group(), k, m, same_ptr(Einv), rc, ec);
-}
 
-// z[r, :] += ec[aggof[r], :]
-__global__ void prolong_add_kernel(GroupTab gt, int nrows, int m, const int* __restrict__ aggof,
-                                   const double* __restrict__ ec, size_t gse,
-                                   double* __restrict__ z, size_t gsz) {
-  const int grp = gt.gid[blockIdx.z];
-  ec += (size_t)grp * gse;
-  z += (size_t)grp * gsz;
-  size_t n = (size_t)nrows * m;
-  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
-       e += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = e / m;
-    const int c = (int)(e - r * m);
-    z[e] += ec[(size_t)aggof[r] * m + c];
-  }
-}
-void launch_prolong_add_b(hipStream_t st, const GroupTab& gt, int nrows, int m, const int* aggof,
-                          const double* ec, size_t gse, double* z, size_t gsz) {
-  size_t n = (size_t)nrows * m;
-  if (!n || gt.ng <= 0) return;
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(prolong_add_kernel, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nrows, m, aggof,
-                     ec, gse, z, gsz);
-}
-void launch_prolong_add(hipStream_t st, int nrows, int m, const int* aggof, const double* ec,
-                        double* z) {
-  launch_prolong_add_b(st, single_group(), nrows, m, aggof, ec, 0, z, 0);
-}
 
 // ---------------------------------------------------------------------------
 // K5/K6: dense tall-skinny products on the FP64 matrix cores.
@@ -2052,16 +1919,5 @@ void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a
 }
 
 // identity matrix (for getrs against I)
-__global__ void set_identity_kernel(int k, double* out) {
-  size_t n = (size_t)k * k;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x)
-    out[i] = (i / k == i % k) ? 1.0 : 0.0;
-}
-void launch_set_identity(hipStream_t st, int k, double* out) {
-  size_t n = (size_t)k * k;
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(set_identity_kernel, dim3(grid), dim3(256), 0, st, k, out);
-}
 
 }  // namespace ricadi

@@ -109,7 +109,6 @@ struct ricadi_ctx {
   DArr<int> s_rp, s_ci;
   DArr<double> srcA, srcE, srcJ;
   DevCsr A, E, J, JT;
-  DArr<double> dA, dE;
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
   DArr<double> bvA, bvE, jd_val;
   DArr<int> agg_ptr, agg_rows, aggof;
@@ -1421,8 +1420,6 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->J.upload(J, st);
   HostCsr JT = transpose(J);
   c->JT.upload(JT, st);
-  c->dA.upload(hs.dA, st);
-  c->dE.upload(hs.dE, st);
   c->bv_ptr.upload(hs.bv_ptr, st);
   c->bv_rows.upload(hs.bv_rows, st);
   c->bp_ptr.upload(hs.bp_ptr, st);
