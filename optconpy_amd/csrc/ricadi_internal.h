@@ -62,6 +62,9 @@ struct HostSetup {
   std::vector<int> agg_ptr, agg_rows;  // aggregates over all n dofs
   std::vector<int> aggof;              // n -> coarse index
   std::vector<double> E0, EM, EJ;      // kc x kc dense
+  // S * Y: CSR over (row, aggregate) with the three value sources of the saddle pattern
+  std::vector<int> sy_rp, sy_ci;
+  std::vector<double> sy_A, sy_E, sy_J;
 };
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
                  HostSetup& hs);

@@ -69,7 +69,7 @@ struct DArr {
 struct ShiftData {
   double alpha = 0, beta = 0;
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
-  DArr<double> sval, svalb, bvinv, bpinv, einv;
+  DArr<double> sval, svalb, syval, bvinv, bpinv, einv;
   // FP32 copies of the inverses, the ones the preconditioner applies (a fixed linear
   // operator either way; halves its HBM traffic).  einvf is stored in 16 x 16 tiles
   // (dense_apply_tiled_kernel).  RICADI_PRECOND64=1 applies the FP64 originals instead.
@@ -113,6 +113,10 @@ struct ricadi_ctx {
   DArr<double> bvA, bvE, jd_val;
   DArr<int> agg_ptr, agg_rows, aggof;
   DArr<double> E0, EM, EJ, ones;
+  // prolongated operator S*Y (CSR, n x kc) for the residual after the coarse correction
+  size_t synnz = 0;
+  DArr<int> sy_rp, sy_ci;
+  DArr<double> sy_A, sy_E, sy_J;
   // LDS-tiled SpMM structure
   int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
   bool sb_ok = false;
@@ -269,6 +273,9 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     if (k > 0) {
       stable_alloc(sd->einv, (size_t)k * k);
       launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
+      stable_alloc(sd->syval, c->synnz);
+      launch_assemble_shift(st, (int)c->synnz, c->sy_A.p, c->sy_E.p, c->sy_J.p, alpha, beta,
+                            sd->syval.p);
     }
   }
   const int nb = (int)todo.size();
@@ -332,7 +339,7 @@ struct Batch {
   int G = 0;                 // groups in the solve (ids 0 .. G-1)
   int m = 0;                 // panel width of every group
   GroupTab tab;              // groups the next launches act on
-  GroupPtrs sval, svalb, bvinv, bpinv, einv;
+  GroupPtrs sval, svalb, syval, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
@@ -355,13 +362,14 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.G = G;
   bt.m = m;
   bt.tab = GroupTab{};
-  bt.sval = bt.svalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
+  bt.sval = bt.svalb = bt.syval = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   for (int g = 0; g < G; ++g) {
     bt.bvinvf.p[g] = sds[g]->bvinvf.p;
     bt.bpinvf.p[g] = sds[g]->bpinvf.p;
     bt.einvf.p[g] = sds[g]->einvf.p;
     bt.sval.p[g] = sds[g]->sval.p;
+    bt.syval.p[g] = sds[g]->syval.p;
     bt.svalb.p[g] = sds[g]->svalb.p;
     bt.bvinv.p[g] = sds[g]->bvinv.p;
     bt.bpinv.p[g] = sds[g]->bpinv.p;
@@ -435,8 +443,10 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
-    // r2 = r - S * (Y ec), prolongation folded into the gather
-    saddle_spmm(c, bt, c->ec.p, bt.gsc, c->aggof.p, c->r2.p, bt.gs, r, gsr, -1.0, 1.0);
+    // r2 = r - (S Y) ec with the prolongated operator (short rows over the L2-resident
+    // coarse vector) -- not a full saddle SpMM through the prolongation map
+    launch_spmm_b(st, gt, c->n, c->sy_rp.p, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr, c->r2.p,
+                  m, bt.gs, r, m, gsr, -1.0, 1.0, m);
     rr = c->r2.p;
     gsrr = bt.gs;
   }
@@ -1432,6 +1442,12 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->agg_ptr.upload(hs.agg_ptr, st);
   c->agg_rows.upload(hs.agg_rows, st);
   c->aggof.upload(hs.aggof, st);
+  c->synnz = hs.sy_ci.size();
+  c->sy_rp.upload(hs.sy_rp, st);
+  c->sy_ci.upload(hs.sy_ci, st);
+  c->sy_A.upload(hs.sy_A, st);
+  c->sy_E.upload(hs.sy_E, st);
+  c->sy_J.upload(hs.sy_J, st);
   c->E0.upload(hs.E0, st);
   c->EM.upload(hs.EM, st);
   c->EJ.upload(hs.EJ, st);
