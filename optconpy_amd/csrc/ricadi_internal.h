@@ -129,15 +129,22 @@ struct LowRankArgs {
   int q = 0, nrows = 0;
 };
 
-// Input of a block-Jacobi sweep produced on the fly:  in = C * src  with a CSR matrix C
-// (rows = the sweep's rows) and a panel src (group stride gss, same leading dimension
-// as `in` would have).  Saves writing and re-reading the intermediate panel.
+// Input of a block-Jacobi sweep produced on the fly:
+//   in[row, :] = base[row, :] + scale * (C * src)[row, :]
+// with a CSR matrix C (rows = the sweep's rows; values per group), a panel src (group
+// stride gss, same leading dimension as `in` would have) and an optional panel base
+// (group stride gsb; NULL = 0).  Saves writing and re-reading the intermediate panel:
+// the J^T product of the SIMPLE sweep (base = NULL, scale = 1) and the residual after
+// the coarse correction r - (S Y) e (base = r, scale = -1).
 struct CsrInArgs {
   const int* rp = nullptr;
   const int* ci = nullptr;
-  const double* v = nullptr;
+  GroupPtrs v = {};
   const double* src = nullptr;
   size_t gss = 0;
+  const double* base = nullptr;
+  size_t gsb = 0;
+  double scale = 1.0;
 };
 
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
@@ -146,7 +153,8 @@ struct CsrInArgs {
 void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
-                   double alpha, double beta_r, int m, const LowRankArgs& lr = LowRankArgs());
+                   double alpha, double beta_r, int m, const LowRankArgs& lr = LowRankArgs(),
+                   int chunk = 16);   // chunk = 8: matrices with short rows (<= ~10 entries)
 void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2,
                            const int* rp2, const int* cols2, const uint16_t* lidx,
                            const GroupPtrs& vals, const double* x, int ldx, size_t gsx, double* y,

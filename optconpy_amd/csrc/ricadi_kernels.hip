@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256) void spmm_kernel(
 // so the inner loop is branch free.  Row blocks are dealt to the 8 XCDs in
 // contiguous ranges (blockIdx % 8 selects the range), which keeps the gathered
 // x rows of a band matrix inside that XCD's L2.
-template <int CPL>
+// CHK = entries per chunk (16, or 8 for matrices with short rows such as S*Y: half the
+// broadcast steps are saved when a row has <= 8 entries).
+template <int CPL, int CHK>
 __global__ __launch_bounds__(256) void spmm_kernel_v2(
     GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
     GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
@@ -151,14 +153,14 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
   const int k0 = live ? rp[row] : 0, k1 = live ? rp[row + 1] : 0;
   // all 4 groups of the wave iterate the same number of chunks (shuffles need
   // every lane): take the wave-wide maximum
-  int nch = (k1 - k0 + 15) >> 4;
+  int nch = (k1 - k0 + CHK - 1) / CHK;
   nch = max(nch, __shfl_xor(nch, 16, 64));
   nch = max(nch, __shfl_xor(nch, 32, 64));
   for (int ch = 0; ch < nch; ++ch) {
-    const int k = k0 + ch * 16 + g;
+    const int k = k0 + ch * CHK + g;
     int myc = 0;            // padding: val = 0 times row 0 of x (always a valid row;
     double myv = 0.0;       // the matrix may be rectangular, so "own row" is not)
-    if (k < k1) {
+    if (g < CHK && k < k1) {
       myc = ci[k];
       myv = val[k];
       if (xmap) myc = xmap[myc];
@@ -171,7 +173,12 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
     _Pragma("unroll") for (int c = 0; c < CPL; ++c)                   \
         acc[c] = fma(v0, x0[colx[c]], acc[c]);                        \
   }
-    RICADI_FOR16(RICADI_V2_STEP)
+    if (CHK == 16) {
+      RICADI_FOR16(RICADI_V2_STEP)
+    } else {
+      RICADI_V2_STEP(0) RICADI_V2_STEP(1) RICADI_V2_STEP(2) RICADI_V2_STEP(3)
+      RICADI_V2_STEP(4) RICADI_V2_STEP(5) RICADI_V2_STEP(6) RICADI_V2_STEP(7)
+    }
 #undef RICADI_V2_STEP
   }
   if (!live) return;
@@ -201,15 +208,25 @@ static void spmm_dispatch(hipStream_t st, const GroupTab& gt, int nrows, const i
                           const int* ci, const GroupPtrs& vals, const double* x, int ldx,
                           size_t gsx, const int* xmap, double* y, int ldy, size_t gsy,
                           const double* r, int ldr, size_t gsr, double alpha, double beta_r,
-                          const double* rowscale, int m, const LowRankArgs& lr = LowRankArgs()) {
+                          const double* rowscale, int m, const LowRankArgs& lr = LowRankArgs(),
+                          int chunk = 16) {
   if (nrows <= 0 || m <= 0 || gt.ng <= 0) return;
   dim3 grid((nrows + 15) / 16, 1, gt.ng), block(256);
   const int cpl = (m + 15) / 16;
   const bool v2 = spmm_variant() == 2;
+  if (v2 && chunk == 8 && cpl <= 2) {
+    if (cpl == 1)
+      hipLaunchKernelGGL((spmm_kernel_v2<1, 8>), grid, block, 0, st, gt, nrows, rp, ci, vals, x, ldx,
+                         gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, rowscale, m, lr);
+    else
+      hipLaunchKernelGGL((spmm_kernel_v2<2, 8>), grid, block, 0, st, gt, nrows, rp, ci, vals, x, ldx,
+                         gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, rowscale, m, lr);
+    return;
+  }
 #define RICADI_SPMM_CASE(C)                                                              \
   case C:                                                                                \
     if (v2)                                                                              \
-      hipLaunchKernelGGL(spmm_kernel_v2<C>, grid, block, 0, st, gt, nrows, rp, ci, vals, \
+      hipLaunchKernelGGL((spmm_kernel_v2<C, 16>), grid, block, 0, st, gt, nrows, rp, ci, vals, \
                          x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha, beta_r,     \
                          rowscale, m, lr);                                               \
     else                                                                                 \
@@ -241,9 +258,9 @@ void launch_spmm(hipStream_t st, int nrows, const int* rp, const int* ci, const 
 void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,
-                   double alpha, double beta_r, int m, const LowRankArgs& lr) {
+                   double alpha, double beta_r, int m, const LowRankArgs& lr, int chunk) {
   spmm_dispatch(st, gt, nrows, rp, ci, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha,
-                beta_r, nullptr, m, lr);
+                beta_r, nullptr, m, lr, chunk);
 }
 
 // ---------------------------------------------------------------------------
@@ -1049,6 +1066,8 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
   in += (size_t)grp * gsi;
   out += (size_t)grp * gso;
   const double* __restrict__ csrc = ci.rp ? ci.src + (size_t)grp * ci.gss : nullptr;
+  const double* __restrict__ cval = ci.v.p[grp];
+  const double* __restrict__ cbase = ci.base ? ci.base + (size_t)grp * ci.gsb : nullptr;
   const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
   // One wave per block, FP64 MFMA 16x16x4: out_tile (16 rows x 16 cols) +=
   // inv[rows 16*ti.., k] * x[k, cols].  A-operand lane (r = l&15, q = l>>4)
@@ -1086,20 +1105,22 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
         if (!csrc) {
           xb[s2] = (kk < nb && col < m) ? in[(size_t)rows[b0 + kk] * ldi + col] : 0.0;
         } else {
-          // input row computed on the fly: (C * src)[row, col] with the CSR matrix C
-          // (the J^T product of the SIMPLE sweep; src = pressure part, L2 resident)
-          double acc0 = 0.0, acc1 = 0.0;
+          // input row computed on the fly: base[row] + scale * (C * src)[row] with the CSR
+          // matrix C (J^T product of the SIMPLE sweep / residual after the coarse
+          // correction; src is small and L2 resident)
+          double acc0 = 0.0, acc1 = 0.0, bv = 0.0;
           if (kk < nb && col < m) {
             const int row = rows[b0 + kk];
             int k = ci.rp[row];
             const int k1 = ci.rp[row + 1];
+            if (cbase) bv = cbase[(size_t)row * ldi + col];
             for (; k + 1 < k1; k += 2) {
-              acc0 = fma(ci.v[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
-              acc1 = fma(ci.v[k + 1], csrc[(size_t)ci.ci[k + 1] * ldi + col], acc1);
+              acc0 = fma(cval[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
+              acc1 = fma(cval[k + 1], csrc[(size_t)ci.ci[k + 1] * ldi + col], acc1);
             }
-            if (k < k1) acc0 = fma(ci.v[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
+            if (k < k1) acc0 = fma(cval[k], csrc[(size_t)ci.ci[k] * ldi + col], acc0);
           }
-          xb[s2] = acc0 + acc1;
+          xb[s2] = fma(ci.scale, acc0 + acc1, bv);
         }
       }
 #pragma unroll
