@@ -385,6 +385,45 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       hs.sy_rp.push_back((int)hs.sy_ci.size());
     }
   }
+  // S*Y in the tile format of the LDS-tiled SpMM, on the SAME row blocks as S: per block
+  // the distinct aggregates its rows touch (the LDS tile of coarse-vector rows) and per
+  // entry the 16-bit tile row; values are gathered through sy_perm.
+  hs.syb_rp.assign(1, 0);
+  hs.syb_cptr.assign(1, 0);
+  hs.syb_cols.clear();
+  hs.syb_perm.clear();
+  hs.syb_lidx.clear();
+  hs.syb_max_cols = 0;
+  {
+    std::vector<int> pos(kc, -1), cols;
+    for (int b = 0; b < hs.sb_nblk; ++b) {
+      cols.clear();
+      for (int q = hs.sb_rowptr[b]; q < hs.sb_rowptr[b + 1]; ++q) {
+        const int row = hs.sb_rows[q];
+        for (int k = hs.sy_rp[row]; k < hs.sy_rp[row + 1]; ++k)
+          if (pos[hs.sy_ci[k]] < 0) {
+            pos[hs.sy_ci[k]] = 0;
+            cols.push_back(hs.sy_ci[k]);
+          }
+      }
+      std::sort(cols.begin(), cols.end());
+      for (size_t j = 0; j < cols.size(); ++j) pos[cols[j]] = (int)j;
+      for (int q = hs.sb_rowptr[b]; q < hs.sb_rowptr[b + 1]; ++q) {
+        const int row = hs.sb_rows[q];
+        for (int k = hs.sy_rp[row]; k < hs.sy_rp[row + 1]; ++k) {
+          hs.syb_perm.push_back(k);
+          hs.syb_lidx.push_back((uint16_t)pos[hs.sy_ci[k]]);
+        }
+        hs.syb_rp.push_back((int)hs.syb_perm.size());
+      }
+      for (int c : cols) {
+        hs.syb_cols.push_back(c);
+        pos[c] = -1;
+      }
+      hs.syb_cptr.push_back((int)hs.syb_cols.size());
+      hs.syb_max_cols = std::max(hs.syb_max_cols, (int)cols.size());
+    }
+  }
 }
 
 // Cauchy data of one shift-parallel ADI sweep:

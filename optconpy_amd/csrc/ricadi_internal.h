@@ -65,6 +65,10 @@ struct HostSetup {
   // S * Y: CSR over (row, aggregate) with the three value sources of the saddle pattern
   std::vector<int> sy_rp, sy_ci;
   std::vector<double> sy_A, sy_E, sy_J;
+  // ... and in tile format on the row blocks of the saddle operator
+  int syb_max_cols = 0;
+  std::vector<int> syb_rp, syb_cptr, syb_cols, syb_perm;
+  std::vector<uint16_t> syb_lidx;
 };
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
                  HostSetup& hs);

@@ -69,7 +69,7 @@ struct DArr {
 struct ShiftData {
   double alpha = 0, beta = 0;
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
-  DArr<double> sval, svalb, syval, bvinv, bpinv, einv;
+  DArr<double> sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   // FP32 copies of the inverses, the ones the preconditioner applies (a fixed linear
   // operator either way; halves its HBM traffic).  einvf is stored in 16 x 16 tiles
   // (dense_apply_tiled_kernel).  RICADI_PRECOND64=1 applies the FP64 originals instead.
@@ -118,6 +118,11 @@ struct ricadi_ctx {
   int sy_chunk = 16;          // 8 when its rows are short (mean <= 10 entries)
   DArr<int> sy_rp, sy_ci;
   DArr<double> sy_A, sy_E, sy_J;
+  // tile format of S*Y on the saddle operator's row blocks (rows2 shared)
+  int syb_max_cols = 0;
+  bool syb_ok = false;
+  DArr<int> syb_rp2, syb_cols2, syb_perm;
+  DArr<uint16_t> syb_lidx;
   // LDS-tiled SpMM structure
   int sb_nblk = 0, sb_max_cols = 0, sb_max_nnz = 0;
   bool sb_ok = false;
@@ -277,6 +282,10 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       stable_alloc(sd->syval, c->synnz);
       launch_assemble_shift(st, (int)c->synnz, c->sy_A.p, c->sy_E.p, c->sy_J.p, alpha, beta,
                             sd->syval.p);
+      if (c->syb_ok) {
+        stable_alloc(sd->syvalb, c->synnz);
+        launch_gather_vals(st, (int)c->synnz, c->syb_perm.p, sd->syval.p, sd->syvalb.p);
+      }
     }
   }
   const int nb = (int)todo.size();
@@ -340,7 +349,7 @@ struct Batch {
   int G = 0;                 // groups in the solve (ids 0 .. G-1)
   int m = 0;                 // panel width of every group
   GroupTab tab;              // groups the next launches act on
-  GroupPtrs sval, svalb, syval, bvinv, bpinv, einv;
+  GroupPtrs sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
@@ -363,7 +372,7 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.G = G;
   bt.m = m;
   bt.tab = GroupTab{};
-  bt.sval = bt.svalb = bt.syval = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
+  bt.sval = bt.svalb = bt.syval = bt.syvalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   for (int g = 0; g < G; ++g) {
     bt.bvinvf.p[g] = sds[g]->bvinvf.p;
@@ -371,6 +380,7 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
     bt.einvf.p[g] = sds[g]->einvf.p;
     bt.sval.p[g] = sds[g]->sval.p;
     bt.syval.p[g] = sds[g]->syval.p;
+    bt.syvalb.p[g] = sds[g]->syvalb.p;
     bt.svalb.p[g] = sds[g]->svalb.p;
     bt.bvinv.p[g] = sds[g]->bvinv.p;
     bt.bpinv.p[g] = sds[g]->bpinv.p;
@@ -449,8 +459,16 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // through the prolongation map.  (Forming the velocity rows of r2 inside the first
     // velocity sweep instead, like the J^T product below, was measured slower: 249 vs
     // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
-    launch_spmm_b(st, gt, c->n, c->sy_rp.p, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
-                  c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, LowRankArgs(), c->sy_chunk);
+    // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
+    static const bool sy_csr = getenv("RICADI_SY_CSR") != nullptr;
+    if (c->syb_ok && !sy_csr &&
+        spmm_blocked_lds_bytes(m, c->syb_max_cols, 0) <= (size_t)40 * 1024)
+      launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
+                            c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, bt.gs, r, m, gsr,
+                            -1.0, 1.0, m, c->syb_max_cols);
+    else
+      launch_spmm_b(st, gt, c->n, c->sy_rp.p, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
+                    c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, LowRankArgs(), c->sy_chunk);
     rr = c->r2.p;
     gsrr = bt.gs;
   }
@@ -1456,6 +1474,22 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->sy_A.upload(hs.sy_A, st);
   c->sy_E.upload(hs.sy_E, st);
   c->sy_J.upload(hs.sy_J, st);
+  c->syb_ok = hs.kc > 0 && hs.sb_nblk > 0 && hs.syb_max_cols > 0;
+  c->syb_max_cols = hs.syb_max_cols;
+  if (c->syb_ok) {
+    const int nb = hs.sb_nblk, mc = hs.syb_max_cols;
+    std::vector<int> rp2((size_t)nb * 33, 0), cols2((size_t)nb * mc, -1);
+    for (int b = 0; b < nb; ++b) {
+      const int q0 = hs.sb_rowptr[b], nr = hs.sb_rowptr[b + 1] - q0;
+      for (int q = 0; q <= 32; ++q) rp2[(size_t)b * 33 + q] = hs.syb_rp[q0 + std::min(q, nr)];
+      const int c0 = hs.syb_cptr[b], nc = hs.syb_cptr[b + 1] - c0;
+      for (int j = 0; j < nc; ++j) cols2[(size_t)b * mc + j] = hs.syb_cols[c0 + j];
+    }
+    c->syb_rp2.upload(rp2, st);
+    c->syb_cols2.upload(cols2, st);
+    c->syb_perm.upload(hs.syb_perm, st);
+    c->syb_lidx.upload(hs.syb_lidx, st);
+  }
   c->E0.upload(hs.E0, st);
   c->EM.upload(hs.EM, st);
   c->EJ.upload(hs.EJ, st);
