@@ -607,11 +607,18 @@ __global__ __launch_bounds__(256) void cols_dots_kernel(
     int r = 0;
     if (i < nvec) {
       const BT* v = basis + (size_t)i * vstride + (size_t)r0 * m + c;
-      for (; r + 1 < nr; r += 2) {
-        s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
-        s1 = fma((double)v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+      double s2 = 0.0, s3 = 0.0;
+      for (; r + 3 < nr; r += 4) {       // four independent row loads in flight
+        const double v0 = (double)v[(size_t)r * m], v1 = (double)v[(size_t)(r + 1) * m];
+        const double v2 = (double)v[(size_t)(r + 2) * m], v3 = (double)v[(size_t)(r + 3) * m];
+        s0 = fma(v0, wl[r * m + c], s0);
+        s1 = fma(v1, wl[(r + 1) * m + c], s1);
+        s2 = fma(v2, wl[(r + 2) * m + c], s2);
+        s3 = fma(v3, wl[(r + 3) * m + c], s3);
       }
-      if (r < nr) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+      for (; r < nr; ++r) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+      s0 += s2;
+      s1 += s3;
     } else {
       for (; r < nr; ++r) s0 = fma(wl[r * m + c], wl[r * m + c], s0);
     }
@@ -734,11 +741,18 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
     if (i < nvec) {
       const BT* v = basis + (size_t)i * vstride + base + c;
       int r = 0;
-      for (; r + 1 < nr; r += 2) {
-        s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
-        s1 = fma((double)v[(size_t)(r + 1) * m], wl[(r + 1) * m + c], s1);
+      double s2 = 0.0, s3 = 0.0;
+      for (; r + 3 < nr; r += 4) {
+        const double v0 = (double)v[(size_t)r * m], v1 = (double)v[(size_t)(r + 1) * m];
+        const double v2 = (double)v[(size_t)(r + 2) * m], v3 = (double)v[(size_t)(r + 3) * m];
+        s0 = fma(v0, wl[r * m + c], s0);
+        s1 = fma(v1, wl[(r + 1) * m + c], s1);
+        s2 = fma(v2, wl[(r + 2) * m + c], s2);
+        s3 = fma(v3, wl[(r + 3) * m + c], s3);
       }
-      if (r < nr) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+      for (; r < nr; ++r) s0 = fma((double)v[(size_t)r * m], wl[r * m + c], s0);
+      s0 += s2;
+      s1 += s3;
     } else {
       for (int r = 0; r < nr; ++r) s0 = fma(wl[r * m + c], wl[r * m + c], s0);
     }
