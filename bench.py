@@ -149,7 +149,11 @@ def main():
     ap.add_argument("--nu", type=float, default=0.05)
     ap.add_argument("--shifts", type=int, default=16)
     ap.add_argument("--sequential", action="store_true",
-                    help="N=1 only: single-stream sequential ADI inside libricadi_hip.so")
+                    help="N=1 only: the Newton step through ricadi_ric_newtonadi (the drop-in's C++ "
+                         "path), ADI steps one at a time")
+    ap.add_argument("--cpp-sweeps", action="store_true",
+                    help="with --sequential: the same C++ path in sweep form (sweep_width = "
+                         "--sweep-width), as optconpy_amd.proj_ric_utils.proj_alg_ric_newtonadi runs it")
     ap.add_argument("--sweep-width", type=int, default=8, help="shifts per sweep (<= 8)")
     ap.add_argument("--streams", type=int, default=1,
                     help="1 (default): the shifts of a rank go through one batched solve; k > 1: "
@@ -190,7 +194,8 @@ def main():
     d = dict(pb.default_nwtn_adi_dict(), ms=ms)
     prm_full = _lib.adi_params(d)
     prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1,
-                                   compress_cols=int(os.environ.get("RICADI_CC", "0"))))
+                                   compress_cols=int(os.environ.get("RICADI_CC", "0")),
+                                   sweep_width=args.sweep_width if args.cpp_sweeps else 1))
     nb, mw = tb.shape[1], trct.shape[1]
     m = nb + mw
     n = pr.NV + pr.NP
@@ -300,7 +305,9 @@ def main():
                             % (args.N, n, nnz_s, args.nu, len(ms), m),
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),
-                "parallelism": "sequential ADI, 1 GPU" if not use_sp
+                "parallelism": ("C++ Newton-ADI, %s, 1 GPU" % ("sweeps of %d shifts in one batched solve"
+                                                              % args.sweep_width if args.cpp_sweeps
+                                                              else "ADI steps one at a time")) if not use_sp
                 else "shift-parallel ADI on %d GPU(s), %d shifts/sweep, %s, 1 all-gather/sweep"
                 % (world, G, "one batched lockstep solve per rank and sweep" if nstreams == 1
                    else "%d concurrent stream(s)/GPU" % nstreams),

@@ -80,6 +80,14 @@ typedef struct ricadi_adi_params {
                             sqrt(eps)*sigma_1, i.e. exact to rounding in Z Z^T).
                             0: ricadi_lyap_adi keeps the raw ADI columns like
                             the reference; ricadi_ric_newtonadi uses 512.      */
+  int sweep_width;       /* 1 (default): ADI steps one at a time, as the reference.
+                            G > 1: sweep form -- G consecutive steps (distinct
+                            shifts) are solved together in one batched GMRES and
+                            recombined with their Cauchy matrix; same Z Z^T, the
+                            stopping rule is applied every G steps.  Falls back to
+                            1 when the shift list has repeats, fewer than G
+                            entries or an ill-conditioned Cauchy matrix.  G <= 16;
+                            8 is what the benchmark uses.                       */
 } ricadi_adi_params;
 
 const char* ricadi_last_error(void);

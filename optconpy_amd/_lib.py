@@ -31,7 +31,7 @@ class RicadiAdiParams(C.Structure):
     _fields_ = [("adi_max_steps", C.c_int), ("adi_newZ_reltol", C.c_double),
                 ("nwtn_max_steps", C.c_int), ("nwtn_upd_reltol", C.c_double),
                 ("nwtn_upd_abstol", C.c_double), ("project_w", C.c_int),
-                ("verbose", C.c_int), ("compress_cols", C.c_int)]
+                ("verbose", C.c_int), ("compress_cols", C.c_int), ("sweep_width", C.c_int)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -199,6 +199,7 @@ def adi_params(d=None, project_w=True):
     p.verbose = 1 if d.get("verbose", False) else 0
     p.project_w = 1 if d.get("project_w", project_w) else 0
     p.compress_cols = int(d.get("compress_cols", 0))
+    p.sweep_width = int(d.get("sweep_width", 1))
     return p
 
 

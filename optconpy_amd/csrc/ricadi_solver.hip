@@ -7,6 +7,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cmath>
+#include <numeric>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -137,6 +138,7 @@ struct ricadi_ctx {
   long lr_epoch = 0;          // bumped whenever U / V change
   bool smw = true;            // RICADI_SMW=0: keep the low-rank term inside the Krylov operator
   DArr<double> smw_rhs, smw_x, smw_cap;
+  DArr<double> sweep_u, sweep_t, sweep_coef;   // ADI sweeps: the G solutions, a panel, coefficients
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
@@ -1013,9 +1015,113 @@ struct AdiStats {
 
 // dW: NV x m device panel (overwritten by the final residual factor).
 // Appends sqrt(-2p) V_i to c->Z (ld = c->zld) starting at column c->zc.
+// Sweep form of the same ADI: G consecutive steps
+// with distinct shifts are G independent solves against the SAME residual factor,
+//   S(p_g) [U_g; *] = [W; 0],
+// recombined with the G x G Cauchy matrix C_ij = -1/(p_i+p_j) = R^T R:
+//   Z-block = U (R^-1 (x) I),   W <- W + E U ((C^-1 1) (x) I)
+// -- identical to the G sequential steps up to a rotation of the block's columns (Z Z^T
+// and the gain are the same).  The G solves go through ONE batched lockstep GMRES, which
+// is what fills the GPU at n ~ 3e4.  The stopping rule is applied per sweep (mean block
+// norm).  Returns false (nothing done) if the shift list does not allow sweeps.
+static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
+                                const ricadi_adi_params& prm, AdiStats& stt) {
+  const int G = std::min(std::min(prm.sweep_width, ns), RICADI_MAX_GROUPS);
+  if (G < 2 || prm.adi_max_steps < G || G * m > 2048) return false;
+  for (int i = 0; i < ns; ++i)
+    for (int j = i + 1; j < ns; ++j)
+      if (shifts[i] == shifts[j]) return false;     // sweeps need distinct shifts
+  // Cauchy data of every sweep of the cycle up front: a numerically singular Cauchy
+  // matrix (shifts too many / too close) sends the caller back to the sequential form
+  const int ncyc = ns / std::gcd(ns, G);          // sweeps until the shift pattern repeats
+  std::vector<std::vector<double>> rinvs(ncyc), cinvs(ncyc);
+  std::vector<std::vector<double>> pss(ncyc);
+  for (int sw = 0; sw < ncyc; ++sw) {
+    pss[sw].resize(G);
+    for (int g = 0; g < G; ++g) pss[sw][g] = shifts[(sw * G + g) % ns];
+    rinvs[sw].resize((size_t)G * G);
+    cinvs[sw].resize(G);
+    if (cauchy_data(pss[sw].data(), G, rinvs[sw].data(), cinvs[sw].data()) != RICADI_OK) return false;
+  }
+  hipStream_t st = c->st;
+  const int n = c->n, nv = c->nv;
+  const size_t nm = (size_t)n * m;
+  ensure_work(c, m, G);
+  if (prm.project_w) project_panel(c, dW, m);
+  const long it0 = c->total_iters;
+  c->sweep_u.ensure(nm * G);
+  c->sweep_t.ensure((size_t)nv * m);
+  c->sweep_coef.ensure((size_t)(G + 1) * G * m);
+  double znorm2 = 0.0;
+  int zc_last = c->zc;
+  std::vector<double> be(G, 1.0), coef((size_t)(G + 1) * G * m);
+  std::vector<ShiftData*> sds(G);
+  std::vector<GmresResult> res(G);
+  int steps = 0;
+  for (int sw = 0; steps + G <= prm.adi_max_steps; ++sw) {
+    const std::vector<double>& ps = pss[sw % ncyc];
+    const std::vector<double>& rinv = rinvs[sw % ncyc];
+    const std::vector<double>& cinv1 = cinvs[sw % ncyc];
+    get_shifts(c, ps.data(), be.data(), G, sds.data());
+    load_rhs(c, dW, m, c->bvec.p);
+    solve_batch(c, sds.data(), G, c->bvec.p, 0, c->sweep_u.p, m, true, nullptr, res.data());
+    for (int g = 0; g < G; ++g)
+      if (!res[g].converged) {
+        stt.nonconverged++;
+        stt.worst_relres = std::max(stt.worst_relres, res[g].max_relres);
+      }
+    stt.shift_solves += G;
+    // coefficient rows (replicated over the m columns): G columns of R^-1, then C^-1 1
+    for (int j = 0; j <= G; ++j)
+      for (int i = 0; i < G; ++i) {
+        const double v = j < G ? rinv[(size_t)i * G + j] : cinv1[i];
+        for (int cidx = 0; cidx < m; ++cidx) coef[((size_t)j * G + i) * m + cidx] = v;
+      }
+    HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * coef.size(),
+                          hipMemcpyHostToDevice, st));
+    // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
+    for (int j = 0; j < G; ++j) {
+      launch_cols_update(st, nv, m, G, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)j * G * m, 1.0,
+                         nullptr, nullptr, c->sweep_t.p);
+      launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, c->Z.p, c->zld, c->zc + j * m, 1.0);
+      col_norms2(c, c->sweep_t.p, nv, m, c->nrm2.p + (size_t)j * m);
+    }
+    // W <- W + E (U C^-1 1)
+    launch_cols_update(st, nv, m, G, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)G * G * m, 1.0,
+                       nullptr, nullptr, c->sweep_t.p);
+    launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0,
+                1.0, nullptr, m);
+    HIPCHK(hipMemcpyAsync(c->h_resid, c->nrm2.p, sizeof(double) * G * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double n2 = 0.0;
+    for (int j = 0; j < G * m; ++j) n2 += c->h_resid[j];
+    znorm2 += n2;
+    c->zc += G * m;
+    steps += G;
+    stt.steps = steps;
+    stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / G / znorm2) : 0.0;
+    if (prm.verbose) {
+      int its = 0;
+      for (int g = 0; g < G; ++g) its = std::max(its, res[g].iters);
+      fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d\n",
+              sw + 1, steps - G + 1, steps, stt.rel, its);
+    }
+    if (stt.rel < prm.adi_newZ_reltol) break;
+    if (prm.compress_cols > 0 && c->zc - zc_last >= prm.compress_cols) {
+      factor_recompress(c);
+      zc_last = c->zc;
+    }
+  }
+  stt.gmres_iters = c->total_iters - it0;
+  DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
+  return true;
+}
+
 static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
                              const ricadi_adi_params& prm) {
   AdiStats stt;
+  if (prm.sweep_width > 1 && lyap_adi_sweeps_dev(c, shifts, ns, dW, m, prm, stt)) return stt;
+  stt = AdiStats();
   hipStream_t st = c->st;
   ensure_work(c, m);
   if (prm.project_w) project_panel(c, dW, m);
@@ -1347,6 +1453,7 @@ void ricadi_default_adi_params(ricadi_adi_params* p) {
   p->project_w = 1;
   p->verbose = 0;
   p->compress_cols = 0;
+  p->sweep_width = 1;
 }
 
 int ricadi_create(int device_id, ricadi_ctx** out) {

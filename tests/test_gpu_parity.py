@@ -498,3 +498,35 @@ def test_batched_shift_solve_matches_single():
             assert abs(it1 - its[g]) <= max(2, 0.4 * it1)
             assert rel(Xh[g], Xs) < 1e-8
     ctx.close()
+
+
+def test_cpp_sweep_adi_matches_stepwise_adi():
+    """ricadi_lyap_adi with sweep_width = G (G steps = one batched solve + Cauchy recombination)
+    against the step-by-step recurrence: same Z Z^T after the same number of steps; a shift
+    list with repeats silently falls back to the step-by-step form."""
+    pr = pb.ricc_problem(15, 0.05)
+    ctx = _lib.Context(0)
+    ctx.set_operator((-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr(), pr.J)
+    rng = np.random.default_rng(11)
+    W = rng.standard_normal((pr.NV, 5))
+    B = rng.standard_normal((pr.NV, 3))
+    ms = pb.logshifts(1.0, 1e3, 8)
+    for G in (2, 4, 8):
+        d = dict(adi_max_steps=24, adi_newZ_reltol=0.0, ms=ms)
+        Z1, i1 = ctx.lyap_adi(ms, W, _lib.adi_params(d))
+        Zs, i2 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, sweep_width=G)))
+        assert i1["adi_steps"] == i2["adi_steps"] == 24 and Zs.shape == Z1.shape
+        assert rel(Zs @ (Zs.T @ B), Z1 @ (Z1.T @ B)) < 1e-8
+    # stopping rule at sweep granularity
+    d = dict(adi_max_steps=200, adi_newZ_reltol=1e-8, ms=ms)
+    Z1, i1 = ctx.lyap_adi(ms, W, _lib.adi_params(d))
+    Zs, i2 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, sweep_width=8)))
+    assert i2["adi_steps"] % 8 == 0 and abs(i2["adi_steps"] - i1["adi_steps"]) <= 16
+    assert rel(Zs @ (Zs.T @ B), Z1 @ (Z1.T @ B)) < 1e-6
+    # repeated shifts: no sweeps possible, the result is the step-by-step one
+    ms_rep = np.r_[ms[:4], ms[:4]]
+    d = dict(adi_max_steps=16, adi_newZ_reltol=0.0)
+    Za, _ = ctx.lyap_adi(ms_rep, W, _lib.adi_params(d))
+    Zb, _ = ctx.lyap_adi(ms_rep, W, _lib.adi_params(dict(d, sweep_width=4)))
+    assert rel(Zb, Za) < 1e-7
+    ctx.close()
