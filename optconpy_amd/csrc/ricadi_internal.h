@@ -267,13 +267,14 @@ void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* 
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                         size_t vstride, const double* h, double sign, const double* w,
                         const double* scale, double* out);
+// setup kernels for up to RICADI_MAX_GROUPS shifts per launch (blockIdx.y = shift)
+void launch_schur_blocks_bj(hipStream_t st, int nshift, int nblocks, int bs, const int* bptr,
+                            const int* jd_ptr, const int* jd_vblk, const double* jd_val,
+                            const GroupPtrs& bvinv, const GroupPtrs& blocks);
+void launch_block_invert(hipStream_t st, int nshift, int nblocks, int bs, const int* bptr,
+                         const GroupPtrs& blocks, int* flag);
 void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const double* Be,
                           double alpha, double beta, double* out);
-void launch_schur_blocks_bj(hipStream_t st, int nblocks, int bs, const int* bptr, const int* jd_ptr,
-                            const int* jd_vblk, const double* jd_val, const double* bvinv,
-                            double* blocks);
-void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
-                         int* flag);
 void launch_gemm_tn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* B,
                     int ldb, double* C, int ldc);
 void launch_gemm_nn(hipStream_t st, int n, int p, int q, const double* A, int lda, const double* C,

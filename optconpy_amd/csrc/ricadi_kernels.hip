@@ -1226,7 +1226,10 @@ void launch_block_combine(hipStream_t st, size_t n, const double* Ba, const doub
 __global__ __launch_bounds__(256) void schur_blocks_bj_kernel(
     int bs, const int* __restrict__ bptr, const int* __restrict__ jd_ptr,
     const int* __restrict__ jd_vblk, const double* __restrict__ jd_val,
-    const double* __restrict__ bvinv, double* __restrict__ blocks) {
+    GroupPtrs bvinvs, GroupPtrs blockss) {
+  // one launch serves all shifts being set up: blockIdx.y = shift
+  const double* __restrict__ bvinv = bvinvs.p[blockIdx.y];
+  double* __restrict__ blocks = const_cast<double*>(blockss.p[blockIdx.y]);
   extern __shared__ double sm[];           // Jd, Ai, T : 3 x bs x bs
   double* Jd = sm;
   double* Ai = sm + bs * bs;
@@ -1266,11 +1269,11 @@ __global__ __launch_bounds__(256) void schur_blocks_bj_kernel(
     Bb[e] = (i < nb && k < nb) ? acc[t] : (i == k ? 1.0 : 0.0);
   }
 }
-void launch_schur_blocks_bj(hipStream_t st, int nblocks, int bs, const int* bptr, const int* jd_ptr,
-                            const int* jd_vblk, const double* jd_val, const double* bvinv,
-                            double* blocks) {
+void launch_schur_blocks_bj(hipStream_t st, int nshift, int nblocks, int bs, const int* bptr,
+                            const int* jd_ptr, const int* jd_vblk, const double* jd_val,
+                            const GroupPtrs& bvinv, const GroupPtrs& blocks) {
   if (nblocks <= 0) return;
-  hipLaunchKernelGGL(schur_blocks_bj_kernel, dim3(nblocks), dim3(256),
+  hipLaunchKernelGGL(schur_blocks_bj_kernel, dim3(nblocks, nshift), dim3(256),
                      (size_t)3 * bs * bs * sizeof(double), st, bs, bptr, jd_ptr, jd_vblk, jd_val, bvinv,
                      blocks);
 }
@@ -1278,8 +1281,9 @@ void launch_schur_blocks_bj(hipStream_t st, int nblocks, int bs, const int* bptr
 // In-place inverse of dense bs x bs blocks by Gauss-Jordan with partial
 // pivoting in LDS; one workgroup per block.  flag[0] is set to 1 on a zero pivot.
 __global__ __launch_bounds__(256) void block_invert_kernel(int bs, const int* __restrict__ bptr,
-                                                           double* __restrict__ blocks,
+                                                           GroupPtrs blockss,
                                                            int* __restrict__ flag) {
+  double* __restrict__ blocks = const_cast<double*>(blockss.p[blockIdx.y]);   // blockIdx.y = shift
   extern __shared__ double sm[];  // bs x (2*bs) augmented matrix
   __shared__ int piv;
   __shared__ double pivval;
@@ -1336,10 +1340,10 @@ __global__ __launch_bounds__(256) void block_invert_kernel(int bs, const int* __
     Bb[e] = sm[i * W + bs + j];
   }
 }
-void launch_block_invert(hipStream_t st, int nblocks, int bs, const int* bptr, double* blocks,
-                         int* flag) {
-  if (nblocks <= 0) return;
-  hipLaunchKernelGGL(block_invert_kernel, dim3(nblocks), dim3(256),
+void launch_block_invert(hipStream_t st, int nshift, int nblocks, int bs, const int* bptr,
+                         const GroupPtrs& blocks, int* flag) {
+  if (nblocks <= 0 || nshift <= 0) return;
+  hipLaunchKernelGGL(block_invert_kernel, dim3(nblocks, nshift), dim3(256),
                      (size_t)bs * 2 * bs * sizeof(double), st, bs, bptr, blocks, flag);
 }
 

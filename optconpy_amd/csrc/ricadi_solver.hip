@@ -271,13 +271,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     }
     stable_alloc(sd->bvinv, (size_t)c->nbv * bsz);
     launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
-    launch_block_invert(st, c->nbv, c->bs, c->bv_ptr.p, sd->bvinv.p, c->flag.p);
-    if (c->nbp > 0) {
-      stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
-      launch_schur_blocks_bj(st, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p, c->jd_val.p,
-                             sd->bvinv.p, sd->bpinv.p);
-      launch_block_invert(st, c->nbp, c->bs, c->bp_ptr.p, sd->bpinv.p, c->flag.p);
-    }
+    if (c->nbp > 0) stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
     if (k > 0) {
       stable_alloc(sd->einv, (size_t)k * k);
       launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
@@ -288,6 +282,21 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         stable_alloc(sd->syvalb, c->synnz);
         launch_gather_vals(st, (int)c->synnz, c->syb_perm.p, sd->syval.p, sd->syvalb.p);
       }
+    }
+  }
+  // block inversions and Schur blocks: one launch each for all shifts (<= 16 per call)
+  for (size_t t0 = 0; t0 < todo.size(); t0 += RICADI_MAX_GROUPS) {
+    const int cnt = (int)std::min<size_t>(RICADI_MAX_GROUPS, todo.size() - t0);
+    GroupPtrs pv = same_ptr((const double*)nullptr), pp = pv;
+    for (int i = 0; i < cnt; ++i) {
+      pv.p[i] = todo[t0 + i]->bvinv.p;
+      pp.p[i] = todo[t0 + i]->bpinv.p;
+    }
+    launch_block_invert(st, cnt, c->nbv, c->bs, c->bv_ptr.p, pv, c->flag.p);
+    if (c->nbp > 0) {
+      launch_schur_blocks_bj(st, cnt, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p,
+                             c->jd_val.p, pv, pp);
+      launch_block_invert(st, cnt, c->nbp, c->bs, c->bp_ptr.p, pp, c->flag.p);
     }
   }
   const int nb = (int)todo.size();

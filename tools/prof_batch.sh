@@ -1,10 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the batched solve alone (8 shifts, cfg2).  Run on the GPU box:
-#   bash tools/prof_batch.sh [tag]
+# rocprofv3 kernel stats of the batched solve alone (cfg2; default 16 shifts).  Run on the GPU box:
+#   bash tools/prof_batch.sh [tag] [groups]
 tag=${1:-pb}
+ng=${2:-16}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export BATCH_ONLY=1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o $tag -- python tools/batch_probe.py 58 8 > gpurun_out/$tag.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o $tag -- python tools/batch_probe.py 58 $ng > gpurun_out/$tag.log 2>&1 || exit 1
 cp $(find gpurun_out/$tag -name "*kernel_stats.csv") gpurun_out/${tag}_stats.csv
 rm -rf gpurun_out/$tag
 grep "G=" gpurun_out/$tag.log
