@@ -194,7 +194,7 @@ def main():
     ctx = _lib.Context(local, **xopts)
     ctx.set_operator(calA, calE, pr.J)
     d = dict(pb.default_nwtn_adi_dict(), ms=ms)
-    prm_full = _lib.adi_params(d)
+    prm_full = _lib.adi_params(dict(d, sweep_width=16))     # untimed reference solve: sweep form
     prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1,
                                    compress_cols=int(os.environ.get("RICADI_CC", "0")),
                                    sweep_width=args.sweep_width if args.cpp_sweeps else 1))
