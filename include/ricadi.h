@@ -234,6 +234,14 @@ int ricadi_apply_e_dev(ricadi_ctx* ctx, double coef, const double* dV, int m, do
  * Cauchy recombination.                              */
 int ricadi_lincomb_dev(ricadi_ctx* ctx, int nrows, int m, int nvec, const double* dBasis,
                        int64_t stride, const double* coef, double* dOut);
+/* Cauchy recombination of one ADI sweep on the device:
+ * dU holds the G solutions U_i (G x NV x m, contiguous, NV rows each); with
+ * rinv = R^-1 (G x G row-major, C = R^T R) and cinv1 = C^-1 1 (host arrays from
+ * ricadi_host_cauchy):  dZ (NV x G*m, row-major) = U (R^-1 (x) I_m),
+ * dW (NV x m) += E U ((C^-1 1) (x) I_m),  *n2_out = ||dZ||_F^2.                */
+int ricadi_sweep_recombine_dev(ricadi_ctx* ctx, int G, const double* dU, int m,
+                               const double* rinv, const double* cinv1,
+                               double* dZ, double* dW, double* n2_out);
 /* dK (NV x nb) = coef * E * (Z * (Z^T B)) for a device-resident factor dZ
  * (NV x c, row-major with leading dimension ldz) and dB (NV x nb).          */
 int ricadi_gain_dev(ricadi_ctx* ctx, double coef, const double* dZ, int c, int ldz,

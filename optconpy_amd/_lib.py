@@ -77,6 +77,8 @@ SIGNATURES = {
                                                C.POINTER(C.c_int), _dp]),
     "ricadi_time_spmm_batch_dev": (C.c_int, [_vp, C.c_int, _dp, _dp, _vp, C.c_int, _vp, C.c_int,
                                              C.POINTER(C.c_double)]),
+    "ricadi_sweep_recombine_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _dp, _dp, _vp, _vp,
+                                             C.POINTER(C.c_double)]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
@@ -458,6 +460,15 @@ class Context:
         _chk(self._lib.ricadi_time_spmm_batch_dev(self._h, al.size, _d(al), _d(be), x_ptr, m, y_ptr,
                                                   reps, C.byref(ms)))
         return ms.value
+
+    def sweep_recombine_dev(self, G, u_ptr, m, rinv, cinv1, z_ptr, w_ptr):
+        """Cauchy recombination of one sweep on the device; returns ``||Z-block||_F^2``."""
+        ri = np.ascontiguousarray(rinv, dtype=np.float64)
+        ci = np.ascontiguousarray(cinv1, dtype=np.float64)
+        n2 = C.c_double(0.0)
+        _chk(self._lib.ricadi_sweep_recombine_dev(self._h, int(G), u_ptr, m, _d(ri), _d(ci), z_ptr,
+                                                  w_ptr, C.byref(n2)))
+        return n2.value
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):
         _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))

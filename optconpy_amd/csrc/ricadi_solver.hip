@@ -1859,6 +1859,48 @@ int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* 
   API_END
 }
 
+int ricadi_sweep_recombine_dev(ricadi_ctx* c, int G, const double* dU, int m, const double* rinv,
+                               const double* cinv1, double* dZ, double* dW, double* n2_out) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(dU && rinv && cinv1 && dZ && dW && n2_out, RICADI_EINVAL, "NULL argument");
+  REQUIRE(G >= 1 && G <= 64 && G * m <= 2048, RICADI_EINVAL, "1 <= G <= 64 and G*m <= 2048 required");
+  API_BEGIN
+  hipStream_t st = c->st;
+  const int nv = c->nv;
+  const size_t nvm = (size_t)nv * m;
+  ensure_work(c, m, std::min(G, RICADI_MAX_GROUPS));
+  c->sweep_t.ensure(nvm);
+  c->sweep_coef.ensure((size_t)(G + 1) * G * m);
+  c->scratch.ensure((size_t)G * m + 64);
+  std::vector<double> coef((size_t)(G + 1) * G * m);
+  for (int j = 0; j <= G; ++j)
+    for (int i = 0; i < G; ++i) {
+      const double v = j < G ? rinv[(size_t)i * G + j] : cinv1[i];
+      for (int cc = 0; cc < m; ++cc) coef[((size_t)j * G + i) * m + cc] = v;
+    }
+  HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * coef.size(),
+                        hipMemcpyHostToDevice, st));
+  // Z-block j = sum_i rinv[i][j] U_i  (columns j*m .. of dZ, leading dimension G*m)
+  for (int j = 0; j < G; ++j) {
+    launch_cols_update(st, nv, m, G, dU, nvm, c->sweep_coef.p + (size_t)j * G * m, 1.0, nullptr,
+                       nullptr, c->sweep_t.p);
+    launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, dZ, G * m, j * m, 1.0);
+    col_norms2(c, c->sweep_t.p, nv, m, c->scratch.p + (size_t)j * m);
+  }
+  // W += E (sum_i cinv1[i] U_i)
+  launch_cols_update(st, nv, m, G, dU, nvm, c->sweep_coef.p + (size_t)G * G * m, 1.0, nullptr, nullptr,
+                     c->sweep_t.p);
+  launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0, 1.0,
+              nullptr, m);
+  std::vector<double> nr((size_t)G * m);
+  HIPCHK(hipMemcpyAsync(nr.data(), c->scratch.p, sizeof(double) * G * m, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  double n2 = 0.0;
+  for (double v : nr) n2 += v;
+  *n2_out = n2;
+  API_END
+}
+
 int ricadi_gain_dev(ricadi_ctx* c, double coef, const double* dZ, int cz, int ldz, const double* dB,
                     int nb, double* dK) {
   REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");

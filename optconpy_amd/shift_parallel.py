@@ -129,6 +129,17 @@ class HipOps:
         self.shift_solves += 1
         return U
 
+    def recombine(self, U_all, rinv, cinv1, W):
+        """One device call for the Cauchy recombination of a sweep: returns the
+        NV x (G*m) block ``U (R^-1 (x) I)`` and its squared Frobenius norm, and
+        updates ``W += E U ((C^-1 1) (x) I)`` in place."""
+        G, nv, m = U_all.shape
+        Zb = self.empty(nv, G * m)
+        self._sync_in()
+        n2 = self.ctx.sweep_recombine_dev(G, U_all.data_ptr(), m, rinv, cinv1, Zb.data_ptr(),
+                                          W.data_ptr())
+        return Zb, n2
+
     def lincomb(self, coef, U_all):
         """``sum_i coef[i] * U_all[i]``; ``U_all`` is G x NV x m, contiguous."""
         G, nv, m = U_all.shape
@@ -219,13 +230,17 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         else:
             U_all = U_loc[:G].contiguous()
         rinv, cinv1 = _lib.host_cauchy(ps)
-        n2 = 0.0
-        for j in range(G):
-            Zj = ops.lincomb(rinv[:, j], U_all)
-            n2 += ops.fro2(Zj)
-            blocks.append(Zj)
-        T = ops.lincomb(cinv1, U_all)
-        ops.apply_E(1.0, T, W)
+        if hasattr(ops, "recombine"):
+            Zb, n2 = ops.recombine(U_all, rinv, cinv1, W)
+            blocks.append(Zb)
+        else:
+            n2 = 0.0
+            for j in range(G):
+                Zj = ops.lincomb(rinv[:, j], U_all)
+                n2 += ops.fro2(Zj)
+                blocks.append(Zj)
+            T = ops.lincomb(cinv1, U_all)
+            ops.apply_E(1.0, T, W)
         znorm2 += n2
         steps += G
         nsweeps += 1
