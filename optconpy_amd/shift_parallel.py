@@ -202,6 +202,15 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
     G = int(width) if width else max(1, min(world, ns, max_width))
     if G > ns:
         raise ValueError("sweep width {0} exceeds the number of shifts {1}".format(G, ns))
+    # A sweep needs a numerically positive definite Cauchy matrix of its shifts: halve the
+    # width until every sweep of the shift cycle has one (deterministic, the same on all ranks)
+    while G > 1:
+        try:
+            for sw in range(ns):
+                _lib.host_cauchy(sweep_shifts(ms, sw, G))
+            break
+        except (RuntimeError, ValueError):
+            G = max(1, G // 2)
     per_rank = (G + world - 1) // world
     nv, m = W.shape
     W = W.clone()

@@ -89,6 +89,23 @@ def test_rejects_repeated_shift_in_sweep():
         lyap_adi_shift_parallel(ops, [-1.0, -2.0], torch.from_numpy(W.copy()), width=3)
 
 
+def test_sweep_width_shrinks_when_cauchy_matrix_is_singular():
+    """A shift cycle with a repeated shift cannot be swept 4 wide (singular Cauchy matrix):
+    the width is halved until every sweep is admissible, the result is the sequential one."""
+    pr, F, W, tb = _problem(4)
+    ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    ms = [-1.0, -3.0, -1.0, -9.0]
+    blocks, info = lyap_adi_shift_parallel(ops, ms, torch.from_numpy(W.copy()), width=4,
+                                           adi_max_steps=8, adi_newZ_reltol=0.0)
+    assert info["width"] == 2 and info["adi_steps"] == 8
+    Zb = torch.cat(blocks, dim=1).numpy()
+    Zs = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=W,
+                                    adi_dict=dict(adi_max_steps=8, adi_newZ_reltol=0.0, ms=ms))
+    Ks = opru.get_mTzzTtb(pr.M.T, Zs["zfac"], tb)
+    Kb = opru.get_mTzzTtb(pr.M.T, Zb, tb)
+    assert np.linalg.norm(Kb - Ks) <= 1e-10 * np.linalg.norm(Ks)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
