@@ -305,15 +305,34 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
     c->ipiv.ensure((size_t)k * nb);
     c->info.ensure(nb);
-    if (nb == 1) {
-      RBCHK(rocsolver_dgetrf(c->rb, k, k, todo[0]->einv.p, k, c->ipiv.p, c->info.p));
-      RBCHK(rocsolver_dgetri(c->rb, k, todo[0]->einv.p, k, c->ipiv.p, c->info.p));
-    } else {
-      std::vector<double*> hp(nb);
-      for (int i = 0; i < nb; ++i) hp[i] = todo[i]->einv.p;
-      c->eptrs.ensure(nb);
-      HIPCHK(hipMemcpyAsync(c->eptrs.p, hp.data(), sizeof(double*) * nb, hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));   // hp is a stack object
+    std::vector<double*> hp(nb);
+    for (int i = 0; i < nb; ++i) hp[i] = todo[i]->einv.p;
+    c->eptrs.ensure(nb);
+    HIPCHK(hipMemcpyAsync(c->eptrs.p, hp.data(), sizeof(double*) * nb, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // hp is a stack object
+    // LU WITHOUT pivoting first: with the velocity aggregates ordered before the pressure
+    // aggregates it is block elimination of the coarse saddle matrix -- the velocity
+    // block has a definite symmetric part for ADI shifts (and is s.p.d. for the
+    // projection), the Schur complement -B Av^-1 B^T inherits it -- and it spares
+    // rocSOLVER's pivot search / row swap kernels, most of the small launches of the
+    // factorisation.  A zero pivot (info != 0) sends all matrices of the call through
+    // the pivoted routines.
+    static const bool npvt = getenv("RICADI_COARSE_PIVOT") == nullptr;
+    bool done = false;
+    if (npvt) {
+      RBCHK(rocsolver_dgetrf_npvt_batched(c->rb, k, k, c->eptrs.p, k, c->info.p, nb));
+      HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      done = true;
+      for (int i = 0; i < nb; ++i) done = done && info[i] == 0;
+      if (done) {
+        RBCHK(rocsolver_dgetri_npvt_batched(c->rb, k, c->eptrs.p, k, c->info.p, nb));
+      } else {
+        for (ShiftData* sd : todo)   // the factorisation overwrote the matrices: assemble again
+          launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, sd->alpha, sd->beta, sd->einv.p);
+      }
+    }
+    if (!done) {
       RBCHK(rocsolver_dgetrf_batched(c->rb, k, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
       RBCHK(rocsolver_dgetri_batched(c->rb, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
     }
