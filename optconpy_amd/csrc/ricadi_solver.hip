@@ -146,7 +146,7 @@ struct ricadi_ctx {
   DArr<double> basis, vcur, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
   DArr<float> basisf;
   bool basis32 = true;
-  bool basis16 = false;       // RICADI_BASIS16=1: experimental FP16-stored Krylov basis
+  bool basis16 = true;        // FP16-stored Krylov basis (default for n <= 2^21)
   bool precond32 = true;
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
@@ -184,12 +184,17 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   if (want <= c->wcols && restart == c->wrestart) return;
   const size_t gm = (size_t)std::max(want, c->wcols);
   const size_t nm = (size_t)c->n * gm;
-  // Krylov basis: stored in FP32 by default (all arithmetic stays FP64) -- its three
-  // passes per iteration are the largest share of the HBM traffic.  The current
-  // vector is also kept in FP64 (vcur, holding the same rounded values) for the
-  // operator / preconditioner application.  RICADI_BASIS64=1 keeps an FP64 basis.
+  // Krylov basis: stored in FP16 by default (FP32 with RICADI_BASIS32=1, FP64 with
+  // RICADI_BASIS64=1); ALL arithmetic stays FP64 -- the three passes over the basis per
+  // iteration are the largest share of the HBM traffic.  The current vector is also
+  // kept in FP64 (vcur, holding the same rounded values) for the operator /
+  // preconditioner application, so the Arnoldi relation holds exactly for the stored
+  // vectors; what the storage precision limits is the residual reduction one restart
+  // cycle can deliver (~1e-3 for FP16, cycles gain ~1e-2), and every cycle starts from
+  // the true FP64 residual.  Unit vectors of dimension n have entries ~ n^-1/2: FP16
+  // (normal range from 6e-5) is used up to n = 2^21, FP32 beyond.
   c->basis32 = getenv("RICADI_BASIS64") == nullptr;
-  c->basis16 = c->basis32 && getenv("RICADI_BASIS16") != nullptr;
+  c->basis16 = c->basis32 && getenv("RICADI_BASIS32") == nullptr && c->n <= (1 << 21);
   if (c->basis32) {
     c->basisf.alloc((size_t)(restart + 1) * nm);
     c->vcur.alloc(nm);
@@ -653,7 +658,8 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
   // iteration: three passes over it) small; a cycle that gains less than a factor 10
   // on some column lengthens the following ones, up to gmres_restart.
-  int cyc = std::min(restart, 12);
+  static const int cyc0 = getenv("RICADI_CYC0") ? std::max(2, atoi(getenv("RICADI_CYC0"))) : 12;
+  int cyc = std::min(restart, cyc0);
   std::vector<double> rstart(GM, 0.0);
   while (!act.empty()) {
     bt.set(act);
