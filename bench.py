@@ -314,6 +314,11 @@ def main():
                 % (world, G, "one batched lockstep solve per rank and sweep" if nstreams == 1
                    else "%d concurrent stream(s)/GPU" % nstreams),
                 "K_rel_diff_vs_converged": k_err,
+                "storage": "arithmetic and all residual checks FP64; Krylov basis stored in %s, "
+                           "preconditioner inverses in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage)"
+                           % ("FP64" if os.environ.get("RICADI_BASIS64") else
+                              "FP32" if os.environ.get("RICADI_BASIS32") else "FP16",
+                              "FP64" if os.environ.get("RICADI_PRECOND64") else "FP32"),
             },
         }
         # the launch of the hot path: the sweep's shifts of one rank in one batched launch
