@@ -530,3 +530,31 @@ def test_cpp_sweep_adi_matches_stepwise_adi():
     Zb, _ = ctx.lyap_adi(ms_rep, W, _lib.adi_params(dict(d, sweep_width=4)))
     assert rel(Zb, Za) < 1e-7
     ctx.close()
+
+
+def test_sweep_of_the_whole_16_shift_cycle_matches_oracle():
+    """The benchmark's configuration in small: 16 log-spaced shifts over 3.5 decades swept in
+    ONE batch (16 x 16 Cauchy matrix), through HipOps (batched solve + device recombination),
+    against the oracle's step-by-step ADI with the same shifts."""
+    import torch
+    from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel
+    pr = pb.ricc_problem(15, 0.05)
+    F = (-pr.A - pr.Nc).tocsr()
+    mct = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = olau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+    trct = olau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    ms = pb.logshifts(1.0, 3e3, 16)
+    ctx = _lib.Context(0)
+    ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    torch.cuda.set_device(0)
+    ops = HipOps(ctx)
+    blocks, info = lyap_adi_shift_parallel(ops, ms, ops.to_panel(trct), adi_max_steps=200,
+                                           adi_newZ_reltol=1e-9, width=16)
+    assert info["width"] == 16 and info["adi_steps"] % 16 == 0
+    Z = torch.cat(blocks, dim=1).cpu().numpy()
+    ctx.close()
+    ref = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=trct,
+                                     adi_dict=dict(adi_max_steps=200, adi_newZ_reltol=1e-9, ms=ms))
+    K = pr.M.T @ (Z @ (Z.T @ tb))
+    Ko = opru.get_mTzzTtb(pr.M.T, ref["zfac"], tb)
+    assert rel(K, Ko) < K_TOL
