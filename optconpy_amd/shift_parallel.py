@@ -72,8 +72,8 @@ class HipOps:
         """Solve the same panel ``W`` against several shifts.  Default: ONE batched
         solve (``ricadi_shift_solve_batch_dev``) -- all shifts advance in lockstep
         inside one launch sequence, grid.z = shifts still iterating.  With extra
-        contexts (``extra_ctxs``) the shifts are instead spread over host threads and
-        HIP streams, one solve each (the older scheme, kept for comparison)."""
+        contexts (``extra_ctxs``) the list is cut into one batch per context and the
+        batches run concurrently on their streams."""
         import time
         nctx = len(self.ctxs)
         if len(ps) <= 1:
@@ -95,20 +95,34 @@ class HipOps:
                 self.shift_solves += len(chunk)
             self.t_solve += time.perf_counter() - t0
             return out
+        # several contexts: the shift list is cut into len(ctxs) contiguous chunks, each
+        # chunk is ONE batched solve on its context's stream, driven by its own host thread
+        # (ctypes releases the GIL).  While one batch is down to a few active groups --
+        # short, latency-bound kernels -- the other batch's kernels fill the chip.
         from concurrent.futures import ThreadPoolExecutor
         if self._pool is None:
             self._pool = ThreadPoolExecutor(max_workers=nctx)
         self._sync_in()
+        t0 = time.perf_counter()
+        m = W.shape[1]
+        nchunk = min(nctx, len(ps))
+        bounds = [round(i * len(ps) / nchunk) for i in range(nchunk + 1)]
 
-        def lane(k):            # one host thread per context, its shifts in order
-            return [(i, self._solve_on(self.ctxs[k], ps[i], W)) for i in range(k, len(ps), nctx)]
+        def lane(k):
+            ctx = self.ctxs[k]
+            chunk = [float(p) for p in ps[bounds[k]:bounds[k + 1]]]
+            X = self.empty(len(chunk), ctx.n, m)
+            its, _ = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
+                                               X.data_ptr(), strict=False)
+            ctx.synchronize()
+            return [X[g, :ctx.nv].contiguous() for g in range(len(chunk))], int(sum(its))
 
-        out = [None] * len(ps)
-        for res in self._pool.map(lane, range(min(nctx, len(ps)))):
-            for i, (U, its) in res:
-                out[i] = U
-                self.gmres_iters += its
-                self.shift_solves += 1
+        out = []
+        for Us, its in self._pool.map(lane, range(nchunk)):
+            out.extend(Us)
+            self.gmres_iters += its
+        self.shift_solves += len(ps)
+        self.t_solve += time.perf_counter() - t0
         return out
 
     def to_panel(self, W):
