@@ -87,11 +87,22 @@ typedef struct ricadi_adi_params {
                             stopping rule is applied every G steps.  Falls back to
                             1 when the shift list has repeats, fewer than G
                             entries or an ill-conditioned Cauchy matrix.  G <= 16;
-                            8 is what the benchmark uses.                       */
+                            the drop-in's proj_alg_ric_newtonadi and the benchmark
+                            use 16 (the whole shift cycle of cfg2 in one sweep).  */
 } ricadi_adi_params;
 
 const char* ricadi_last_error(void);
 int ricadi_version(void);
+/* sizeof(ricadi_opts) / sizeof(ricadi_adi_params) as THIS build of the library sees
+ * them.  A binding whose mirror of the structs has another size must refuse to load:
+ * the library reads every field of the structs it is handed, so a shorter mirror makes
+ * it read past the caller's buffer (optconpy_amd/_lib.py checks this at load time). */
+int ricadi_sizeof_opts(void);
+int ricadi_sizeof_adi_params(void);
+/* Field types of the two structs in declaration order, d = double, i = int:
+ * "ricadi_opts:<types>;ricadi_adi_params:<types>" -- sizes alone cannot see a
+ * trailing int that hides in the tail padding.                                   */
+const char* ricadi_struct_signature(void);
 void ricadi_default_opts(ricadi_opts* o);
 void ricadi_default_adi_params(ricadi_adi_params* p);
 
@@ -165,9 +176,12 @@ int ricadi_lyap_adi(ricadi_ctx* ctx, const double* shifts, int nshifts,
  * /root/reference/solve_dae_ric.py:152-159).  B is NV x nb dense, W NV x mw,
  * Z0 NV x c0 (or NULL), oldB NV x nb (mtxoldb, or NULL).  Z_out capacity
  * NV x zcap doubles (zcap >= adi_max_steps*(mw+nb)); may be NULL.
- * stats_out (>= 8 doubles): [newton_steps, last_upd_abs, last_upd_rel,
+ * stats_out (>= 12 doubles): [newton_steps, last_upd_abs, last_upd_rel,
  * total_adi_steps, total_gmres_iters, shift_solves, shift-solves that missed
- * the GMRES tolerance, their worst relative residual].                       */
+ * the GMRES tolerance, their worst relative residual, ||W_end^T W_end||_F of the
+ * last Lyapunov solve (its projected residual norm: `check_lyap_res`,
+ * /root/reference/optcont_main.py:130), ||W_0^T W_0||_F of its right-hand side,
+ * 0, 0].                                                                       */
 int ricadi_ric_newtonadi(ricadi_ctx* ctx, const double* shifts, int nshifts,
                          const double* B, int nb, const double* W, int mw,
                          const double* Z0, int c0, const double* oldB,
@@ -222,7 +236,10 @@ int ricadi_shift_solve_dev(ricadi_ctx* ctx, double alpha, double beta,
  * single n ~ 3e4 panel cannot.  ng <= 16, ng*m <= 2048.  iters_out: ng ints,
  * relres_out: ng*m doubles (either may be NULL).  Returns RICADI_ENOCONV if a
  * group stopped at gmres_maxit.  Counterpart of the per-shift factorise-and-
- * solve calls in the ADI loop, /root/reference/proj_ric_utils.py:183-262.    */
+ * solve work inside pru.solve_proj_lyap_stein / pru.proj_alg_ric_newtonadi (the package
+ * body is not in /root/reference; call sites: /root/reference/solve_dae_ric.py:152-159,
+ * /root/reference/optcont_main.py:488-492,
+ * /root/reference/tests/test_units_compfacres_compress.py:62-64).                */
 int ricadi_shift_solve_batch_dev(ricadi_ctx* ctx, int ng, const double* alphas,
                                  const double* betas, const double* dR,
                                  int64_t r_stride, int m, double* dX,

@@ -42,6 +42,9 @@ _vp = C.c_void_p
 SIGNATURES = {
     "ricadi_last_error": (C.c_char_p, []),
     "ricadi_version": (C.c_int, []),
+    "ricadi_sizeof_opts": (C.c_int, []),
+    "ricadi_sizeof_adi_params": (C.c_int, []),
+    "ricadi_struct_signature": (C.c_char_p, []),
     "ricadi_default_opts": (None, [C.POINTER(RicadiOpts)]),
     "ricadi_default_adi_params": (None, [C.POINTER(RicadiAdiParams)]),
     "ricadi_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
@@ -117,6 +120,23 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    # struct handshake: the library reads every field of the structs it is handed, so a
+    # mirror that is shorter than the library's struct makes it read past our buffer
+    # (root cause of the round-1 abort: a rebuilt .so with a new ricadi_adi_params field
+    # met a not-yet-updated mirror).  Refuse to run with a mismatched build.
+    for what, ours, theirs in (("ricadi_opts", C.sizeof(RicadiOpts), lib.ricadi_sizeof_opts()),
+                               ("ricadi_adi_params", C.sizeof(RicadiAdiParams),
+                                lib.ricadi_sizeof_adi_params())):
+        if ours != theirs:
+            raise RuntimeError("{0}: struct {1} is {2} bytes in the library but {3} bytes in "
+                               "optconpy_amd/_lib.py -- rebuild the library (__graft_entry__.build())"
+                               .format(LIB_PATH, what, theirs, ours))
+    ours = ";".join("{0}:{1}".format(nm, "".join("d" if t is C.c_double else "i" for _, t in st._fields_))
+                    for nm, st in (("ricadi_opts", RicadiOpts), ("ricadi_adi_params", RicadiAdiParams)))
+    theirs = lib.ricadi_struct_signature().decode()
+    if ours != theirs:
+        raise RuntimeError("{0}: struct layout '{1}' in the library, '{2}' in optconpy_amd/_lib.py "
+                           "-- rebuild the library or update the mirror".format(LIB_PATH, theirs, ours))
     _lib = lib
     return lib
 
@@ -361,7 +381,7 @@ class Context:
         cap = prm.adi_max_steps * (mw + nb)
         Z = np.empty((self.nv, cap)) if fetch else None
         cc = C.c_int(0)
-        stats = np.zeros(8)
+        stats = np.zeros(12)
         _chk(self._lib.ricadi_ric_newtonadi(
             self._h, _d(sh), sh.size, _d(B), nb, _d(W), mw,
             None if Z0 is None else _d(Z0), 0 if Z0 is None else Z0.shape[1],
@@ -373,7 +393,8 @@ class Context:
         info = dict(nwtn_steps=int(stats[0]), upd_abs=stats[1], upd_rel=stats[2],
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
                     shift_solves=int(stats[5]), cols=c,
-                    gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7])
+                    gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7],
+                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9])
         _warn_nonconverged(info)
         return Z, info
 

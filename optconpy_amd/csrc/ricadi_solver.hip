@@ -67,6 +67,18 @@ struct DArr {
   }
 };
 
+// Restores a value when the scope is left, also by an exception (a throw between a
+// temporary change of the context's state and its restoration must not leak the change).
+template <class T>
+struct Restore {
+  T& ref;
+  T saved;
+  explicit Restore(T& r) : ref(r), saved(r) {}
+  ~Restore() { ref = saved; }
+  Restore(const Restore&) = delete;
+  Restore& operator=(const Restore&) = delete;
+};
+
 struct ShiftData {
   double alpha = 0, beta = 0;
   bool valid = false;   // contents computed for the current operator (buffers are kept when invalid)
@@ -948,12 +960,13 @@ static void solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const doubl
     HIPCHK(hipMemcpyAsync(c->smw_rhs.p, c->wv.p, sizeof(double) * nm * G, hipMemcpyDeviceToDevice, st));
     std::vector<GmresResult> r2(G);
     // residual equation on the closed-loop operator; its tolerance is relative to ||r||
-    const double save_tol = c->opts.gmres_tol;
     double worst = 0.0;
     for (double v : rr) worst = std::max(worst, v);
-    c->opts.gmres_tol = std::min(0.5, std::max(1e-14, 0.5 * tol / worst));
-    gmres_solve_batch(c, sds, G, c->smw_rhs.p, nm, c->smw_x.p, m, true, nullptr, r2.data());
-    c->opts.gmres_tol = save_tol;
+    {
+      Restore<double> keep_tol(c->opts.gmres_tol);
+      c->opts.gmres_tol = std::min(0.5, std::max(1e-14, 0.5 * tol / worst));
+      gmres_solve_batch(c, sds, G, c->smw_rhs.p, nm, c->smw_x.p, m, true, nullptr, r2.data());
+    }
     launch_axpby_b(st, all, nm, 1.0, c->smw_x.p, nm, 1.0, x, nm);
     for (int g = 0; g < G; ++g) res[g].iters += r2[g].iters;
     true_relres(c, sds, G, b, gsb, x, m, true, rr.data());
@@ -1447,6 +1460,10 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
     ricadi::set_error(e.what());                                  \
     return RICADI_EHIP;                                           \
   }                                                               \
+  catch (...) {                                                   \
+    ricadi::set_error("unknown C++ exception");                   \
+    return RICADI_EHIP;                                           \
+  }                                                               \
   return RICADI_OK;
 
 #define REQUIRE(cond, code, msg)     \
@@ -1460,7 +1477,11 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 100; }
+int ricadi_version(void) { return 200; }
+int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
+int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
+// field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
+const char* ricadi_struct_signature(void) { return "ricadi_opts:diiiiiiiii;ricadi_adi_params:ididdiiii"; }
 
 void ricadi_default_opts(ricadi_opts* o) {
   if (!o) return;
@@ -1790,6 +1811,12 @@ int ricadi_shift_solve_dev(ricadi_ctx* c, double alpha, double beta, const doubl
   } catch (const ricadi::HipError& e) {
     ricadi::set_error(e.msg);
     return RICADI_EHIP;
+  } catch (const std::exception& e) {
+    ricadi::set_error(e.what());
+    return RICADI_EHIP;
+  } catch (...) {
+    ricadi::set_error("unknown C++ exception");
+    return RICADI_EHIP;
   }
   return status;
 }
@@ -1823,6 +1850,12 @@ int ricadi_shift_solve_batch_dev(ricadi_ctx* c, int ng, const double* alphas, co
   } catch (const ricadi::HipError& e) {
     ricadi::set_error(e.msg);
     return RICADI_EHIP;
+  } catch (const std::exception& e) {
+    ricadi::set_error(e.what());
+    return RICADI_EHIP;
+  } catch (...) {
+    ricadi::set_error("unknown C++ exception");
+    return RICADI_EHIP;
   }
   return status;
 }
@@ -1853,6 +1886,12 @@ int ricadi_shift_solve(ricadi_ctx* c, double alpha, double beta, const double* R
     }
   } catch (const ricadi::HipError& e) {
     ricadi::set_error(e.msg);
+    return RICADI_EHIP;
+  } catch (const std::exception& e) {
+    ricadi::set_error(e.what());
+    return RICADI_EHIP;
+  } catch (...) {
+    ricadi::set_error("unknown C++ exception");
     return RICADI_EHIP;
   }
   return status;
@@ -2080,6 +2119,16 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   hipStream_t st = c->st;
   const int nv = c->nv;
   const int mfull = mw + nb;
+  // The Newton loop installs its own low-rank term (K_k - old) B^T in the context; whatever
+  // way this function is left -- also by an exception -- no stale term may stay behind for
+  // later ricadi_lyap_adi / ricadi_shift_solve calls.
+  struct LowRankReset {
+    ricadi_ctx* c;
+    ~LowRankReset() {
+      c->q = 0;
+      ++c->lr_epoch;
+    }
+  } lowrank_reset{c};
   ensure_work(c, mfull);
   DArr<double> dB, dWm, dOld, dK, dKall, dRhs, Zk, Znew;
   dB.alloc((size_t)nv * nb);
@@ -2106,7 +2155,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   if (p2.compress_cols <= 0) p2.compress_cols = 512;
   double upd = 0, updrel = 0;
   long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves, nonconv = 0;
-  double worst = 0.0;
+  double worst = 0.0, last_res = 0.0, last_rhs = 0.0;
   int steps = 0;
   for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
     int m = mw;
@@ -2132,7 +2181,9 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     launch_copy_cols(st, nv, mw, dWm.p, mw, 0, dRhs.p, m, 0, 1.0);
     if (m > mw) launch_copy_cols(st, nv, nb, dK.p, nb, 0, dRhs.p, m, mw, 1.0);
     factor_reserve(c, prm->adi_max_steps * m);
+    DScalar::gram_norms(c, dRhs.p, nv, m, &last_rhs, nullptr);
     AdiStats s = lyap_adi_dev(c, shifts, ns, dRhs.p, m, p2);
+    last_res = s.res_fro;
     adi_total += s.steps;
     nonconv += s.nonconverged;
     worst = std::max(worst, s.worst_relres);
@@ -2153,7 +2204,6 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     if (upd < prm->nwtn_upd_abstol || updrel < prm->nwtn_upd_reltol) break;
   }
   if (steps > prm->nwtn_max_steps) steps = prm->nwtn_max_steps;
-  c->q = 0;
   if (c_out) *c_out = c->zc;
   if (Z_out && c->zc > 0) {
     if (c->zc > zcap) throw ricadi::HipError{"Z_out capacity too small"};
@@ -2170,6 +2220,9 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     stats_out[5] = (double)(c->total_solves - sol0);
     stats_out[6] = (double)nonconv;
     stats_out[7] = worst;
+    stats_out[8] = last_res;
+    stats_out[9] = last_rhs;
+    stats_out[10] = stats_out[11] = 0.0;
   }
   API_END
 }
@@ -2282,14 +2335,13 @@ int ricadi_lyap_res_norm(ricadi_ctx* c, const double* Z, int cz, const double* W
     launch_copy_cols(st, nv, w, out, w, 0, S.p, wtot, cz + c0, 1.0);
   }
   // project every column: P^T s
-  const int saved_q = c->q;
+  Restore<int> keep_q(c->q);
   for (int c0 = 0; c0 < wtot; c0 += CH) {
     const int w = std::min(CH, wtot - c0);
     launch_copy_cols(st, nv, w, S.p, wtot, c0, in, w, 0, 1.0);
     project_panel(c, in, w);
     launch_copy_cols(st, nv, w, in, w, 0, S.p, wtot, c0, 1.0);
   }
-  c->q = saved_q;
   G.alloc((size_t)wtot * wtot);
   HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * wtot * wtot, st));
   launch_gemm_tn(st, nv, wtot, wtot, S.p, wtot, S.p, wtot, G.p, wtot);

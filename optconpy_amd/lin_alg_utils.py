@@ -44,8 +44,13 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, umat=None,
                      vmat=None, rhsp=None, **kw):
     """Solve ``[[amat - umat*vmat, J^T],[J, 0]] x = [rhsv; rhsp]`` on the GPU.
 
-    The low-rank term is part of the Krylov operator (no Sherman-Morrison-
-    Woodbury needed).  Returns the ``(NV+NP) x q`` solution like the reference
+    The low-rank term is handled inside the library as the reference does, by
+    Sherman-Morrison-Woodbury around solves with the plain saddle operator
+    (``x = y + W (V^T y)``, ``W = S^-1 [U;0] (I - V^T S^-1 U)^-1``), followed by an
+    FP64 check of the closed-loop residual and, should it miss the tolerance,
+    one GMRES refinement on the closed-loop operator itself (``RICADI_SMW=0``
+    keeps the term inside the Krylov operator from the start).
+    Returns the ``(NV+NP) x q`` solution like the reference
     (callers slice ``[:NV]``: ``solve_dae_ric.py:192-194``,
     ``optcont_main.py:510-514``).
     """

@@ -72,13 +72,21 @@ def solve_proj_lyap_stein(amat=None, mmat=None, jmat=None, wmat=None,
         ctx.set_lowrank(None, None)
     prm = _lib.adi_params(d)
     W = _dense(wmat)
+    out = {}
     try:
         if W.shape[1] > _lib.MAX_M:
             raise ValueError("right-hand side factor wider than {0} columns".format(_lib.MAX_M))
         Z, info = ctx.lyap_adi(_shifts(d), W, prm)
+        if d.get("check_lyap_res", False):
+            # optcont_main.py:130 -- the residual of the equation just solved, evaluated
+            # independently of the ADI recurrence from the factors (a5, same context)
+            out["lyap_res"] = float(np.sqrt(abs(ctx.lyap_res_norm(Z, W))))
+            if d.get("verbose", False):
+                print("projected Lyapunov residual (factored): {0:.3e}; ADI recurrence: {1:.3e}"
+                      .format(out["lyap_res"], info["res_fro"]))
     finally:
         ctx.set_lowrank(None, None)
-    out = dict(zfac=Z)
+    out["zfac"] = Z
     out.update(info)
     return out
 
@@ -110,6 +118,13 @@ def proj_alg_ric_newtonadi(mmat=None, amat=None, jmat=None, bmat=None,
                                 oldB=None if mtxoldb is None else _dense(mtxoldb))
     out = dict(zfac=Z)
     out.update(info)
+    if d.get("check_lyap_res", False):
+        # optcont_main.py:130: residual of the last Newton step's Lyapunov equation --
+        # in residual-form ADI it is W_end W_end^T, whose norm the driver returns
+        out["lyap_res"] = info["lyap_res_fro"]
+        if d.get("verbose", False):
+            print("last Newton step: projected Lyapunov residual {0:.3e} (rhs {1:.3e})"
+                  .format(info["lyap_res_fro"], info["lyap_rhs_fro"]))
     return out
 
 

@@ -48,8 +48,20 @@ class HipOps:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.gmres_iters = 0
         self.shift_solves = 0
+        self.nonconverged = 0       # shift-solves that stopped at gmres_maxit above the tolerance
+        self.worst_relres = 0.0     # worst true relative residual seen (all solves)
         self.t_solve = 0.0          # wall seconds inside solve_many / solve (synchronised)
         self._pool = None
+
+    def _account(self, relres):
+        """Book-keeping of the true FP64 residuals a solve returned (one row per shift):
+        a solve that missed ``gmres_tol`` is folded into Z like any other -- as in the
+        C++ driver -- but it is counted and reported (``info`` of the sweep loop)."""
+        rr = np.atleast_2d(np.asarray(relres, dtype=float))
+        tol = float(getattr(getattr(self.ctx, "_opts", None), "gmres_tol", 1e-10))
+        worst = rr.max(axis=1)
+        self.nonconverged += int(np.sum(~(worst <= tol * 1.0000001)))
+        self.worst_relres = max(self.worst_relres, float(worst.max()))
 
     def set_lowrank(self, U=None, V=None):
         for c in self.ctxs:
@@ -62,8 +74,9 @@ class HipOps:
     def _solve_on(self, ctx, p, W):
         m = W.shape[1]
         X = self.empty(ctx.n, m)
-        its, _ = ctx.shift_solve_dev(float(p), 1.0, W.data_ptr(), m, X.data_ptr(), strict=False)
+        its, rr = ctx.shift_solve_dev(float(p), 1.0, W.data_ptr(), m, X.data_ptr(), strict=False)
         ctx.synchronize()
+        self._account(rr)
         return X[:ctx.nv].contiguous(), its
 
     MAX_BATCH = 16
@@ -87,9 +100,10 @@ class HipOps:
             for c0 in range(0, len(ps), self.MAX_BATCH):
                 chunk = [float(p) for p in ps[c0:c0 + self.MAX_BATCH]]
                 X = self.empty(len(chunk), ctx.n, m)
-                its, _ = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
-                                                   X.data_ptr(), strict=False)
+                its, rr = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
+                                                    X.data_ptr(), strict=False)
                 ctx.synchronize()
+                self._account(rr)
                 out.extend(X[g, :ctx.nv].contiguous() for g in range(len(chunk)))
                 self.gmres_iters += int(sum(its))
                 self.shift_solves += len(chunk)
@@ -112,15 +126,16 @@ class HipOps:
             ctx = self.ctxs[k]
             chunk = [float(p) for p in ps[bounds[k]:bounds[k + 1]]]
             X = self.empty(len(chunk), ctx.n, m)
-            its, _ = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
-                                               X.data_ptr(), strict=False)
+            its, rr = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
+                                                X.data_ptr(), strict=False)
             ctx.synchronize()
-            return [X[g, :ctx.nv].contiguous() for g in range(len(chunk))], int(sum(its))
+            return [X[g, :ctx.nv].contiguous() for g in range(len(chunk))], int(sum(its)), rr
 
         out = []
-        for Us, its in self._pool.map(lane, range(nchunk)):
+        for Us, its, rr in self._pool.map(lane, range(nchunk)):
             out.extend(Us)
             self.gmres_iters += its
+            self._account(rr)
         self.shift_solves += len(ps)
         self.t_solve += time.perf_counter() - t0
         return out
@@ -281,5 +296,18 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         if stop:
             break
     info = dict(adi_steps=steps, sweeps=nsweeps, width=G, adi_rel_newZ=rel,
-                res_fro=ops.gram_fro(W), resfac=W)
+                res_fro=ops.gram_fro(W), resfac=W,
+                gmres_nonconverged=int(getattr(ops, "nonconverged", 0)),
+                gmres_worst_relres=float(getattr(ops, "worst_relres", 0.0)),
+                shift_solves=int(getattr(ops, "shift_solves", 0)))
+    if world > 1:
+        # a rank only sees its own solves: the counts are summed, the worst residual maximised
+        t = W.new_tensor([info["gmres_nonconverged"], info["shift_solves"]])
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        w = W.new_tensor([info["gmres_worst_relres"]])
+        dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
+        info["gmres_nonconverged"], info["shift_solves"] = int(t[0].item()), int(t[1].item())
+        info["gmres_worst_relres"] = float(w.item())
+    if info["gmres_nonconverged"] and rank == 0:
+        _lib._warn_nonconverged(info)
     return blocks, info

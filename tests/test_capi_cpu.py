@@ -95,3 +95,63 @@ def test_dropin_package_names():
     # host-only helpers work without a GPU
     Ms = sps.csr_matrix(np.diag([4.0, 9.0]))
     assert np.allclose(lau.apply_invsqrt_fromright(Ms, np.eye(2)), np.diag([0.5, 1 / 3.0]))
+
+
+def test_struct_layout_matches_header(tmp_path):
+    """sizeof / offsetof of the two structs that cross the C-ABI, three ways: a C probe
+    compiled from include/ricadi.h, the library's own ricadi_sizeof_*(), and the ctypes
+    mirrors in optconpy_amd/_lib.py.  (A mirror shorter than the library's struct makes the
+    library read past the caller's buffer: the round-1 abort)"""
+    import ctypes as C
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "ricadi.h")).read()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return re.findall(r"\b(?:int|double)\s+(\w+)\s*;", body)
+
+    names = {"ricadi_opts": fields("ricadi_opts"), "ricadi_adi_params": fields("ricadi_adi_params")}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ricadi.h"', 'int main(void){']
+    for st, fl in names.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fl:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    lines.append('return 0;}')
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    probe = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    lib = _lib.load()
+    mirrors = {"ricadi_opts": _lib.RicadiOpts, "ricadi_adi_params": _lib.RicadiAdiParams}
+    sizes = {"ricadi_opts": lib.ricadi_sizeof_opts(), "ricadi_adi_params": lib.ricadi_sizeof_adi_params()}
+    sig = dict(part.split(":") for part in lib.ricadi_struct_signature().decode().split(";"))
+    for st in names:      # the library's signature string follows the header's declarations
+        decl = re.search(r"typedef struct %s \{(.*?)\} %s;" % (st, st), hdr, re.S).group(1)
+        decl = re.sub(r"/\*.*?\*/", "", decl, flags=re.S)
+        assert sig[st] == "".join(t[0] for t in re.findall(r"\b(int|double)\s+\w+\s*;", decl)), st
+    for st, fl in names.items():
+        mir = mirrors[st]
+        assert [f for f, _ in mir._fields_] == fl, st           # same fields, same order
+        assert int(probe[st]) == C.sizeof(mir) == sizes[st], st
+        for f in fl:
+            assert int(probe[st + "." + f]) == getattr(mir, f).offset, (st, f)
+
+
+def test_load_refuses_mismatched_struct(monkeypatch):
+    """The handshake itself: a mirror of another size must not get past load()."""
+    import ctypes as C
+
+    class Short(C.Structure):
+        _fields_ = _lib.RicadiAdiParams._fields_[:-1]
+    full = _lib.RicadiAdiParams
+    monkeypatch.setattr(_lib, "RicadiAdiParams", Short)
+    monkeypatch.setattr(_lib, "_lib", None)
+    # dropping the trailing int leaves sizeof unchanged (tail padding): the signature sees it
+    assert C.sizeof(Short) == C.sizeof(full)
+    with pytest.raises(RuntimeError, match="ricadi_adi_params"):
+        _lib.load()
+    monkeypatch.undo()
+    _lib._lib = None
+    _lib.load()

@@ -7,7 +7,6 @@ BASELINE.json's north_star states -- and in practice ~1e-11.
 import numpy as np
 import pytest
 import scipy.sparse as sps
-import scipy.sparse.linalg as spsla
 
 from optconpy_amd import _lib, backend, problems as pb
 from oracle import lin_alg_utils as olau, proj_ric_utils as opru
@@ -196,47 +195,29 @@ def test_newton_with_initial_guess_and_old_feedback(ctx1, cfg1):
 
 # ----------------------------------------- the reference's own test, via the drop-in
 def test_reference_unit_test_through_dropin():
-    """/root/reference/tests/test_units_compfacres_compress.py:15-106 with
-    `pru` / `lau` resolved to the MI355X implementation."""
-    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    """The five identities of /root/reference/tests/test_units_compfacres_compress.py:85-106
+    (tests/identities.py) with `pru` resolved to the MI355X drop-in package; set-up as there
+    (:45-60): Stokes matrices, F = -M - 0.1 A - sparse random perturbation, W = randn(NV, 5),
+    here seeded and with an explicit shift list."""
     import sadptprj_riclyap_adi.proj_ric_utils as pru
+    from identities import check_reference_identities
     backend.reset()
-    N, NY, thresh = 8, 5, 1e-6
-    sm = pb.stokes_system(N, nu=1.0)
+    sm = pb.stokes_system(8, nu=1.0)
     M, A, J, NV = sm["M"], sm["A"], sm["J"], sm["NV"]
     rng = np.random.default_rng(0)
-    R = sps.random(NV, NV, density=0.03, format="csr", random_state=rng)
-    F = (-M - 0.1 * A - 0.03 * M.diagonal().mean() * R).tocsr()
-    W = rng.standard_normal((NV, NY))
-    nwtn_adi_dict = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, nwtn_max_steps=24,
-                         nwtn_upd_reltol=4e-7, nwtn_upd_abstol=4e-7,
-                         full_upd_norm_check=True, verbose=False,
-                         ms=pb.logshifts(2.0, 8e3, 12))
-    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=nwtn_adi_dict)["zfac"]
-    MtZ = M.T * Z
-    MtXM = np.dot(M.T * Z, Z.T * M)
-    FtXM = F.T * np.dot(Z, Z.T) * M
-    Mlu = spsla.factorized(M.tocsc())
-    MinvJt = lau.app_luinv_to_spmat(Mlu, J.T)
-    Sinv = np.linalg.inv(J * MinvJt)
-    P = np.eye(NV) - np.dot(MinvJt, Sinv * J)
-    PtW = np.dot(P.T, W)
-    ProjRes = np.dot(P.T, np.dot(FtXM, P)) + np.dot(np.dot(P.T, FtXM.T), P) + np.dot(PtW, PtW.T)
-    resn = np.linalg.norm(ProjRes)
-    wwn = np.linalg.norm(np.dot(PtW, PtW.T))
-    ownresn = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Z, F, M, W, J)))
-    assert np.allclose(np.linalg.norm(MtXM), np.linalg.norm(np.dot(MtZ.T, MtZ)))
-    assert abs(resn - ownresn) <= 1e-5 * wwn and resn < 1e-6 * wwn
-    Zred = pru.compress_Zsvd(Z, k=None, thresh=thresh, shplot=True)
-    MtZr = M.T * Zred
-    MtXMr = np.dot(MtZr, MtZr.T)
-    assert np.allclose(MtXMr, np.dot(P.T, np.dot(MtXMr, P)))
-    assert np.allclose(np.linalg.norm(np.dot(MtZ.T, MtZ)), np.linalg.norm(np.dot(MtZr.T, MtZr)))
-    ownresr = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Zred, F, M, W, J)))
-    assert abs(ownresr - resn) <= 1e-5 * wwn
+    pert = sps.random(NV, NV, density=0.03, format="csr", random_state=rng)
+    F = (-M - 0.1 * A - 0.03 * M.diagonal().mean() * pert).tocsr()
+    W = rng.standard_normal((NV, 5))
+    d = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, nwtn_max_steps=24, nwtn_upd_reltol=4e-7,
+             nwtn_upd_abstol=4e-7, full_upd_norm_check=True, verbose=False,
+             ms=pb.logshifts(2.0, 8e3, 12))
+    Z, _ = check_reference_identities(pru, M, J, F, W, d)
     # the same Z as the oracle, as far as Z Z^T is concerned
-    Zo = opru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=nwtn_adi_dict)["zfac"]
+    Zo = opru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
     assert opru.comp_diff_zzt_fnorm(Z, Zo) <= 1e-8 * np.linalg.norm(Zo.T @ Zo)
+    # check_lyap_res (optcont_main.py:130) is honoured: the factored residual comes back
+    out = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=dict(d, check_lyap_res=True))
+    assert 0.0 <= out["lyap_res"] < 1e-6 * np.linalg.norm(W.T @ W)
     backend.reset()
 
 
@@ -497,6 +478,44 @@ def test_batched_shift_solve_matches_single():
             Xs, it1, rr1 = ctx.shift_solve(p, 1.0, R[0 if shared else g])
             assert abs(it1 - its[g]) <= max(2, 0.4 * it1)
             assert rel(Xh[g], Xs) < 1e-8
+    ctx.close()
+
+
+@pytest.mark.parametrize("m", [1, 5, 7])
+def test_odd_panel_widths_through_adi_and_batched_solve(m):
+    """Regression for the round-1 abort (N = 8 Stokes pencil, m = 5, adi_max_steps = 150, more
+    factor columns than rows): panel widths that are no multiple of 4 through the step-wise
+    ADI, the sweep form and the batched solve, against the oracle."""
+    import torch
+    sm = pb.stokes_system(8, nu=1.0)
+    M, A, J, NV = sm["M"], sm["A"], sm["J"], sm["NV"]
+    F = (-M - 0.1 * A).tocsr()
+    rng = np.random.default_rng(m)
+    W = rng.standard_normal((NV, m))
+    ms = pb.logshifts(2.0, 8e3, 12)
+    d = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, ms=ms)
+    ctx = _lib.Context(0)
+    ctx.set_operator(F.T.tocsr(), M.T.tocsr(), J)
+    Zo = opru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
+    Z1, i1 = ctx.lyap_adi(ms, W, _lib.adi_params(d))
+    assert i1["cols"] == Z1.shape[1] == i1["adi_steps"] * m
+    assert opru.comp_diff_zzt_fnorm(Z1, Zo) <= 1e-8 * np.linalg.norm(Zo.T @ Zo)
+    Z2, i2 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, sweep_width=4)))
+    assert opru.comp_diff_zzt_fnorm(Z2, Zo) <= 1e-7 * np.linalg.norm(Zo.T @ Zo)
+    # in-ADI recompression with a factor that has more columns than rows
+    Z3, i3 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, compress_cols=64)))
+    assert Z3.shape[1] <= NV and opru.comp_diff_zzt_fnorm(Z3, Zo) <= 1e-7 * np.linalg.norm(Zo.T @ Zo)
+    dev = torch.device("cuda", 0)
+    ps = [-2.0, -50.0, -3000.0]
+    Rd = torch.as_tensor(W).to(dev)
+    X = torch.empty(len(ps), ctx.n, m, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), Rd.data_ptr(), 0, m, X.data_ptr())
+    ctx.synchronize()
+    Xh = X.cpu().numpy()
+    for g, p in enumerate(ps):
+        Xo = olau.SaddleLU(F.T.tocsr() + p * M.T.tocsr(), J).solve(W)
+        assert rel(Xh[g], Xo) < 1e-8
     ctx.close()
 
 

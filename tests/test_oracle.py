@@ -31,39 +31,14 @@ def _projector(M, J, NV):
 
 
 def test_reference_identities():
+    from identities import check_reference_identities
     M, A, J, F, W, NV = _setup()
     # parameters of the reference test (:54-60) plus an explicit shift list that
     # covers this pencil's spectrum, so that the iteration really converges
     d = dict(adi_max_steps=150, adi_newZ_reltol=1e-11, nwtn_max_steps=24,
              nwtn_upd_reltol=4e-7, nwtn_upd_abstol=4e-7, full_upd_norm_check=True,
              ms=pb.logshifts(2.0, 8e3, 12))
-    Z = pru.solve_proj_lyap_stein(amat=F, mmat=M, jmat=J, wmat=W, adi_dict=d)["zfac"]
-    MtZ = M.T @ Z
-    MtXM = MtZ @ MtZ.T
-    FtXM = F.T @ (Z @ (Z.T @ M.toarray()))
-    P = _projector(M, J, NV)
-    PtW = P.T @ W
-    ProjRes = P.T @ FtXM @ P + P.T @ FtXM.T @ P + PtW @ PtW.T
-    resn = np.linalg.norm(ProjRes)
-    # converged: the squared norm is rounding noise around zero, may be negative
-    ownresn = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Z, F, M, W, J)))
-    # (1) smart fnorm  (reference test :85-86)
-    assert np.allclose(np.linalg.norm(MtXM), np.linalg.norm(MtZ.T @ MtZ))
-    # (2) factored residual == dense residual (:89); tolerance relative to ||W W^T||
-    assert abs(resn - ownresn) <= 1e-5 * np.linalg.norm(PtW @ PtW.T)
-    # ADI actually converged here (the reference test does not check this)
-    assert resn < 1e-6 * np.linalg.norm(PtW @ PtW.T)
-    Zred = pru.compress_Zsvd(Z, k=None, thresh=1e-6, shplot=True)
-    MtZr = M.T @ Zred
-    MtXMr = MtZr @ MtZr.T
-    # (3) reduction is 'projected' (:96-97)
-    assert np.allclose(MtXMr, P.T @ MtXMr @ P)
-    # (4) norm preserved (:100-101)
-    assert np.allclose(np.linalg.norm(MtZ.T @ MtZ), np.linalg.norm(MtZr.T @ MtZr))
-    # (5) residual preserved (:104-106), again relative to ||W W^T||
-    ownresr = np.sqrt(abs(pru.comp_proj_lyap_res_norm(Zred, F, M, W, J)))
-    assert abs(ownresr - resn) <= 1e-5 * np.linalg.norm(PtW @ PtW.T)
-    assert Zred.shape[1] < Z.shape[1]
+    check_reference_identities(pru, M, J, F, W, d)
 
 
 def test_unconverged_residual_formula():
