@@ -6,32 +6,39 @@
 Metric (BASELINE.json): ADI shift-solves per second, next to the wall-clock to
 the feedback gain K.  One *step* = one Newton step of the projected Riccati
 solve on BASELINE config 2 (driven cavity, N=58 -> n = 29 930, nu = 0.05,
-16 log-spaced ADI shifts, right-hand-side panel m = NY' + NU = 16): a complete
-low-rank ADI solve of the closed-loop Lyapunov equation with the reference's
-default stopping rule (adi_newZ_reltol = 1e-8, optcont_main.py:124) followed by
-the gain K = -E Z Z^T B.  One *unit* = one shift-solve, i.e. one saddle-point
-solve S(p) [V;L] = [R;0] with an NV x 16 panel to relative residual 1e-11.
+16 log-spaced ADI shifts, right-hand-side panel m = NY' + NU = 16), started from
+the converged iterate (so that the step sees the closed-loop low-rank term and the
+full m = 16 panel, like every Newton step but the first):
 
-Every N runs the same problem with the shift-parallel Cauchy sweeps
-(optconpy_amd/shift_parallel.py): sweeps of 16 distinct shifts (the whole shift
-cycle) solved independently against the same residual factor, recombined with
-the 16 x 16 Cauchy matrix -- identical to 16 sequential ADI steps.  Shift g of a
-sweep is solved by rank g % N; a rank solves its 16/N shifts in ONE batched GMRES
-(ricadi_shift_solve_batch_dev: all shifts advance in lockstep, every kernel of
-the iteration is launched once with grid.z = shifts still iterating), since one
-shift-solve at this size is a chain of short kernels that leaves most of the
-chip idle.  N > 1: one process per GPU (torch.distributed, RCCL), one
-all-gather per sweep -> total work fixed, "scaling": "strong".
-`--sequential` times the single-panel device-resident C++ ADI instead;
-`--streams k` cuts a rank's shifts into k batches that run concurrently on k HIP streams.
+    Z = pru.proj_alg_ric_newtonadi(mmat=M, amat=-A-N, jmat=J, bmat=B~, wmat=C~^T, z0=Z_k,
+                                   nwtn_adi_dict={..., nwtn_max_steps: 1})['zfac']
+    K = -pru.get_mTzzTtb(M^T, Z, B~)
 
-The JSON line also carries the SpMM roofline figures (kernel time from HIP
-events on the library's stream) and the CPU baseline (oracle = scipy SuperLU on
-the same matrices, bounded sample, rank 0 / N = 1 only).
+-- the reference's own calls (optcont_main.py:488-492,505) resolved to this repo's
+drop-in package `sadptprj_riclyap_adi`, i.e. THROUGH THE BOUNDARY: closed-loop
+low-rank ADI to adi_newZ_reltol = 1e-8 (optcont_main.py:124) in sweeps of 16 shifts
+(one batched lockstep GMRES per sweep), Newton update norm, recompression, gain.
+One *unit* = one shift-solve: one saddle-point solve S(p) [V;L] = [R;0] with an
+NV x 16 panel to relative residual 1e-10.  Per-shift setup (the counterpart of the
+reference's sparse LUs) is part of every step: the cache is cleared first.
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the shift-parallel sweeps
+of optconpy_amd/shift_parallel.py on the same problem -- work items = (shift, column
+half) pairs dealt to the ranks, one all-gather per sweep -> "scaling": "strong".
+
+The JSON line also carries: the same step through the Python sweep driver
+(`value_python_sweep_driver`), with FP64-stored Krylov basis / preconditioner
+(`value_fp64_storage`), roofline objects for K1 (the saddle SpMM: median AND best of
+the trials, per-panel and batched-form byte models) and for the kernels that dominate
+the run time (block-Jacobi sweep, coarse apply, the three Arnoldi kernels), the Gram
+and TSQR MFMA figures, and the CPU baseline (oracle = scipy SuperLU, the full step
+on the host cores).  Every figure's kernel duration is measured live with HIP events
+on the library's stream; the committed rocprofv3 summaries are under profiles/.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,104 +48,246 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_inputs(N, nu, nshifts):
-    """cfg2 inputs, prepared with the product's own host-side mirror (GPU solves)."""
-    from optconpy_amd import lin_alg_utils as lau, problems as pb
+def build_inputs(N, nu, nshifts, pmax=3e3):
+    """cfg2 inputs, prepared with the drop-in's own modules (GPU solves), as
+    optcont_main.py:405-425 prepares them."""
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    from optconpy_amd import problems as pb
     pr = pb.ricc_problem(N, nu, NU=4, NY=4, alphau=1e-2)
     mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
     trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
-    ms = pb.logshifts(1.0, 3e3, nshifts)
+    ms = pb.logshifts(1.0, pmax, nshifts)
     return pr, tb, trct, ms
 
 
-def spmm_roofline(ctx, nnz_s, n, m, shifts, reps=200):
-    """K1 roofline on the launch the hot path issues: ONE batched tile-SpMM launch over
-    the G = len(shifts) panels of a sweep (grid.z = G).  Algorithmic bytes per unit
-    (12 nnz + 4 (n+1) + 16 n m) x G units per launch, over the launch's
-    average duration measured with HIP events on the ctx stream.  The single-panel launch
-    (sequential path) is reported next to it."""
+def oracle_gain(N, nu, nshifts):
+    """K of the CPU oracle for this workload from the committed fixture (cfg2 only)."""
+    path = os.path.join(ROOT, "tests", "golden", "cfg2_golden.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    cfg = g["cfg"]
+    if int(cfg[0]) != N or abs(cfg[1] - nu) > 1e-15 or int(cfg[5]) != nshifts:
+        return None
+    return g["K_ric"]
+
+
+def trials(fn, ntrial=5):
+    """Median and best of `ntrial` measurements (ms)."""
+    v = [fn() for _ in range(ntrial)]
+    return statistics.median(v), min(v)
+
+
+def traffic_entry(key):
+    for name in ("r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                e = json.load(f).get(key)
+            if e:
+                return e.get("hbm_bytes"), name
+        except (OSError, ValueError):
+            pass
+    return None, None
+
+
+def spmm_roofline(ctx, nnz_k, nnz_j, n, m, shifts, reps=200):
+    """K1 roofline on the launch the hot path issues: ONE batched tile-SpMM launch over the
+    G = len(shifts) panels of a sweep (grid.z = G), HIP events on the ctx stream.
+    Two byte models, both reported:
+      per-panel   G x B_spmm,  B_spmm  = 12 nnz(S) + 4 (n+1) + 16 n m           (`frac`)
+      batched     B_batch = nnz(K) (8+8+4) + 2 nnz(J) 12 + 4 (n+1) + 16 n m G   (`frac_batched_form`)
+    -- the second counts the matrix once for all G shifts.  `frac` uses the MEDIAN of five
+    trials of `reps` launches; the best trial is next to it."""
     import torch
     G = len(shifts)
+    nnz_s = nnz_k + 2 * nnz_j
     x = torch.randn(G, n, m, dtype=torch.float64, device="cuda")
     y = torch.empty_like(x)
     torch.cuda.synchronize()
     al, be = [float(p) for p in shifts], [1.0] * G
     ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
-    # best of three trials of `reps` launches each (clock dips of a freshly loaded box)
-    ms = min(ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), reps) for _ in range(3))
-    ms1 = min(ctx.time_spmm_dev(al[0], 1.0, x.data_ptr(), m, y.data_ptr(), reps) for _ in range(3))
+    med, best = trials(lambda: ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), reps))
+    med1, best1 = trials(lambda: ctx.time_spmm_dev(al[0], 1.0, x.data_ptr(), m, y.data_ptr(), reps))
     unit = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
     nbytes = unit * G
-    gbs = nbytes / (ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC passes of this kernel and shape
-    # (profiles/r01_spmm_traffic.json); None for shapes that were not profiled
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")) as f:
-            traffic = json.load(f).get("%dx%dx%d" % (G, n, m), {}).get("hbm_bytes")
-    except (OSError, ValueError):
-        pass
+    b_batch = nnz_k * 20.0 + 2.0 * nnz_j * 12.0 + 4.0 * (n + 1) + 16.0 * n * m * G
+    gbs = nbytes / (med * 1e-3) / 1e9
+    traffic, tsrc = traffic_entry("%dx%dx%d" % (G, n, m))
     return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic,
-                kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(ms * 1e3, 2),
+                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
+                kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(med * 1e3, 2),
+                us_per_launch_best=round(best * 1e3, 2),
+                frac_best=round(nbytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 units_per_launch=G, algorithmic_bytes=int(nbytes),
-                algorithmic_bytes_per_unit=int(unit), n=int(n), m=int(m), nnz=int(nnz_s),
-                single_panel_us_per_launch=round(ms1 * 1e3, 2),
-                single_panel_frac=round(unit / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+                algorithmic_bytes_per_unit=int(unit),
+                algorithmic_bytes_batched_form=int(b_batch),
+                frac_batched_form=round(b_batch / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                traffic_over_batched_form=(round(traffic / b_batch, 3) if traffic else None),
+                n=int(n), m=int(m), nnz=int(nnz_s),
+                single_panel_us_per_launch=round(med1 * 1e3, 2),
+                single_panel_frac=round(unit / (med1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                timing="median of 5 trials x %d launches, HIP events" % reps)
+
+
+def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
+    """Roofline objects for the kernels that dominate the run time besides K1, on the launch
+    the batched GMRES issues (G groups).  Algorithmic bytes per launch:
+      block_apply<32,float>   G (4 nb 32^2 + 16 nv m)         FP32 inverses + panel in/out
+      dense_apply_tiled       G (4 (16 ceil(k/16))^2 + 16 k m)  FP32 coarse inverse + rc/ec
+      cols_dots               G ((nvec b + 8) n m)            nvec basis vectors of b bytes/entry + w
+      cols_update_dots        G ((nvec b + 16) n m)           basis (second pass from cache) + w in/out
+      cols_update             G ((nvec b + 16 + b) n m)       basis + w in, FP64 + stored copy out
+    with b = 2 (FP16-stored basis; 4 / 8 with RICADI_BASIS32 / 64)."""
+    G = len(shifts)
+    al, be = [float(p) for p in shifts], [1.0] * G
+    n, nv = ctx.n, ctx.nv
+    info = ctx.setup_info()
+    nb, kc = info["nbv"], info["kc"]
+    b = 8 if os.environ.get("RICADI_BASIS64") else (4 if os.environ.get("RICADI_BASIS32") else 2)
+    pb_ = 8 if os.environ.get("RICADI_PRECOND64") else 4
+    kp = 16 * ((kc + 15) // 16)
+    models = {
+        "block_v": ("ricadi::block_apply_kernel<32,%s>" % ("double" if pb_ == 8 else "float"),
+                    G * (pb_ * nb * 1024.0 + 16.0 * nv * m)),
+        "coarse": ("ricadi::dense_apply_tiled_kernel" if pb_ == 4 else "ricadi::dense_apply_kernel<double>",
+                   G * (pb_ * float(kp) * kp + 16.0 * kc * m)),
+        "dots": ("ricadi::cols_dots_kernel (+reduce_partials)", G * ((nvec * b + 8.0) * n * m)),
+        "update_dots": ("ricadi::cols_update_dots_kernel (+reduce_partials)", G * ((nvec * b + 16.0) * n * m)),
+        "update": ("ricadi::cols_update_kernel", G * ((nvec * b + 16.0 + b) * n * m)),
+    }
+    out = {}
+    for key, (kname, nbytes) in models.items():
+        ctx.time_kernel_dev(key, al, be, m, nvec=nvec, reps=10)
+        med, best = trials(lambda: ctx.time_kernel_dev(key, al, be, m, nvec=nvec, reps=reps))
+        gbs = nbytes / (med * 1e-3) / 1e9
+        out[key] = dict(bound="hbm", kernel=kname, achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(gbs / HBM_PEAK_GBS, 4), us_per_launch=round(med * 1e3, 2),
+                        us_per_launch_best=round(best * 1e3, 2), algorithmic_bytes=int(nbytes),
+                        units_per_launch=G, nvec=nvec if key in ("dots", "update_dots", "update") else None)
+    # anatomy of one lockstep iteration at G groups (sum over its launches)
+    ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=5)
+    med, _ = trials(lambda: ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=50), 3)
+    out["precond_apply_all_launches_us"] = round(med * 1e3, 1)
+    return out
 
 
 def gram_mfma(ctx, nv, c, reps=20):
-    """K5: G = Z^T Z on v_mfma_f64_16x16x4_f64 -- the 2*NV*c^2 flops of the compression step
-     against the FP64 matrix peak (78.6 TFLOP/s)."""
+    """K5 (default compression route): G = Z^T Z on v_mfma_f64_16x16x4_f64 -- 2 NV c^2 flops
+    against the FP64 matrix peak."""
     import torch
     z = torch.randn(nv, c, dtype=torch.float64, device="cuda")
     g = torch.empty(c, c, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     ctx.time_gram_dev(z.data_ptr(), c, g.data_ptr(), 3)
-    ms = min(ctx.time_gram_dev(z.data_ptr(), c, g.data_ptr(), reps) for _ in range(3))
+    med, best = trials(lambda: ctx.time_gram_dev(z.data_ptr(), c, g.data_ptr(), reps))
     flops = 2.0 * nv * c * c
-    tf = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", achieved=round(tf, 2), peak=78.6, unit="TFLOP/s",
-                frac=round(tf / 78.6, 4), kernel="ricadi::gemm_tn_kernel<4,4> (symmetric)",
-                us_per_launch=round(ms * 1e3, 1), nv=int(nv), c=int(c))
+    tf = flops / (med * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(tf, 2), peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                frac=round(tf / FP64_MFMA_PEAK_TF, 4), kernel="ricadi::gemm_tn_kernel<4,4> (symmetric)",
+                us_per_launch=round(med * 1e3, 1), us_per_launch_best=round(best * 1e3, 1),
+                nv=int(nv), c=int(c))
 
 
-def cpu_baseline(pr, ms, m, adi_steps, nsample_shifts=3, solves_per_shift=4):
-    """Oracle (scipy SuperLU, as the reference's technology) on a bounded sample:
-    LU of `nsample_shifts` shifted saddle matrices + `solves_per_shift` panel solves
-    each; extrapolated to the step's work (16 LUs + adi_steps shift-solves)."""
+def tsqr_mfma(ctx, nv, c, reps=3):
+    """K5 (TSQR route, north_star's "MFMA utilisation on the TSQR"): thin QR of an NV x c factor
+    by ricadi_qr's device path -- Householder TSQR panels (LDS) inside a block Gram-Schmidt on
+    the MFMA GEMMs.  Algorithmic flops 2 NV c^2 - 2/3 c^3 over the whole
+    factorisation's duration (HIP events)."""
+    import torch
+    z = torch.randn(nv, c, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.time_qr_dev(z.data_ptr(), c, 1)
+    med, best = trials(lambda: ctx.time_qr_dev(z.data_ptr(), c, reps), 3)
+    flops = 2.0 * nv * c * c - (2.0 / 3.0) * c ** 3
+    tf = flops / (med * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                frac=round(tf / FP64_MFMA_PEAK_TF, 4),
+                kernel="ricadi block QR: tsqr_local/tsqr_apply (LDS Householder) + gemm_tn/gemm_nn (MFMA)",
+                ms_per_factorisation=round(med, 2), ms_best=round(best, 2), nv=int(nv), c=int(c))
+
+
+def _cpu_shift_worker(args):
+    """One process per shift (BASELINE.md plan (b)): LU of its shifted saddle matrix once, then
+    `nsolve` panel solves -- the work one shift contributes to a step in sweep form."""
+    calA, M, J, p, m, nsolve, seed = args
     from oracle import lin_alg_utils as olau
+    t0 = time.perf_counter()
+    lu = olau.SaddleLU(calA + p * M, J)
+    t_lu = time.perf_counter() - t0
+    R = np.random.default_rng(seed).standard_normal((M.shape[0], m))
+    t0 = time.perf_counter()
+    for _ in range(nsolve):
+        lu.solve(R)
+    return t_lu, time.perf_counter() - t0
+
+
+def cpu_baseline(pr, ms, m, adi_steps, full=False):
+    """Oracle (scipy SuperLU -- the reference's technology) on the host cores, same matrices.
+    One step = len(ms) sparse LUs + adi_steps shift-solves (the reference amortises one LU per
+    shift over the ADI cycles).
+      `value` (cores = 1): bounded sample -- 4 of the LUs and 2 panel solves on each (~12 s),
+         priced up to the step; with --cpu-full ALL LUs and ALL solves are run (~100 s);
+      `parallel`: the FULL step, nothing extrapolated, as the sweep form parallelises it on a
+         CPU: one process per shift (LU + its adi_steps/len(ms) panel solves), min(cores, 16)
+         processes, wall time (BASELINE.md plan (b))."""
+    from oracle import lin_alg_utils as olau
+    import multiprocessing as mp
     calA = (-pr.A - pr.Nc).T.tocsr()
-    rng = np.random.default_rng(0)
-    R = rng.standard_normal((pr.NV, m))
-    t_lu, t_solve, nlu, nsol = 0.0, 0.0, 0, 0
-    pick = [ms[0], ms[len(ms) // 2], ms[-1]][:nsample_shifts]
+    M = pr.M.T.tocsr()
+    R = np.random.default_rng(0).standard_normal((pr.NV, m))
+    ns = len(ms)
+    per_shift = max(1, adi_steps // ns)
+    pick = list(ms) if full else [ms[0], ms[ns // 3], ms[(2 * ns) // 3], ms[-1]]
+    nsol_each = per_shift if full else 2
+    t_lu, t_sol = 0.0, 0.0
     for p in pick:
         t0 = time.perf_counter()
-        lu = olau.SaddleLU(calA + p * pr.M, pr.J)
+        lu = olau.SaddleLU(calA + p * M, pr.J)
         t_lu += time.perf_counter() - t0
-        nlu += 1
-        for _ in range(solves_per_shift):
-            t0 = time.perf_counter()
+        t0 = time.perf_counter()
+        for _ in range(nsol_each):
             lu.solve(R)
-            t_solve += time.perf_counter() - t0
-            nsol += 1
-    lu_s, sol_s = t_lu / nlu, t_solve / nsol
-    step_time = len(ms) * lu_s + adi_steps * sol_s
-    return dict(value=round(adi_steps / step_time, 3), unit="shift-solves/s", cores=1,
-                kind="port",
-                sample="%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) "
-                       "of the cfg2 saddle matrix, scipy SuperLU single-threaded; "
-                       "extrapolated to one step = %d LUs + %d shift-solves"
-                       % (nlu, lu_s, nsol, m, sol_s, len(ms), adi_steps),
-                lu_seconds=round(lu_s, 3), solve_seconds=round(sol_s, 4))
+        t_sol += time.perf_counter() - t0
+        del lu
+    lu_s, sol_s = t_lu / len(pick), t_sol / (len(pick) * nsol_each)
+    step_time = ns * lu_s + ns * per_shift * sol_s
+    out = dict(value=round(ns * per_shift / step_time, 3), unit="shift-solves/s", cores=1, kind="port",
+               sample=("the full step: %d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each)"
+                       % (ns, lu_s, ns * per_shift, m, sol_s)) if full else
+                      ("%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) of the cfg2 "
+                       "saddle matrices, scipy SuperLU single-threaded; priced up to one step = %d LUs + "
+                       "%d shift-solves (%.0f s)" % (len(pick), lu_s, len(pick) * nsol_each, m, sol_s, ns,
+                                                    ns * per_shift, step_time)),
+               lu_seconds=round(lu_s, 3), solve_seconds=round(sol_s, 4), step_seconds=round(step_time, 2))
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or 1
+    nproc = max(1, min(ns, ncore, 16))
+    try:
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(nproc) as pool:
+            res = pool.map(_cpu_shift_worker, [(calA, M, pr.J, p, m, per_shift, i) for i, p in enumerate(ms)],
+                           chunksize=1)
+        wall = time.perf_counter() - t0
+        out["parallel"] = dict(value=round(ns * per_shift / wall, 3), unit="shift-solves/s", cores=nproc,
+                               kind="port",
+                               sample="the FULL step, one process per shift on %d cores: %d LUs + %d panel "
+                                      "solves, wall %.1f s (sum over processes: LU %.1f s, solves %.1f s)"
+                                      % (nproc, ns, ns * per_shift, wall, sum(r[0] for r in res),
+                                         sum(r[1] for r in res)),
+                               step_seconds=round(wall, 2))
+    except Exception as e:                                   # never lose the headline line
+        out["parallel"] = {"error": str(e)}
+    return out
 
 
 def main():
@@ -149,26 +298,29 @@ def main():
     ap.add_argument("--N", type=int, default=58, help="mesh parameter (58 = BASELINE cfg2)")
     ap.add_argument("--nu", type=float, default=0.05)
     ap.add_argument("--shifts", type=int, default=16)
-    ap.add_argument("--sequential", action="store_true",
-                    help="N=1 only: the Newton step through ricadi_ric_newtonadi (the drop-in's C++ "
-                         "path), ADI steps one at a time")
-    ap.add_argument("--cpp-sweeps", action="store_true",
-                    help="with --sequential: the same C++ path in sweep form (sweep_width = "
-                         "--sweep-width), as optconpy_amd.proj_ric_utils.proj_alg_ric_newtonadi runs it")
     ap.add_argument("--sweep-width", type=int, default=16,
                     help="shifts per sweep (<= 16; default: the whole 16-shift cycle in one sweep)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="1 (default): the shifts of a rank go through one batched solve; k > 1: they "
-                         "are cut into k batches that run concurrently (one library context, HIP "
-                         "stream and host thread each; measured at cfg2: 2 -> +5 %, 3 -> +7 %, 4 -> "
-                         "+6 %, 8 -> -12 % against one batch of 16)")
+    ap.add_argument("--python-driver", action="store_true",
+                    help="N=1: time the Python sweep driver (shift_parallel.py, the multi-GPU code path "
+                         "at world size 1) as the headline instead of the drop-in boundary")
+    ap.add_argument("--stepwise", action="store_true",
+                    help="N=1: the drop-in call with sweep_width=1 (ADI steps one at a time, as the reference)")
+    ap.add_argument("--col-split", type=int, default=0,
+                    help="N>1: column parts per shift (0 = automatic: 2 when the ranks would otherwise "
+                         "hold fewer than 4 groups)")
+    ap.add_argument("--streams", type=int, default=1, help="Python driver only: concurrent batches per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="cpu_baseline: run the whole single-core step (all LUs, all panel solves, ~100 s)")
     ap.add_argument("--no-large-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline only (no second figures, no kernel rooflines)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from optconpy_amd import _lib, backend, problems as pb
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -185,73 +337,83 @@ def main():
 
     t0 = time.time()
     pr, tb, trct, ms = build_inputs(args.N, args.nu, args.shifts)
-    backend.reset()
-    calA = (-pr.A - pr.Nc).T.tocsr()
-    calE = pr.M.T.tocsr()
-    # developer hook for option sweeps: RICADI_OPTS="agg_v=24,agg_p=36,gmres_restart=20"
-    xopts = {}
-    for kv in filter(None, os.environ.get("RICADI_OPTS", "").split(",")):
-        k, v = kv.split("=")
-        xopts[k] = float(v) if "tol" in k else int(v)
-    ctx = _lib.Context(local, **xopts)
-    ctx.set_operator(calA, calE, pr.J)
-    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
-    prm_full = _lib.adi_params(dict(d, sweep_width=16))     # untimed reference solve: sweep form
-    prm_one = _lib.adi_params(dict(d, nwtn_max_steps=1,
-                                   compress_cols=int(os.environ.get("RICADI_CC", "0")),
-                                   sweep_width=args.sweep_width if args.cpp_sweeps else 1))
+    F = (-pr.A - pr.Nc).tocsr()
+    MT = pr.M.T.tocsr()
+    calA, calE = F.T.tocsr(), MT
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms, sweep_width=1 if args.stepwise else args.sweep_width)
     nb, mw = tb.shape[1], trct.shape[1]
     m = nb + mw
     n = pr.NV + pr.NP
-    nnz_s = (calA + calE).nnz + 2 * pr.J.nnz
+    nnz_k = (calA + calE).nnz
+    nnz_s = nnz_k + 2 * pr.J.nnz
+    K_oracle = oracle_gain(args.N, args.nu, args.shifts)
 
-    # untimed: converge the Newton iteration once; its compressed iterate is the
-    # linearisation point of the timed Newton step (so that the step sees the
-    # closed-loop low-rank term and the full m = 16 panel, like steps >= 2 do)
-    Zfull, info_full = ctx.ric_newtonadi(ms, tb, trct, prm_full, fetch=False)
-    Zk = ctx.factor_get()          # the Newton driver leaves the compressed iterate on the device
-    K_ref = -ctx.gain(tb)
+    # untimed: converge the Newton iteration once through the boundary; its compressed
+    # iterate is the linearisation point Z_k of the timed Newton step
+    conv = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
+    Zk = conv["zfac"]
+    K_conv = -pru.get_mTzzTtb(MT, Zk, tb)
+    ctx = backend.context_for(calA, calE, pr.J)          # the drop-in's context (operator resident)
     if rank == 0:
-        log("setup %.1fs: n=%d nnz(S)=%d m=%d; converged Newton: %s; |Z_k| cols %d"
-            % (time.time() - t0, n, nnz_s, m, info_full, Zk.shape[1]))
+        log("setup %.1fs: n=%d nnz(S)=%d m=%d; converged Newton: %d steps, %d shift-solves; |Z_k| cols %d; "
+            "K vs oracle fixture: %s"
+            % (time.time() - t0, n, nnz_s, m, conv["nwtn_steps"], conv["shift_solves"], Zk.shape[1],
+               "n/a" if K_oracle is None else "%.2e" % (np.linalg.norm(K_conv - K_oracle) / np.linalg.norm(K_oracle))))
+    d1 = dict(d, nwtn_max_steps=1)
 
-    use_sp = world > 1 or not args.sequential
-    if not use_sp:
-        def one_step():
-            ctx.clear_cache()                       # per-shift setup is part of the step
-            _, info = ctx.ric_newtonadi(ms, tb, trct, prm_one, Z0=Zk, fetch=False)
-            K = -ctx.gain(tb)
-            return info["shift_solves"], info["gmres_iters"], K, info["shift_solves"]
-    else:
-        from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel
+    def dropin_step():
+        """optcont_main.py:488-492,505 through the boundary; per-shift setup is part of the step."""
+        ctx.clear_cache()
+        out = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=Zk,
+                                         nwtn_adi_dict=d1)
+        K = -pru.get_mTzzTtb(MT, out["zfac"], tb)
+        if out["gmres_nonconverged"]:
+            raise RuntimeError("bench: %d timed shift-solves missed gmres_tol (worst %.2e)"
+                               % (out["gmres_nonconverged"], out["gmres_worst_relres"]))
+        return out["adi_steps"], out["gmres_iters"], K, out["shift_solves"]
+
+    # the Python sweep driver (the multi-GPU code path; at world size 1 a second figure)
+    from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel, plan_items
+    from optconpy_amd import lin_alg_utils as glau
+    sp = {}
+
+    def sp_prepare():
         nstreams = max(1, args.streams)
         extra = []
         for _ in range(max(0, nstreams - 1)):
-            cx = _lib.Context(local, **xopts)
+            cx = _lib.Context(local)
             cx.set_operator(calA, calE, pr.J)
             extra.append(cx)
         ops = HipOps(ctx, extra)
         G = max(1, min(args.sweep_width, 16, len(ms)))
-        # closed-loop operator cal A - K_k B^T and rhs [W, K_k] of the Newton step
-        Kk = -K_ref                                  # K_k = E Z_k Z_k^T B
-        from optconpy_amd import lin_alg_utils as lau
-        Wp = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=trct, transposedprj=True)
-        backend.reset()
-        rhs = ops.to_panel(np.hstack([Wp, Kk]))
-        tbd = ops.to_panel(tb)
+        Kk = -K_conv                                         # K_k = E Z_k Z_k^T B
+        Wp = glau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=trct, transposedprj=True)
+        backend.context_for(calA, calE, pr.J)                # the projection re-set the operator (E only)
+        sp.update(ops=ops, G=G, Kk=Kk, rhs=ops.to_panel(np.hstack([Wp, Kk])), tbd=ops.to_panel(tb),
+                  extra=extra, parts=plan_items(G, world, args.col_split))
 
-        def one_step():
-            ops.clear_cache()
-            if not os.environ.get('BENCH_NO_LR'):     # developer probe: open-loop operator
-                ops.set_lowrank(Kk, tb)
-            ops.gmres_iters = 0
-            ops.shift_solves = 0
-            blocks, info = lyap_adi_shift_parallel(ops, ms, rhs, adi_max_steps=200,
-                                                   adi_newZ_reltol=1e-8, width=G)
+    def sp_step():
+        ops = sp["ops"]
+        ops.clear_cache()
+        ops.set_lowrank(sp["Kk"], tb)
+        ops.gmres_iters = ops.shift_solves = ops.nonconverged = 0
+        try:
+            blocks, info = lyap_adi_shift_parallel(ops, ms, sp["rhs"], adi_max_steps=200,
+                                                   adi_newZ_reltol=1e-8, width=sp["G"],
+                                                   col_parts=sp["parts"])
+        finally:
             ops.set_lowrank(None, None)
-            Z = torch.cat(blocks, dim=1).contiguous()
-            Kt = ops.gain(-1.0, Z, tbd)             # gain on the replicated factor
-            return info["adi_steps"], ops.gmres_iters, Kt.cpu().numpy(), ops.shift_solves
+        if info["gmres_nonconverged"]:
+            raise RuntimeError("bench: %d timed shift-solves missed gmres_tol (worst %.2e)"
+                               % (info["gmres_nonconverged"], info["gmres_worst_relres"]))
+        Z = torch.cat(blocks, dim=1).contiguous()
+        Kt = ops.gain(-1.0, Z, sp["tbd"])                    # gain on the replicated factor
+        return info["adi_steps"], ops.gmres_iters, Kt.cpu().numpy(), ops.shift_solves
+
+    use_sp = world > 1 or args.python_driver
+    if use_sp:
+        sp_prepare()
+    one_step = sp_step if use_sp else dropin_step
 
     def barrier():
         if world > 1:
@@ -259,36 +421,42 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    if use_sp:
-        ops.t_solve = 0.0
+    def timed(step, nsteps, nwarm):
+        for _ in range(nwarm):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        units = iters = solves = 0
+        K = None
+        for _ in range(nsteps):
+            u, it, K, ls = step()
+            units += u
+            iters += it
+            solves += ls
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return units, iters, solves, K, el
 
-    def ops_t_solve():
-        return ops.t_solve
-    t0 = time.perf_counter()
-    units = 0
-    iters = 0
-    local_solves = 0
-    K = None
-    for _ in range(args.steps):
-        u, it, K, ls = one_step()
-        units += u
-        iters += it
-        local_solves += ls
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_sp and rank == 0:
-        log("[bench] rank 0: %.1f %% of the timed region inside the batched shift-solves "
-            "(incl. per-shift setup)" % (100.0 * ops_t_solve() / max(elapsed, 1e-9)))
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    k_err = float(np.linalg.norm(K - K_ref) / np.linalg.norm(K_ref))
+    units, iters, local_solves, K, elapsed = timed(one_step, args.steps, args.warmup)
+    k_conv = float(np.linalg.norm(K - K_conv) / np.linalg.norm(K_conv))
+    k_orc = None if K_oracle is None else float(np.linalg.norm(K - K_oracle) / np.linalg.norm(K_oracle))
 
     if rank == 0:
+        basis = "FP64" if os.environ.get("RICADI_BASIS64") else "FP32" if os.environ.get("RICADI_BASIS32") else "FP16"
+        prec = "FP64" if os.environ.get("RICADI_PRECOND64") else "FP32"
+        if use_sp:
+            par = ("shift-parallel ADI on %d GPU(s) (Python sweep driver): %d shifts/sweep x %d column part(s) "
+                   "= %d work items dealt to the ranks, one batched lockstep solve per rank and sweep, "
+                   "1 all-gather/sweep" % (world, sp["G"], sp["parts"], sp["G"] * sp["parts"]))
+        else:
+            par = ("drop-in boundary (sadptprj_riclyap_adi.proj_ric_utils.proj_alg_ric_newtonadi + get_mTzzTtb), "
+                   "C++ Newton-ADI, %s, 1 GPU"
+                   % ("ADI steps one at a time" if args.stepwise
+                      else "sweeps of %d shifts in one batched lockstep solve" % args.sweep_width))
         out = {
             "metric": "ADI shift-solves/sec (wall-clock to feedback K in ms_per_step)",
             "value": round(units / elapsed, 3),
@@ -303,46 +471,102 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "driven cavity N=%d (cfg2: n=%d, nnz(S)=%d), nu=%g, %d log-spaced "
-                            "ADI shifts, 1 Newton step (closed-loop Lyapunov ADI to "
-                            "adi_newZ_reltol=1e-8) + gain K; panel m=%d; GMRES tol 1e-10"
+                "workload": "driven cavity N=%d (cfg2: n=%d, nnz(S)=%d), nu=%g, %d log-spaced ADI shifts, "
+                            "1 Newton step from the converged iterate (closed-loop Lyapunov ADI to "
+                            "adi_newZ_reltol=1e-8, update norm, recompression) + gain K; panel m=%d; "
+                            "GMRES tol 1e-10; per-shift setup inside the step"
                             % (args.N, n, nnz_s, args.nu, len(ms), m),
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),
-                "parallelism": ("C++ Newton-ADI, %s, 1 GPU" % ("sweeps of %d shifts in one batched solve"
-                                                              % args.sweep_width if args.cpp_sweeps
-                                                              else "ADI steps one at a time")) if not use_sp
-                else "shift-parallel ADI on %d GPU(s), %d shifts/sweep, %s, 1 all-gather/sweep"
-                % (world, G, "one batched lockstep solve per rank and sweep" if nstreams == 1
-                   else "%d concurrent batched solves per rank and sweep" % nstreams),
-                "K_rel_diff_vs_converged": k_err,
+                "parallelism": par,
+                "K_rel_diff_vs_oracle": k_orc,
+                "K_rel_diff_vs_converged": k_conv,
                 "storage": "arithmetic and all residual checks FP64; Krylov basis stored in %s, "
                            "preconditioner inverses in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage)"
-                           % ("FP64" if os.environ.get("RICADI_BASIS64") else
-                              "FP32" if os.environ.get("RICADI_BASIS32") else "FP16",
-                              "FP64" if os.environ.get("RICADI_PRECOND64") else "FP32"),
+                           % (basis, prec),
             },
         }
-        # the launch of the hot path: the sweep's shifts of one rank in one batched launch
-        gsh = [float(p) for p in ms[:max(1, (G if use_sp else 1) // world)]]
-        out["roofline"] = spmm_roofline(ctx, nnz_s, n, m, gsh)
+        if k_orc is not None and k_orc > 1e-6:
+            out["config"]["PARITY_VIOLATION"] = "K differs from the oracle fixture by %.2e > 1e-6" % k_orc
+
+    extras = world == 1 and not args.no_extras
+    if extras:
+        # --- second figures on the same workload (untimed by the driver) -------------------
+        try:
+            if use_sp:
+                u2, _, _, K2, el2 = timed(dropin_step, 2, 1)
+                out["value_dropin_boundary"] = round(u2 / el2, 3)
+            else:
+                sp_prepare()
+                u2, _, _, K2, el2 = timed(sp_step, 2, 1)
+                out["value_python_sweep_driver"] = round(u2 / el2, 3)
+                out["python_sweep_driver_K_rel_diff_vs_oracle"] = (
+                    None if K_oracle is None else float(np.linalg.norm(K2 - K_oracle) / np.linalg.norm(K_oracle)))
+        except Exception as e:
+            out["second_figure_error"] = str(e)
+        # --- kernel rooflines on the launches of this workload ---------------------------------
+        G = max(1, min(args.sweep_width, 16, len(ms)))
+        gsh = [float(p) for p in ms[:G]]
+        out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m, gsh)
+        try:
+            out["roofline_kernels"] = kernel_rooflines(ctx, gsh, m)
+        except Exception as e:
+            out["roofline_kernels"] = {"error": str(e)}
         out["roofline_gram_mfma"] = gram_mfma(ctx, pr.NV, 512)
-        if world == 1 and not args.no_large_roofline:
+        try:
+            out["roofline_tsqr_mfma"] = tsqr_mfma(ctx, pr.NV, 456)
+        except Exception as e:
+            out["roofline_tsqr_mfma"] = {"error": str(e)}
+        # --- FP64 storage of basis + preconditioner: the like-for-like number -----------------
+        try:
+            saved = {k: os.environ.get(k) for k in ("RICADI_BASIS64", "RICADI_PRECOND64")}
+            os.environ["RICADI_BASIS64"] = "1"
+            os.environ["RICADI_PRECOND64"] = "1"
+            backend.reset()
+            ctx = backend.context_for(calA, calE, pr.J)
+            u3, it3, _, K3, el3 = timed(dropin_step, 2, 1)
+            out["value_fp64_storage"] = round(u3 / el3, 3)
+            out["fp64_storage_K_rel_diff_vs_oracle"] = (
+                None if K_oracle is None else float(np.linalg.norm(K3 - K_oracle) / np.linalg.norm(K_oracle)))
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            backend.reset()
+            ctx = backend.context_for(calA, calE, pr.J)
+        except Exception as e:
+            out["value_fp64_storage"] = {"error": str(e)}
+        if not args.no_large_roofline:
             # the HBM-resident instance (BASELINE cfg5 pattern, n ~ 5e5)
             try:
                 prl = pb.ricc_problem(236, 0.05, with_convection=True)
-                cl = _lib.Context(local, coarse_max=2048)
-                cl.set_operator((-prl.A - prl.Nc).T.tocsr(), prl.M.T.tocsr(), prl.J)
-                nl = prl.NV + prl.NP
-                nnzl = (prl.A + prl.Nc + prl.M).nnz + 2 * prl.J.nnz
-                out["roofline_cfg5"] = spmm_roofline(cl, nnzl, nl, 16, gsh, reps=50)
+                cl = _lib.Context(local)
+                cAl, cEl = (-prl.A - prl.Nc).T.tocsr(), prl.M.T.tocsr()
+                cl.set_operator(cAl, cEl, prl.J)
+                out["roofline_cfg5"] = spmm_roofline(cl, (cAl + cEl).nnz, prl.J.nnz, prl.NV + prl.NP, 16, gsh,
+                                                     reps=50)
+                try:
+                    out["roofline_kernels_cfg5"] = kernel_rooflines(cl, gsh, 16, reps=20)
+                except Exception as e:
+                    out["roofline_kernels_cfg5"] = {"error": str(e)}
                 cl.close()
             except Exception as e:                   # never lose the headline line
                 out["roofline_cfg5"] = {"error": str(e)}
+    elif rank == 0 and world == 1:
+        G = max(1, min(args.sweep_width, 16, len(ms)))
+        out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m, [float(p) for p in ms[:G]])
+    elif rank == 0:
+        # N > 1: the launch a rank issues holds its share of the sweep's work items
+        G = max(1, min(args.sweep_width, 16, len(ms)))
+        items = G * sp["parts"]
+        g_loc = max(1, -(-items // world))
+        out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m // sp["parts"], [float(p) for p in ms[:min(g_loc, G)]])
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pr, ms, m, units // args.steps)
+            out["cpu_baseline"] = cpu_baseline(pr, ms, m, units // args.steps, full=args.cpu_full)
         print(json.dumps(out), flush=True)
-    ctx.close()
+    backend.reset()
     if world > 1:
         dist.destroy_process_group()
 

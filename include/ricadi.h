@@ -259,6 +259,16 @@ int ricadi_lincomb_dev(ricadi_ctx* ctx, int nrows, int m, int nvec, const double
 int ricadi_sweep_recombine_dev(ricadi_ctx* ctx, int G, const double* dU, int m,
                                const double* rinv, const double* cinv1,
                                double* dZ, double* dW, double* n2_out);
+/* The same with the solutions in an arbitrary order and with unused slots, as an all-gather
+ * of per-rank blocks delivers them: dU holds nslot panels (nslot x NV x m, contiguous);
+ * coefz (nslot x G, row-major) and coefw (nslot) are the rows of R^-1 and the entries of
+ * C^-1 1 of the shift each slot carries (zero rows for padding slots and for slots that
+ * belong to another column part):  dZ (NV x G*m) = sum_i coefz[i][:] (x) U_i,
+ * dW (NV x m) += E sum_i coefw[i] U_i.  The data are consumed where the collective put
+ * them; only the small coefficient table is permuted.                                  */
+int ricadi_sweep_recombine_slots_dev(ricadi_ctx* ctx, int nslot, int G, const double* dU, int m,
+                                     const double* coefz, const double* coefw,
+                                     double* dZ, double* dW, double* n2_out);
 /* dK (NV x nb) = coef * E * (Z * (Z^T B)) for a device-resident factor dZ
  * (NV x c, row-major with leading dimension ldz) and dB (NV x nb).          */
 int ricadi_gain_dev(ricadi_ctx* ctx, double coef, const double* dZ, int c, int ldz,
@@ -277,12 +287,40 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* ctx, int ng, const double* alphas,
                                const double* betas, const double* dX, int m,
                                double* dY, int reps, double* ms_per_launch);
 
+/* One launch of a hot-path kernel class exactly as the batched GMRES issues it (ng groups,
+ * panel width m, nvec Krylov vectors for the Arnoldi classes), on the solver's own
+ * workspace buffers; average over `reps` launches, HIP events on the context stream.
+ * Behind the per-kernel roofline objects of bench.py.  No reference counterpart.      */
+#define RICADI_TK_SPMM 0          /* tile SpMM of the saddle operator                     */
+#define RICADI_TK_BLOCK_V 1       /* block-Jacobi sweep, velocity blocks                  */
+#define RICADI_TK_BLOCK_P 2       /* block-Jacobi sweep, Schur (pressure) blocks          */
+#define RICADI_TK_COARSE 3        /* dense coarse apply                                   */
+#define RICADI_TK_SPMM_SY 4       /* tile SpMM of the prolongated operator S*Y            */
+#define RICADI_TK_DOTS 5          /* cols_dots + reduce_partials                          */
+#define RICADI_TK_UPDATE_DOTS 6   /* cols_update_dots + reduce_partials                   */
+#define RICADI_TK_UPDATE 7        /* cols_update (writes the new Krylov vector)           */
+#define RICADI_TK_PRECOND 8       /* the whole preconditioner application (all launches)  */
+#define RICADI_TK_RESTRICT 9      /* restriction Y^T r (CSR SpMM with unit values)        */
+int ricadi_time_kernel_dev(ricadi_ctx* ctx, int which, int ng, const double* alphas,
+                           const double* betas, int m, int nvec, int reps,
+                           double* ms_per_launch);
+
 /* K5: thin QR factorisation Z = Q R of an NV x c host matrix (c <= NV) by block
  * Gram-Schmidt with re-orthogonalisation over 32-column panels, each panel
  * factorised by a Householder TSQR tree.  R_out: c x c row-major upper triangular;
  * Q_out: NV x c or NULL.  The "QR" of the reference's compress_Zsvd comment
  * (/root/reference/optcont_main.py:133-134) and of the Newton update norm.      */
 int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_out);
+
+/* Structure of the preconditioner the context built for its operator:
+ * out = [NV, NP, velocity blocks, Schur blocks, block size, coarse dimension,
+ *        SpMM row blocks, max distinct columns per row block]; nout >= 8.           */
+int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
+
+/* Average duration (ms) of the thin QR of a device-resident NV x c factor (the device
+ * part of ricadi_qr: Householder TSQR panels inside a block Gram-Schmidt on the MFMA
+ * GEMMs), HIP events on the context stream: the TSQR MFMA-utilisation figure.          */
+int ricadi_time_qr_dev(ricadi_ctx* ctx, const double* dZ, int c, int reps, double* ms_per_call);
 
 /* Average duration (ms) of the FP64-MFMA Gram kernel G = Z^T Z (the 2*NV*c^2 flop
  * part of ricadi_compress) for a device-resident NV x c factor, HIP events on the

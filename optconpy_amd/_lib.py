@@ -82,13 +82,19 @@ SIGNATURES = {
                                              C.POINTER(C.c_double)]),
     "ricadi_sweep_recombine_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _dp, _dp, _vp, _vp,
                                              C.POINTER(C.c_double)]),
+    "ricadi_sweep_recombine_slots_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _dp, _dp, _vp, _vp,
+                                                   C.POINTER(C.c_double)]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "ricadi_panel_norms_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _dp]),
     "ricadi_time_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp, C.c_int,
                                        _dp]),
+    "ricadi_time_kernel_dev": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_double)]),
     "ricadi_qr": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp]),
+    "ricadi_setup_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
+    "ricadi_time_qr_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ricadi_time_gram_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _dp]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
@@ -482,6 +488,29 @@ class Context:
                                                   reps, C.byref(ms)))
         return ms.value
 
+    TK = dict(spmm=0, block_v=1, block_p=2, coarse=3, spmm_sy=4, dots=5, update_dots=6, update=7,
+              precond=8, restrict=9)
+
+    def time_kernel_dev(self, which, alphas, betas, m, nvec=7, reps=100):
+        """Milliseconds per launch of one hot-path kernel class (``Context.TK``) as the
+        batched GMRES issues it for ``len(alphas)`` groups of width ``m``."""
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        ms = C.c_double(0.0)
+        _chk(self._lib.ricadi_time_kernel_dev(self._h, int(self.TK.get(which, which)), al.size, _d(al),
+                                              _d(be), int(m), int(nvec), int(reps), C.byref(ms)))
+        return ms.value
+
+    def setup_info(self):
+        a = (C.c_int * 8)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 8))
+        return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols"), list(a)))
+
+    def time_qr_dev(self, z_ptr, c, reps):
+        ms = C.c_double(0.0)
+        _chk(self._lib.ricadi_time_qr_dev(self._h, z_ptr, int(c), int(reps), C.byref(ms)))
+        return ms.value
+
     def sweep_recombine_dev(self, G, u_ptr, m, rinv, cinv1, z_ptr, w_ptr):
         """Cauchy recombination of one sweep on the device; returns ``||Z-block||_F^2``."""
         ri = np.ascontiguousarray(rinv, dtype=np.float64)
@@ -489,6 +518,17 @@ class Context:
         n2 = C.c_double(0.0)
         _chk(self._lib.ricadi_sweep_recombine_dev(self._h, int(G), u_ptr, m, _d(ri), _d(ci), z_ptr,
                                                   w_ptr, C.byref(n2)))
+        return n2.value
+
+    def sweep_recombine_slots_dev(self, nslot, G, u_ptr, m, coefz, coefw, z_ptr, w_ptr):
+        """Recombination of one sweep from ``nslot`` gathered panels (see the header)."""
+        cz = np.ascontiguousarray(coefz, dtype=np.float64)
+        cw = np.ascontiguousarray(coefw, dtype=np.float64)
+        if cz.shape != (nslot, G) or cw.shape != (nslot,):
+            raise ValueError("coefficient tables do not match (nslot, G)")
+        n2 = C.c_double(0.0)
+        _chk(self._lib.ricadi_sweep_recombine_slots_dev(self._h, int(nslot), int(G), u_ptr, m, _d(cz),
+                                                        _d(cw), z_ptr, w_ptr, C.byref(n2)))
         return n2.value
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):

@@ -23,7 +23,43 @@ import scipy.sparse as sps
 
 from . import lin_alg_utils as _lau
 
-__all__ = ["simulate_linearized_flow", "eval_costfunc"]
+from . import proj_ric_utils as _pru
+
+__all__ = ["simulate_linearized_flow", "eval_costfunc", "steady_state_feedback"]
+
+
+def steady_state_feedback(mmat=None, amat=None, jmat=None, convc_mat=None, tb_mat=None,
+                          trct_mat=None, mc_mat=None, fv=None, ystar0=None, nwtn_adi_dict=None,
+                          z0=None, comprz_thresh=None, comprz_maxc=None, store=None,
+                          datastr="stst", pru=None, lau=None):
+    """The steady-state branch of ``optcon_nse`` (``optcont_main.py:488-521``), call for call:
+
+        Z      = pru.proj_alg_ric_newtonadi(mmat=M, amat=-A-N, jmat=J, bmat=B~, wmat=C~^T, z0)['zfac']
+        Z      = pru.compress_Zsvd(Z, thresh, k)                         (if asked for)
+        mtxtb  = -pru.get_mTzzTtb(M^T, Z, B~);   mtxfv = -pru.get_mTzzTtb(M^T, Z, fv)
+        w      = lau.solve_sadpnt_smw(amat=A^T+N^T, jmat=J, rhsv=C^T y*(0) + mtxfv,
+                                      umat=mtxtb, vmat=B~^T)[:NV]
+
+    and the static ``feedbackthroughdict = {None: {...}}`` the closed-loop simulation reads
+    (``static_feedback=True``).  Returns ``(feedbackthroughdict, Z)``."""
+    pru = _pru if pru is None else pru
+    lau = _lau if lau is None else lau
+    NV = mmat.shape[0]
+    nmat = sps.csr_matrix((NV, NV)) if convc_mat is None else convc_mat
+    Z = pru.proj_alg_ric_newtonadi(mmat=mmat, amat=(-amat - nmat).tocsr(), jmat=jmat, bmat=tb_mat,
+                                   wmat=trct_mat, z0=z0, nwtn_adi_dict=nwtn_adi_dict)["zfac"]
+    if comprz_thresh is not None or comprz_maxc is not None:
+        Z = pru.compress_Zsvd(Z, thresh=comprz_thresh, k=comprz_maxc)
+    MT = mmat.T.tocsr()
+    fv = np.zeros((NV, 1)) if fv is None else np.asarray(fv, dtype=float).reshape(NV, 1)
+    mtxtb = -pru.get_mTzzTtb(MT, Z, tb_mat)
+    mtxfv = -pru.get_mTzzTtb(MT, Z, fv)
+    fl = mc_mat.T @ np.asarray(ystar0, dtype=float).reshape(-1, 1)
+    w = lau.solve_sadpnt_smw(amat=(amat.T + nmat.T).tocsr(), jmat=jmat, rhsv=fl + mtxfv,
+                             umat=mtxtb, vmat=sps.csr_matrix(tb_mat).T)[:NV]
+    store.save(datastr + "__w", w)
+    store.save(datastr + "__mtxtb", mtxtb)
+    return {None: dict(w=datastr + "__w", mtxtb=datastr + "__mtxtb")}, Z
 
 
 def simulate_linearized_flow(mmat=None, amat=None, jmat=None, tb_mat=None, rhsv=None,
@@ -49,7 +85,7 @@ def simulate_linearized_flow(mmat=None, amat=None, jmat=None, tb_mat=None, rhsv=
         op = (mmat / tau + amat) if nmat is None else (mmat / tau + amat + nmat)
         rhs = (mmat @ v) / tau + rhsv + rhs_td
         if closed_loop and feedbackthroughdict is not None:
-            key = None if static_feedback else t1
+            key = None if (static_feedback or t1 not in feedbackthroughdict) else t1
             gain = store.load(feedbackthroughdict[key]["mtxtb"])          # NV x NU
             w = store.load(feedbackthroughdict[key]["w"])
             rhs = rhs + tb @ (tb.T @ w)
@@ -74,7 +110,8 @@ def eval_costfunc(V=None, W=None, cmat=None, ystar=None, tbmat=None, tmesh=None,
     def uru(t):
         if not penau or fbftdict is None:
             return 0.0
-        key = None if static_feedback else t
+        # a static gain is stored under the key None (optcont_main.py:244-248: KeyError fallback)
+        key = None if (static_feedback or t not in fbftdict) else t
         fb = store.load(fbftdict[key]["mtxtb"]).T @ veldict[t]
         ft = tbmat.T @ store.load(fbftdict[key]["w"])
         return float(np.asarray((fb + ft).T @ (fb + ft)).ravel()[0])

@@ -1923,46 +1923,54 @@ int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* 
   API_END
 }
 
-int ricadi_sweep_recombine_dev(ricadi_ctx* c, int G, const double* dU, int m, const double* rinv,
-                               const double* cinv1, double* dZ, double* dW, double* n2_out) {
+int ricadi_sweep_recombine_slots_dev(ricadi_ctx* c, int nslot, int G, const double* dU, int m,
+                                     const double* coefz, const double* coefw, double* dZ, double* dW,
+                                     double* n2_out) {
   if (int rc = check_panel(c, m)) return rc;
-  REQUIRE(dU && rinv && cinv1 && dZ && dW && n2_out, RICADI_EINVAL, "NULL argument");
-  REQUIRE(G >= 1 && G <= 64 && G * m <= 2048, RICADI_EINVAL, "1 <= G <= 64 and G*m <= 2048 required");
+  REQUIRE(dU && coefz && coefw && dZ && dW && n2_out, RICADI_EINVAL, "NULL argument");
+  REQUIRE(G >= 1 && G <= 64 && nslot >= 1 && nslot <= 128 && G * m <= 2048, RICADI_EINVAL,
+          "1 <= G <= 64, 1 <= nslot <= 128 and G*m <= 2048 required");
   API_BEGIN
   hipStream_t st = c->st;
   const int nv = c->nv;
   const size_t nvm = (size_t)nv * m;
   ensure_work(c, m, std::min(G, RICADI_MAX_GROUPS));
   c->sweep_t.ensure(nvm);
-  c->sweep_coef.ensure((size_t)(G + 1) * G * m);
+  c->sweep_coef.ensure((size_t)(G + 1) * nslot * m);
   c->scratch.ensure((size_t)G * m + 64);
-  std::vector<double> coef((size_t)(G + 1) * G * m);
+  // coefficient rows replicated over the m columns: G columns of coefz, then coefw
+  std::vector<double> coef((size_t)(G + 1) * nslot * m);
   for (int j = 0; j <= G; ++j)
-    for (int i = 0; i < G; ++i) {
-      const double v = j < G ? rinv[(size_t)i * G + j] : cinv1[i];
-      for (int cc = 0; cc < m; ++cc) coef[((size_t)j * G + i) * m + cc] = v;
+    for (int i = 0; i < nslot; ++i) {
+      const double v = j < G ? coefz[(size_t)i * G + j] : coefw[i];
+      for (int cc = 0; cc < m; ++cc) coef[((size_t)j * nslot + i) * m + cc] = v;
     }
   HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * coef.size(),
                         hipMemcpyHostToDevice, st));
-  // Z-block j = sum_i rinv[i][j] U_i  (columns j*m .. of dZ, leading dimension G*m)
+  // Z-block j = sum_i coefz[i][j] U_i  (columns j*m .. of dZ, leading dimension G*m)
   for (int j = 0; j < G; ++j) {
-    launch_cols_update(st, nv, m, G, dU, nvm, c->sweep_coef.p + (size_t)j * G * m, 1.0, nullptr,
+    launch_cols_update(st, nv, m, nslot, dU, nvm, c->sweep_coef.p + (size_t)j * nslot * m, 1.0, nullptr,
                        nullptr, c->sweep_t.p);
     launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, dZ, G * m, j * m, 1.0);
     col_norms2(c, c->sweep_t.p, nv, m, c->scratch.p + (size_t)j * m);
   }
-  // W += E (sum_i cinv1[i] U_i)
-  launch_cols_update(st, nv, m, G, dU, nvm, c->sweep_coef.p + (size_t)G * G * m, 1.0, nullptr, nullptr,
-                     c->sweep_t.p);
+  // W += E (sum_i coefw[i] U_i)
+  launch_cols_update(st, nv, m, nslot, dU, nvm, c->sweep_coef.p + (size_t)G * nslot * m, 1.0, nullptr,
+                     nullptr, c->sweep_t.p);
   launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0, 1.0,
               nullptr, m);
   std::vector<double> nr((size_t)G * m);
   HIPCHK(hipMemcpyAsync(nr.data(), c->scratch.p, sizeof(double) * G * m, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipStreamSynchronize(st));   // also keeps `coef` alive until its upload has run
   double n2 = 0.0;
   for (double v : nr) n2 += v;
   *n2_out = n2;
   API_END
+}
+
+int ricadi_sweep_recombine_dev(ricadi_ctx* c, int G, const double* dU, int m, const double* rinv,
+                               const double* cinv1, double* dZ, double* dW, double* n2_out) {
+  return ricadi_sweep_recombine_slots_dev(c, G, G, dU, m, rinv, cinv1, dZ, dW, n2_out);
 }
 
 int ricadi_gain_dev(ricadi_ctx* c, double coef, const double* dZ, int cz, int ldz, const double* dB,
@@ -2035,6 +2043,130 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* c, int ng, const double* alphas, cons
   API_END
 }
 
+// One launch (or launch pair: the dot kernels come with their partial-sum reduction) of a
+// hot-path kernel class exactly as the batched GMRES issues it, timed with HIP events on
+// the context stream.  Operands are the solver's own workspace buffers, filled with finite
+// values; results are discarded.
+int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alphas, const double* betas,
+                           int m, int nvec, int reps, double* ms_per_launch) {
+  if (int rc = check_panel(c, m)) return rc;
+  REQUIRE(alphas && betas && reps > 0 && ms_per_launch, RICADI_EINVAL, "bad argument");
+  REQUIRE(ng >= 1 && ng <= RICADI_MAX_GROUPS && (size_t)ng * m <= 2048, RICADI_EINVAL,
+          "1 <= ng <= 16 and ng*m <= 2048 required");
+  REQUIRE(nvec >= 1 && nvec <= c->opts.gmres_restart, RICADI_EINVAL, "1 <= nvec <= gmres_restart required");
+  API_BEGIN
+  hipStream_t st = c->st;
+  std::vector<ShiftData*> sds(ng);
+  get_shifts(c, alphas, betas, ng, sds.data());
+  ensure_work(c, m, ng, 0);
+  Batch bt = make_batch(c, sds.data(), ng, m);
+  const int n = c->n, restart = c->opts.gmres_restart;
+  const size_t nm = bt.gs, vs = nm * ng;
+  const size_t gsh = (size_t)(restart + 2) * m;
+  const size_t gspart = (size_t)dots_num_blocks(n) * (restart + 2) * m;
+  // finite fill: byte 0x3C -> 1.5e-18 (FP64), 1.06 (FP16), 0.0115 (FP32)
+  HIPCHK(hipMemsetAsync(c->wv.p, 0x3C, sizeof(double) * vs, st));
+  HIPCHK(hipMemsetAsync(c->zv.p, 0x3C, sizeof(double) * vs, st));
+  HIPCHK(hipMemsetAsync(c->r2.p, 0x3C, sizeof(double) * vs, st));
+  HIPCHK(hipMemsetAsync(c->h1.p, 0x3C, sizeof(double) * gsh * ng, st));
+  HIPCHK(hipMemsetAsync(c->h2.p, 0x3C, sizeof(double) * gsh * ng, st));
+  HIPCHK(hipMemsetAsync(c->scale.p, 0x3C, sizeof(double) * (size_t)ng * m, st));
+  if (c->kc > 0) {
+    HIPCHK(hipMemsetAsync(c->rc.p, 0x3C, sizeof(double) * bt.gsc * ng, st));
+    HIPCHK(hipMemsetAsync(c->ec.p, 0x3C, sizeof(double) * bt.gsc * ng, st));
+  }
+  if (c->np > 0) HIPCHK(hipMemsetAsync(c->tp.p, 0x3C, sizeof(double) * bt.gsp * ng, st));
+  const bool b16 = c->basis16, b32 = c->basis32 && !b16;
+  const size_t basis_bytes = (size_t)(nvec + 1) * vs * (b16 ? 2 : b32 ? 4 : 8);
+  if (c->basis32) {
+    HIPCHK(hipMemsetAsync(c->basisf.p, 0x3C, basis_bytes, st));
+    HIPCHK(hipMemsetAsync(c->vcur.p, 0x3C, sizeof(double) * vs, st));
+  } else {
+    HIPCHK(hipMemsetAsync(c->basis.p, 0x3C, basis_bytes, st));
+  }
+  _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);
+  float* Vf = c->basisf.p;
+  double* V = c->basis.p;
+  const GroupTab& gt = bt.tab;
+  const GroupPtrs ones = same_ptr(c->ones.p);
+  auto launch = [&]() {
+    switch (which) {
+      case 0:
+        saddle_spmm(c, bt, c->zv.p, nm, nullptr, c->wv.p, nm, nullptr, 0, 1.0, 0.0);
+        break;
+      case 1:
+        if (c->precond32)
+          launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, c->r2.p, m, nm,
+                               c->zv.p, m, nm, m, 0);
+        else
+          launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, c->r2.p, m, nm,
+                               c->zv.p, m, nm, m, 0);
+        break;
+      case 2:
+        if (c->nbp <= 0) throw HipError{"no pressure block"};
+        if (c->precond32)
+          launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
+                               bt.gsp, c->zv.p + (size_t)c->nv * m, m, nm, m, 0);
+        else
+          launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->tp.p, m,
+                               bt.gsp, c->zv.p + (size_t)c->nv * m, m, nm, m, 0);
+        break;
+      case 3:
+        if (c->kc <= 0) throw HipError{"no coarse level"};
+        if (c->precond32)
+          launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
+        else
+          launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
+        break;
+      case 4:
+        if (!c->syb_ok) throw HipError{"no tiled S*Y"};
+        launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
+                              c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, nm, c->wv.p, m, nm,
+                              -1.0, 1.0, m, c->syb_max_cols);
+        break;
+      case 5:
+        if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        else if (b32) launch_cols_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        else launch_cols_dots_b(st, gt, n, m, nvec, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        break;
+      case 6:
+        if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        else if (b32) launch_cols_update_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        break;
+      case 7:
+        if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
+        else if (b32) launch_cols_update_b(st, gt, n, m, nvec, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vf + (size_t)nvec * vs, nm);
+        else launch_cols_update_b(st, gt, n, m, nvec, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, V + (size_t)nvec * vs, nm);
+        break;
+      case 8:
+        precond_apply(c, bt, c->wv.p, nm, c->zv.p);
+        break;
+      case 9:
+        if (c->kc <= 0) throw HipError{"no coarse level"};
+        launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, c->wv.p, m, nm, nullptr, c->rc.p, m,
+                      bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
+        break;
+      default:
+        throw HipError{"unknown kernel class"};
+    }
+  };
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  launch();   // warm-up (code object load, caches)
+  HIPCHK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) launch();
+  HIPCHK(hipEventRecord(e1, st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  API_END
+}
+
 int ricadi_qr(ricadi_ctx* c, const double* Z, int cz, double* Q_out, double* R_out) {
   REQUIRE(c && c->nv > 0, RICADI_ESTATE, "set the operator (or the dimensions) first");
   REQUIRE(Z && R_out && cz > 0 && cz <= c->nv, RICADI_EINVAL, "bad argument");
@@ -2050,6 +2182,43 @@ int ricadi_qr(ricadi_ctx* c, const double* Z, int cz, double* Q_out, double* R_o
   HIPCHK(hipMemcpyAsync(R_out, dR.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, c->st));
   if (Q_out) HIPCHK(hipMemcpyAsync(Q_out, dQ.p, sizeof(double) * nv * cz, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
+  REQUIRE(c && out && nout >= 8, RICADI_EINVAL, "bad argument");
+  out[0] = c->nv;
+  out[1] = c->np;
+  out[2] = c->nbv;
+  out[3] = c->nbp;
+  out[4] = c->bs;
+  out[5] = c->kc;
+  out[6] = c->sb_nblk;
+  out[7] = c->sb_max_cols;
+  for (int i = 8; i < nout; ++i) out[i] = 0;
+  return RICADI_OK;
+}
+
+int ricadi_time_qr_dev(ricadi_ctx* c, const double* dZ, int cz, int reps, double* ms_per_call) {
+  REQUIRE(c && c->nv > 0 && dZ && cz > 0 && cz <= c->nv && reps > 0 && ms_per_call, RICADI_EINVAL,
+          "bad argument");
+  API_BEGIN
+  (void)hipSetDevice(c->dev);
+  DArr<double> Q, R;
+  Q.alloc((size_t)c->nv * cz);
+  R.alloc((size_t)cz * cz);
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipEventRecord(e0, c->st));
+  for (int i = 0; i < reps; ++i) block_qr_dev(c, dZ, cz, c->nv, cz, Q.p, R.p);
+  HIPCHK(hipEventRecord(e1, c->st));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_call = (double)ms / reps;
   API_END
 }
 

@@ -81,64 +81,80 @@ class HipOps:
 
     MAX_BATCH = 16
 
-    def solve_many(self, ps, W):
-        """Solve the same panel ``W`` against several shifts.  Default: ONE batched
-        solve (``ricadi_shift_solve_batch_dev``) -- all shifts advance in lockstep
-        inside one launch sequence, grid.z = shifts still iterating.  With extra
-        contexts (``extra_ctxs``) the list is cut into one batch per context and the
-        batches run concurrently on their streams."""
+    def _batch_on(self, ctx, pairs):
+        """One batched solve of the (shift, panel) pairs on ``ctx``; returns the n x m' solution
+        panels (device views), the iteration counts and the true residuals."""
+        m = pairs[0][1].shape[1]
+        ps = [float(p) for p, _ in pairs]
+        shared = all(W is pairs[0][1] for _, W in pairs)
+        if shared:
+            R, stride = pairs[0][1], 0
+        else:
+            R = torch.stack([W for _, W in pairs], dim=0).contiguous()
+            stride = R.shape[1] * m
+        X = self.empty(len(ps), ctx.n, m)
+        torch.cuda.current_stream().synchronize()           # R is ready before ricadi's stream reads it
+        its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), R.data_ptr(), stride, m, X.data_ptr(),
+                                            strict=False)
+        ctx.synchronize()
+        return X, its, rr
+
+    def solve_items(self, pairs, U_out):
+        """Solve the work items ``(shift, NV x m' panel)`` of this rank and write the velocity
+        rows of solution k into ``U_out[k]``.  One batched lockstep solve (chunks of 16); with
+        extra contexts the list is cut into one batch per context, run concurrently."""
         import time
-        nctx = len(self.ctxs)
-        if len(ps) <= 1:
-            return [self.solve(p, W) for p in ps]
-        if nctx == 1:
-            self._sync_in()
-            t0 = time.perf_counter()
-            ctx = self.ctx
-            m = W.shape[1]
-            out = []
-            for c0 in range(0, len(ps), self.MAX_BATCH):
-                chunk = [float(p) for p in ps[c0:c0 + self.MAX_BATCH]]
-                X = self.empty(len(chunk), ctx.n, m)
-                its, rr = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
-                                                    X.data_ptr(), strict=False)
-                ctx.synchronize()
-                self._account(rr)
-                out.extend(X[g, :ctx.nv].contiguous() for g in range(len(chunk)))
-                self.gmres_iters += int(sum(its))
-                self.shift_solves += len(chunk)
-            self.t_solve += time.perf_counter() - t0
-            return out
-        # several contexts: the shift list is cut into len(ctxs) contiguous chunks, each
-        # chunk is ONE batched solve on its context's stream, driven by its own host thread
-        # (ctypes releases the GIL).  While one batch is down to a few active groups --
-        # short, latency-bound kernels -- the other batch's kernels fill the chip.
-        from concurrent.futures import ThreadPoolExecutor
-        if self._pool is None:
-            self._pool = ThreadPoolExecutor(max_workers=nctx)
+        if not pairs:
+            return
         self._sync_in()
         t0 = time.perf_counter()
-        m = W.shape[1]
-        nchunk = min(nctx, len(ps))
-        bounds = [round(i * len(ps) / nchunk) for i in range(nchunk + 1)]
+        nctx = min(len(self.ctxs), len(pairs))
+        nv = self.ctx.nv
+        if nctx <= 1:
+            for c0 in range(0, len(pairs), self.MAX_BATCH):
+                chunk = pairs[c0:c0 + self.MAX_BATCH]
+                X, its, rr = self._batch_on(self.ctx, chunk)
+                for k in range(len(chunk)):
+                    U_out[c0 + k].copy_(X[k, :nv])
+                self.gmres_iters += int(sum(its))
+                self._account(rr)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(max_workers=len(self.ctxs))
+            bounds = [round(i * len(pairs) / nctx) for i in range(nctx + 1)]
 
-        def lane(k):
-            ctx = self.ctxs[k]
-            chunk = [float(p) for p in ps[bounds[k]:bounds[k + 1]]]
-            X = self.empty(len(chunk), ctx.n, m)
-            its, rr = ctx.shift_solve_batch_dev(chunk, [1.0] * len(chunk), W.data_ptr(), 0, m,
-                                                X.data_ptr(), strict=False)
-            ctx.synchronize()
-            return [X[g, :ctx.nv].contiguous() for g in range(len(chunk))], int(sum(its)), rr
+            def lane(k):
+                return self._batch_on(self.ctxs[k], pairs[bounds[k]:bounds[k + 1]])
 
-        out = []
-        for Us, its, rr in self._pool.map(lane, range(nchunk)):
-            out.extend(Us)
-            self.gmres_iters += its
-            self._account(rr)
-        self.shift_solves += len(ps)
+            for k, (X, its, rr) in enumerate(self._pool.map(lane, range(nctx))):
+                for j in range(bounds[k + 1] - bounds[k]):
+                    U_out[bounds[k] + j].copy_(X[j, :nv])
+                self.gmres_iters += int(sum(its))
+                self._account(rr)
+        torch.cuda.current_stream().synchronize()
+        self.shift_solves += len(pairs)
         self.t_solve += time.perf_counter() - t0
-        return out
+
+    def solve_many(self, ps, W):
+        """Solve the same panel ``W`` against several shifts; list of NV x m tensors."""
+        if not len(ps):
+            return []
+        U = self.empty(len(ps), W.shape[0], W.shape[1])
+        self.solve_items([(p, W) for p in ps], U)
+        return [U[k] for k in range(len(ps))]
+
+    def recombine_slots(self, U_all, coefz, coefw, W):
+        """One device call for the Cauchy recombination of a sweep from the gathered buffer
+        ``U_all`` (nslot x NV x m'): returns the NV x (G*m') block and its squared Frobenius
+        norm, and updates ``W += E sum_i coefw[i] U_i`` in place."""
+        nslot, nv, m = U_all.shape
+        G = np.asarray(coefz).shape[1]
+        Zb = self.empty(nv, G * m)
+        self._sync_in()
+        n2 = self.ctx.sweep_recombine_slots_dev(nslot, G, U_all.data_ptr(), m, coefz, coefw,
+                                                Zb.data_ptr(), W.data_ptr())
+        return Zb, n2
 
     def to_panel(self, W):
         return torch.as_tensor(np.ascontiguousarray(W), dtype=torch.float64).to(self.device)
@@ -159,15 +175,8 @@ class HipOps:
         return U
 
     def recombine(self, U_all, rinv, cinv1, W):
-        """One device call for the Cauchy recombination of a sweep: returns the
-        NV x (G*m) block ``U (R^-1 (x) I)`` and its squared Frobenius norm, and
-        updates ``W += E U ((C^-1 1) (x) I)`` in place."""
-        G, nv, m = U_all.shape
-        Zb = self.empty(nv, G * m)
-        self._sync_in()
-        n2 = self.ctx.sweep_recombine_dev(G, U_all.data_ptr(), m, rinv, cinv1, Zb.data_ptr(),
-                                          W.data_ptr())
-        return Zb, n2
+        """Recombination with the solutions in sweep order (``U_all``: G x NV x m)."""
+        return self.recombine_slots(U_all, np.asarray(rinv), np.asarray(cinv1), W)
 
     def lincomb(self, coef, U_all):
         """``sum_i coef[i] * U_all[i]``; ``U_all`` is G x NV x m, contiguous."""
@@ -209,15 +218,45 @@ def sweep_shifts(ms, sweep, G):
     return [float(ms[(sweep * G + g) % ns]) for g in range(G)]
 
 
+def plan_items(G, world, col_parts=0):
+    """Column parts per shift.  The work items of a sweep are the pairs (shift g, column
+    part q): the m columns of the residual factor are independent for a fixed shift
+    ("alternative axis"), so a sweep offers ``G * parts`` items.
+    ``col_parts > 0`` fixes the number; automatic: 1 while every rank gets a shift of its
+    own, else the smallest count that gives every rank an item (more ranks than shifts).
+    A part narrower than 16 columns runs the 16-lane-row kernels with idle lanes, so parts
+    are not used to shorten the per-rank batch when the shifts already cover the ranks."""
+    if col_parts and col_parts > 0:
+        return int(col_parts)
+    return max(1, -(-world // G))
+
+
+def item_layout(G, parts, world):
+    """Dealing of the ``G * parts`` items of a sweep: item ``i = g * parts + q`` goes to rank
+    ``i % world``, local slot ``i // world``; in the rank-major buffer an all-gather fills it
+    sits at ``(i % world) * per_rank + i // world``.  With the shifts sorted by magnitude a
+    rank's items are spread over the whole range, which pairs slow and fast solves."""
+    nitems = G * parts
+    per_rank = -(-nitems // world)
+    items = []
+    for i in range(nitems):
+        items.append(dict(g=i // parts, q=i % parts, rank=i % world, slot=i // world,
+                          pos=(i % world) * per_rank + i // world))
+    return items, per_rank
+
+
 def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
-                            group=None, width=None, max_width=8, verbose=False):
+                            group=None, width=None, max_width=8, verbose=False, col_parts=0):
     """Shift-parallel LR-ADI; returns ``(Z_blocks, info)``.
 
     ``W`` is the (already projected) NV x m residual factor as a tensor on the
     ops' device, replicated on every rank.  Each sweep handles ``G`` distinct
     shifts, ``G = width`` or ``min(world_size, len(ms), max_width)`` (Cauchy
-    conditioning limits ``G``: SURVEY.md F8); shift ``g`` of the sweep is
-    solved by rank ``g % world_size``, so ``G`` may exceed the number of ranks.
+    conditioning limits ``G``: SURVEY.md F8).  The sweep's work items -- (shift,
+    column part) pairs, :func:`plan_items` / :func:`item_layout` -- are dealt to the
+    ranks; a rank solves all its items in ONE batched solve, the solutions are
+    all-gathered into one preallocated rank-major buffer that the recombination
+    reads in place (the Cauchy coefficients are permuted, not the data).
     Stops after the sweep in which the mean new-block norm falls below
     ``adi_newZ_reltol`` (the sequential rule of ``optcont_main.py:123-124`` at
     sweep granularity) or after ``adi_max_steps`` steps.
@@ -240,9 +279,19 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             break
         except (RuntimeError, ValueError):
             G = max(1, G // 2)
-    per_rank = (G + world - 1) // world
     nv, m = W.shape
-    W = W.clone()
+    parts = plan_items(G, world, col_parts)
+    if m % parts:
+        raise ValueError("panel width {0} is not divisible into {1} column parts".format(m, parts))
+    mp_ = m // parts
+    items, per_rank = item_layout(G, parts, world)
+    mine = [it for it in items if it["rank"] == rank]
+    nslot = world * per_rank
+    # residual factor kept as `parts` contiguous NV x m' panels (the right-hand sides of the
+    # items and the operands of the recombination)
+    Wq = [W[:, q * mp_:(q + 1) * mp_].contiguous().clone() for q in range(parts)]
+    U_loc = W.new_zeros((per_rank, nv, mp_))          # padding slots stay zero
+    U_all = W.new_zeros((nslot, nv, mp_)) if world > 1 else U_loc
     blocks = []
     znorm2 = 0.0
     steps = 0
@@ -252,33 +301,36 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         ps = sweep_shifts(ms, nsweeps, G)
         if len(set(ps)) != G:
             raise ValueError("shifts within one sweep must be distinct: {0}".format(ps))
-        mine = [g for g in range(G) if g % world == rank]
-        if hasattr(ops, "solve_many"):
-            local = ops.solve_many([ps[g] for g in mine], W)
+        if hasattr(ops, "solve_items"):
+            ops.solve_items([(ps[it["g"]], Wq[it["q"]]) for it in mine], U_loc)
         else:
-            local = [ops.solve(ps[g], W) for g in mine]
-        while len(local) < per_rank:
-            local.append(torch.zeros_like(W))
-        U_loc = torch.stack(local, dim=0).contiguous()
+            for it in mine:
+                U_loc[it["slot"]].copy_(ops.solve(ps[it["g"]], Wq[it["q"]]))
         if world > 1:
-            gathered = [torch.empty_like(U_loc) for _ in range(world)]
-            dist.all_gather(gathered, U_loc, group=group)
-            U_all = torch.stack([gathered[g % world][g // world] for g in range(G)],
-                                dim=0).contiguous()
-        else:
-            U_all = U_loc[:G].contiguous()
+            dist.all_gather_into_tensor(U_all.view(-1), U_loc.view(-1), group=group)
         rinv, cinv1 = _lib.host_cauchy(ps)
-        if hasattr(ops, "recombine"):
-            Zb, n2 = ops.recombine(U_all, rinv, cinv1, W)
-            blocks.append(Zb)
-        else:
-            n2 = 0.0
-            for j in range(G):
-                Zj = ops.lincomb(rinv[:, j], U_all)
-                n2 += ops.fro2(Zj)
-                blocks.append(Zj)
-            T = ops.lincomb(cinv1, U_all)
-            ops.apply_E(1.0, T, W)
+        n2 = 0.0
+        zparts = []
+        for q in range(parts):
+            # coefficients in BUFFER order: slot `pos` carries shift g (other parts / padding: 0)
+            coefz = np.zeros((nslot, G))
+            coefw = np.zeros(nslot)
+            for it in items:
+                if it["q"] == q:
+                    coefz[it["pos"], :] = rinv[it["g"], :]
+                    coefw[it["pos"]] = cinv1[it["g"]]
+            if hasattr(ops, "recombine_slots"):
+                Zq, n2q = ops.recombine_slots(U_all, coefz, coefw, Wq[q])
+                zparts.append(Zq)
+                n2 += n2q
+            else:
+                for j in range(G):
+                    Zj = ops.lincomb(coefz[:, j], U_all)
+                    n2 += ops.fro2(Zj)
+                    zparts.append(Zj)
+                T = ops.lincomb(coefw, U_all)
+                ops.apply_E(1.0, T, Wq[q])
+        blocks.extend(zparts)
         znorm2 += n2
         steps += G
         nsweeps += 1
@@ -295,16 +347,17 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             stop = bool(flag.item() > 0.5)
         if stop:
             break
-    info = dict(adi_steps=steps, sweeps=nsweeps, width=G, adi_rel_newZ=rel,
-                res_fro=ops.gram_fro(W), resfac=W,
+    Wend = Wq[0] if parts == 1 else torch.cat(Wq, dim=1).contiguous()
+    info = dict(adi_steps=steps, sweeps=nsweeps, width=G, col_parts=parts, adi_rel_newZ=rel,
+                res_fro=ops.gram_fro(Wend), resfac=Wend,
                 gmres_nonconverged=int(getattr(ops, "nonconverged", 0)),
                 gmres_worst_relres=float(getattr(ops, "worst_relres", 0.0)),
                 shift_solves=int(getattr(ops, "shift_solves", 0)))
     if world > 1:
         # a rank only sees its own solves: the counts are summed, the worst residual maximised
-        t = W.new_tensor([info["gmres_nonconverged"], info["shift_solves"]])
+        t = W.new_tensor([info["gmres_nonconverged"], info["shift_solves"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        w = W.new_tensor([info["gmres_worst_relres"]])
+        w = W.new_tensor([info["gmres_worst_relres"]], dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
         info["gmres_nonconverged"], info["shift_solves"] = int(t[0].item()), int(t[1].item())
         info["gmres_worst_relres"] = float(w.item())

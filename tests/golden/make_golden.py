@@ -18,6 +18,8 @@ from optconpy_amd import problems as pb  # noqa: E402
 from oracle import lin_alg_utils as lau, proj_ric_utils as pru  # noqa: E402
 
 CFG1 = dict(N=15, nu=0.1, alphau=1e-2, NU=4, NY=4, nshifts=8, pmin=1.0, pmax=1e3)
+# BASELINE cfg2 = the benchmark's workload (bench.py:build_inputs): N = 58 -> n = 29 930
+CFG2 = dict(N=58, nu=0.05, alphau=1e-2, NU=4, NY=4, nshifts=16, pmin=1.0, pmax=3e3)
 
 
 def cfg1_inputs(cfg=CFG1):
@@ -66,5 +68,41 @@ def main():
           "newton steps", ro["nwtn_steps"], "k", Zc.shape[1])
 
 
+def main_cfg2():
+    """Newton-ADI of the oracle at the benchmark size (about 5 min, 16 sparse LUs per Newton
+    step).  Stored: the converged feedback gain K (the bench / GPU-test target), the Newton
+    history, and the gain after the FIRST Newton step (Z_0 = 0: open-loop Lyapunov solve)."""
+    import time
+    t0 = time.time()
+    pr, tb, trct, ms = cfg1_inputs(CFG2)
+    F = (-pr.A - pr.Nc).tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    stats = {}
+    ro = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct,
+                                    nwtn_adi_dict=d, stats=stats)
+    K_ric = -pru.get_mTzzTtb(pr.M.T, ro["zfac"], tb)
+    lo = pru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=trct, adi_dict=d)
+    K_lyap = -pru.get_mTzzTtb(pr.M.T, lo["zfac"], tb)
+    out = dict(
+        cfg=np.array([CFG2[k] for k in ("N", "nu", "alphau", "NU", "NY", "nshifts", "pmin", "pmax")]),
+        shifts=np.array(ms),
+        mat_checks=np.array([pr.M.data.sum(), pr.A.data.sum(), abs(pr.J.data).sum(),
+                             abs(pr.Nc.data).sum(), pr.M.nnz, pr.A.nnz, pr.J.nnz, pr.Nc.nnz]),
+        tb_fro=np.array([np.linalg.norm(tb.toarray())]), trct_fro=np.array([np.linalg.norm(trct)]),
+        K_ric=K_ric, nwtn_steps=np.array([ro["nwtn_steps"]]),
+        upd_hist=np.array([[u[0], u[1], u[2]] for u in ro["upd_hist"]]),
+        K_lyap=K_lyap, lyap_steps=np.array([lo["adi_steps"]]),
+        oracle_seconds=np.array([time.time() - t0, stats.get("lu_time", 0.0), stats.get("solve_time", 0.0),
+                                 stats.get("n_lu", 0), stats.get("n_shift_solves", 0)]),
+    )
+    path = os.path.join(HERE, "cfg2_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; |K_ric| =", np.linalg.norm(K_ric), "newton steps",
+          ro["nwtn_steps"], "upd_hist", out["upd_hist"].tolist(), "seconds", out["oracle_seconds"].tolist())
+
+
 if __name__ == "__main__":
-    main()
+    if "--cfg2" in sys.argv:
+        main_cfg2()
+    else:
+        main()

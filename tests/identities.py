@@ -56,3 +56,61 @@ def check_reference_identities(pru, M, J, F, W, adi_dict, thresh=1e-6):
     assert abs(factored_res_c - dense_res) <= 1e-5 * rhs_norm                              # (5)
     assert Zc.shape[1] < Z.shape[1]
     return Z, Zc
+
+
+def dense_projected_are(calA, calE, J, B, W):
+    """Independent dense solution of the projected algebraic Riccati equation
+
+        cal_A X cal_E^T + cal_E X cal_A^T - cal_E X B B^T X cal_E^T + W W^T = 0,   X = Theta Xh Theta^T,
+
+    on the divergence-free space ker(J) = range(Theta): the equation is restricted to an
+    orthonormal basis Theta of ker(J) and handed to ``scipy.linalg.solve_continuous_are`` --
+    no ADI, no Newton-Kleinman, no saddle-point solve, nothing shared with oracle/ or the HIP
+    path.  Small N only.  Returns the NV x NV matrix X."""
+    import scipy.linalg as sla
+    Th = sla.null_space(J.toarray() if hasattr(J, "toarray") else np.asarray(J))
+    dn = lambda a: a.toarray() if hasattr(a, "toarray") else np.asarray(a)
+    Ah = Th.T @ dn(calA) @ Th
+    Eh = Th.T @ dn(calE) @ Th
+    Bh = Th.T @ dn(B)
+    Wh = Th.T @ dn(W)
+    # standard form in Y = Eh Xh Eh^T:  a^T Y + Y a - Y b b^T Y + q = 0,  a = (Ah Eh^-1)^T, b = Eh^-T Bh
+    # (scipy's generalised-pencil path rejects these pencils after balancing)
+    a = np.linalg.solve(Eh.T, Ah.T)
+    b = np.linalg.solve(Eh.T, Bh)
+    q = Wh @ Wh.T
+    Y = sla.solve_continuous_are(a, b, q, np.eye(b.shape[1]))
+    for _ in range(2):      # polish the Schur-method result: dense Newton steps (LAPACK Lyapunov solver)
+        ac = a - b @ (b.T @ Y)
+        Y = sla.solve_continuous_lyapunov(ac.T, -(q + Y @ b @ b.T @ Y))
+        Y = 0.5 * (Y + Y.T)
+    res = a.T @ Y + Y @ a - Y @ b @ b.T @ Y + q
+    assert np.linalg.norm(res) < 1e-12 * max(np.linalg.norm(q), np.linalg.norm(a.T @ Y))
+    Xh = np.linalg.solve(Eh, np.linalg.solve(Eh, Y).T).T
+    return Th @ (0.5 * (Xh + Xh.T)) @ Th.T
+
+
+def dre_step_inputs(pr, tau=0.05, seed=0, with_old=False):
+    """Arguments of the reference's per-time-step call (/root/reference/solve_dae_ric.py:147-159)
+    built from a small problem: ft_mat = -(M^T/2 + tau (A^T + N^T)), w_mat = [M^T Zc, sqrt(tau) C~^T],
+    bmat = sqrt(tau) B~, z0 = Zc, mtxoldb = sqrt(tau) * (gain accumulated by earlier outer steps).
+    Returns (kwargs for proj_alg_ric_newtonadi, dict of the dense pieces for the checker)."""
+    import scipy.sparse as sps
+    from oracle import lin_alg_utils as olau
+    MT = pr.M.T.tocsr()
+    ft = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
+    mct = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = olau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+    tct = olau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    Zc = np.sqrt(0.1) * olau.apply_massinv(pr.M, tct)             # terminal value (:100)
+    wmat = np.hstack([MT @ Zc, np.sqrt(tau) * tct])
+    kw = dict(mmat=MT, amat=ft, transposed=True, jmat=pr.J, bmat=np.sqrt(tau) * sps.csr_matrix(tb),
+              wmat=wmat, z0=Zc)
+    old = None
+    if with_old:
+        rng = np.random.default_rng(seed)
+        # a gain-like NV x NU matrix in range(P^T): -M^T Y Y^T B~ for a random projected Y
+        Y = 0.3 * olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=rng.standard_normal((pr.NV, 3)))
+        old = -(MT @ (Y @ (Y.T @ tb)))
+        kw["mtxoldb"] = np.sqrt(tau) * old
+    return kw, dict(MT=MT, ft=ft, tb=tb, wmat=wmat, tau=tau, old=old)

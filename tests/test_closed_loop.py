@@ -44,3 +44,61 @@ def test_closed_loop_gpu_vs_oracle_modules():
         assert np.linalg.norm(v_g[t] - v_o[t]) <= 1e-6 * np.linalg.norm(v_o[t]), t
     assert abs(J_g - J_o) <= 1e-6 * abs(J_o)
     backend.reset()
+
+
+# ------------------------------------------------ steady-state branch, static feedback
+def _run_static(pru, lau):
+    """optcont_main.py:488-536: algebraic Riccati gain, static feedthrough, closed-loop
+    simulation with static_feedback=True, cost functional through the None-keyed dict."""
+    from optconpy_amd.closed_loop import steady_state_feedback
+    pr = pb.ricc_problem(5, 0.2, NU=2, NY=2, alphau=1e-2)
+    mct = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="sparse")
+    trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    NY2 = mct.shape[1]
+    ystar = lambda t: (0.05 * np.arange(1, NY2 + 1)).reshape(-1, 1)        # constant target
+    nad = dict(pb.default_nwtn_adi_dict(), ms=pb.logshifts(0.6, 400.0, 8))
+    store = MemoryStore()
+    fb, Z = steady_state_feedback(mmat=pr.M, amat=pr.A, jmat=pr.J, convc_mat=pr.Nc, tb_mat=tb,
+                                  trct_mat=trct, mc_mat=mct.T, ystar0=ystar(0), nwtn_adi_dict=nad,
+                                  comprz_thresh=5e-5, comprz_maxc=50, store=store, pru=pru, lau=lau)
+    assert list(fb) == [None]
+    tmesh = pb.get_tint(0.0, 0.6, 6, False)
+    tdpart = lambda time=None: (pr.Nc, np.zeros((pr.NV, 1)))
+    sim = dict(mmat=pr.M, amat=pr.A, jmat=pr.J, tb_mat=tb, tmesh=tmesh, get_tdpart=tdpart,
+               iniv=np.zeros((pr.NV, 1)), lau=lau)
+    v_cl = simulate_linearized_flow(feedbackthroughdict=fb, store=store, closed_loop=True,
+                                    static_feedback=True, **sim)
+    v_ol = simulate_linearized_flow(closed_loop=False, **sim)
+    cmat = olau.apply_massinv(pr.y_masmat, mct.T)
+    cost = dict(V=0.1 * pr.y_masmat, W=pr.y_masmat, cmat=cmat, ystar=ystar, tbmat=tb, tmesh=tmesh,
+                store=store)
+    J_cl = eval_costfunc(veldict=v_cl, fbftdict=fb, penau=True, static_feedback=True, **cost)
+    J_cl_fallback = eval_costfunc(veldict=v_cl, fbftdict=fb, penau=True, **cost)   # KeyError -> None key
+    J_ol = eval_costfunc(veldict=v_ol, fbftdict=None, penau=False, **cost)
+    return pr, tmesh, store, fb, v_cl, J_cl, J_cl_fallback, J_ol
+
+
+def test_static_feedback_branch_cpu():
+    pr, tmesh, store, fb, v_cl, J_cl, J_fb, J_ol = _run_static(opru, olau)
+    assert J_cl == J_fb                      # the None-keyed gain is found either way
+    assert J_cl < J_ol                       # tracking a constant target: the static gain helps
+    assert all(np.abs(pr.J @ v).max() < 1e-10 for v in v_cl.values())
+    K = store.load(fb[None]["mtxtb"])
+    assert K.shape == (pr.NV, 4)
+
+
+@pytest.mark.gpu
+def test_static_feedback_gpu_vs_oracle_modules():
+    from optconpy_amd import backend, lin_alg_utils as glau, proj_ric_utils as gpru
+    backend.reset()
+    _, tmesh, so, fo, v_o, J_o, _, _ = _run_static(opru, olau)
+    _, _, sg, fg, v_g, J_g, _, _ = _run_static(gpru, glau)
+    Ko, Kg = so.load(fo[None]["mtxtb"]), sg.load(fg[None]["mtxtb"])
+    assert np.linalg.norm(Kg - Ko) <= 1e-6 * np.linalg.norm(Ko)
+    wo, wg = so.load(fo[None]["w"]), sg.load(fg[None]["w"])
+    assert np.linalg.norm(wg - wo) <= 1e-6 * np.linalg.norm(wo)
+    for t in tmesh[1:]:
+        assert np.linalg.norm(v_g[t] - v_o[t]) <= 1e-6 * np.linalg.norm(v_o[t]), t
+    assert abs(J_g - J_o) <= 1e-6 * abs(J_o)
+    backend.reset()

@@ -99,3 +99,88 @@ def test_sweep_gpu_vs_oracle():
         assert np.linalg.norm(Kg - Ko) <= 1e-6 * np.linalg.norm(Ko), t
         assert np.linalg.norm(wg - wo) <= 1e-6 * np.linalg.norm(wo), t
     backend.reset()
+
+
+# ------------------------------------------- outer-Newton accumulation (curnwtnsdict)
+def _cns_dict(tmesh, prefix="cns"):
+    """Names as optcont_main.py:201-210 (init_nwtnstps_value_dict) builds them."""
+    return {t: dict(v="{0}__cns_v_t{1}".format(prefix, t), mtxtb="{0}__cns_mtxtb_t{1}".format(prefix, t),
+                    w="{0}__cns_w_t{1}".format(prefix, t)) for t in tmesh}
+
+
+class _SpyOld:
+    """Records the mtxoldb / bmat arguments of every Newton-ADI call."""
+
+    def __init__(self, mod):
+        self.mod, self.seen = mod, []
+
+    def __getattr__(self, name):
+        f = getattr(self.mod, name)
+        if name == "proj_alg_ric_newtonadi":
+            def g(*a, **k):
+                self.seen.append(None if k.get("mtxoldb") is None else np.array(k["mtxoldb"]))
+                return f(*a, **k)
+            return g
+        return f
+
+
+def _two_outer_steps(pru, lau, store):
+    """Two passes of the sweep as the outer Newton loop of optcont_main.py:577-600 runs them:
+    same curnwtnsdict, a new data string per pass (so that no Z is memoised)."""
+    pr, kw, tmesh = _setup(N=5, Nts=3)
+    cns = _cns_dict(tmesh)
+    fbs = []
+    for cnsno in range(2):
+        kw2 = dict(kw, get_datastr=lambda time=None, **k: "cns{0}_t{1:.6f}".format(cnsno, time))
+        fbs.append(solve_flow_daeric(store=store, pru=pru, lau=lau, curnwtnsdict=cns, **kw2))
+    return pr, kw, tmesh, cns, fbs
+
+
+def test_curnwtnsdict_accumulation_host_logic():
+    """solve_dae_ric.py:133-141,151,181,197-200 with the oracle's modules: the first pass finds no
+    stored feedback (IOError -> None) and stores gain(t_{k+1}) + gain(t_k) and w(t_k); the second
+    pass hands sqrt(tau) * stored gain to the Newton-ADI call as mtxoldb and adds to the stored sums."""
+    store = MemoryStore()
+    spy = _SpyOld(opru)
+    pr, kw, tmesh, cns, fbs = _two_outer_steps(spy, olau, store)
+    nsteps = len(tmesh) - 1
+    assert len(spy.seen) == 2 * nsteps
+    assert all(s is None for s in spy.seen[:nsteps])               # pass 1: nothing stored yet
+    assert all(s is not None for s in spy.seen[nsteps:])           # pass 2: feedback of pass 1
+    # what pass 1 stored, from its own per-step results
+    K1 = {t: store.load(fbs[0][t]["mtxtb"]) for t in tmesh}
+    K2 = {t: store.load(fbs[1][t]["mtxtb"]) for t in tmesh}
+    w1 = {t: store.load(fbs[0][t]["w"]) for t in tmesh}
+    w2 = {t: store.load(fbs[1][t]["w"]) for t in tmesh}
+    for k in range(nsteps):
+        t, tn = tmesh[k], tmesh[k + 1]
+        after1 = K1[tn] + K1[t]                                    # :181 then :199
+        tau = tn - t
+        # the order of the backward loop: spy.seen[nsteps + (nsteps-1-k)] belongs to time t
+        got = spy.seen[nsteps + (nsteps - 1 - k)]
+        assert np.allclose(got, np.sqrt(tau) * after1, rtol=1e-12, atol=1e-14)
+        assert np.allclose(store.load(cns[t]["mtxtb"]), after1 + K2[tn] + K2[t], rtol=1e-10, atol=1e-14)
+        assert np.allclose(store.load(cns[t]["w"]), w1[t] + w2[t], rtol=1e-10, atol=1e-14)
+    # terminal entries are overwritten by every pass with the terminal values (:118-119)
+    assert np.allclose(store.load(cns[tmesh[-1]]["mtxtb"]), K2[tmesh[-1]])
+    # the old feedback changes the Riccati solution: pass 2 is not a copy of pass 1
+    assert np.linalg.norm(K2[tmesh[0]] - K1[tmesh[0]]) > 1e-6 * np.linalg.norm(K1[tmesh[0]])
+
+
+@pytest.mark.gpu
+def test_curnwtnsdict_gpu_vs_oracle_modules():
+    from optconpy_amd import backend, lin_alg_utils as glau, proj_ric_utils as gpru
+    backend.reset()
+    so, sg = MemoryStore(), MemoryStore()
+    _, _, tmesh, cns, fo = _two_outer_steps(opru, olau, so)
+    _, _, _, _, fg = _two_outer_steps(gpru, glau, sg)
+    for cnsno in range(2):
+        for t in tmesh:
+            Ko, Kg = so.load(fo[cnsno][t]["mtxtb"]), sg.load(fg[cnsno][t]["mtxtb"])
+            wo, wg = so.load(fo[cnsno][t]["w"]), sg.load(fg[cnsno][t]["w"])
+            assert np.linalg.norm(Kg - Ko) <= 1e-6 * np.linalg.norm(Ko), (cnsno, t)
+            assert np.linalg.norm(wg - wo) <= 1e-6 * np.linalg.norm(wo), (cnsno, t)
+    for t in tmesh:
+        assert np.linalg.norm(sg.load(cns[t]["mtxtb"]) - so.load(cns[t]["mtxtb"])) <= \
+            1e-6 * np.linalg.norm(so.load(cns[t]["mtxtb"]))
+    backend.reset()

@@ -132,3 +132,65 @@ def test_golden_vectors(golden, cfg1):
     K = -pru.get_mTzzTtb(pr.M.T, lo["zfac"], tb)
     assert lo["adi_steps"] == int(golden["lyap_steps"][0])
     assert np.linalg.norm(K - golden["K_lyap"]) <= 1e-10 * np.linalg.norm(golden["K_lyap"])
+
+
+# ------------------------------------------------------------------ independent pin
+# The oracle's conventions that the reference does not spell out (`transposed=True`,
+# `z0`, `mtxoldb`) are checked here against a solver that shares nothing with it:
+# scipy.linalg.solve_continuous_are on an orthonormal basis of ker(J) (tests/identities.py).
+_TIGHT = dict(adi_max_steps=300, adi_newZ_reltol=1e-13, nwtn_max_steps=30, nwtn_upd_reltol=1e-12,
+              nwtn_upd_abstol=1e-14)
+
+
+def _xrel(Z, X):
+    return np.linalg.norm(Z @ Z.T - X) / np.linalg.norm(X)
+
+
+def test_dense_are_pin_steady_call():
+    """optcont_main.py:488-492: mmat=M, amat=-A-N, transposed=False -> cal A = amat^T, cal E = M^T."""
+    from identities import dense_projected_are
+    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-3)
+    mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+    trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+    F = (-pr.A - pr.Nc).tocsr()
+    d = dict(_TIGHT, ms=pb.logshifts(1.0, 2e3, 10))
+    X = dense_projected_are(F.T, pr.M.T, pr.J, tb, trct)
+    for z0 in (None, 0.05 * lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=np.ones((pr.NV, 2)))):
+        out = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=z0,
+                                         nwtn_adi_dict=d)
+        assert _xrel(out["zfac"], X) < 1e-8
+        K = pru.get_mTzzTtb(pr.M.T, out["zfac"], tb)
+        assert np.linalg.norm(K - pr.M.T @ (X @ tb)) < 1e-8 * np.linalg.norm(K)
+
+
+def test_dense_are_pin_dre_call_transposed_z0_mtxoldb():
+    """solve_dae_ric.py:147-159: transposed=True (cal A = amat = ft_mat, cal E = mmat = M^T), z0 = Zc,
+    and mtxoldb: the Riccati equation of cal A + mtxoldb bmat^T (sign consistent with the
+    feed-forward solve of the same step, solve_dae_ric.py:181,192-194).  The implicit-Euler
+    step of the differential Riccati equation these arguments encode is solved densely."""
+    from identities import dense_projected_are, dre_step_inputs
+    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-2)
+    d = dict(_TIGHT, ms=pb.logshifts(0.4, 60.0, 8))
+    for with_old in (False, True):
+        kw, p = dre_step_inputs(pr, tau=0.05, with_old=with_old)
+        B = np.sqrt(p["tau"]) * p["tb"]
+        calA = p["ft"].toarray()
+        if with_old:
+            calA = calA + kw["mtxoldb"] @ B.T
+        X = dense_projected_are(calA, p["MT"], pr.J, B, p["wmat"])
+        out = pru.proj_alg_ric_newtonadi(nwtn_adi_dict=d, **kw)
+        assert _xrel(out["zfac"], X) < 1e-8, with_old
+        # the implicit Euler step itself, written out (no solver at all): with F = -(A+N),
+        # M^T (X_k - X_{k+1}) M / tau = F^T X_k M + M^T X_k F - M^T X_k B~ B~^T X_k M + C~^T C~
+        if not with_old:
+            from identities import leray_projector
+            P = leray_projector(pr.M, pr.J)
+            Md, Fd = pr.M.toarray(), (-pr.A - pr.Nc).toarray()
+            Z = out["zfac"]
+            Xk = Z @ Z.T
+            Xk1 = kw["z0"] @ kw["z0"].T
+            tct = p["wmat"][:, kw["z0"].shape[1]:] / np.sqrt(p["tau"])
+            lhs = Md.T @ (Xk - Xk1) @ Md / p["tau"]
+            rhs = Fd.T @ Xk @ Md + Md.T @ Xk @ Fd - Md.T @ Xk @ p["tb"] @ p["tb"].T @ Xk @ Md + tct @ tct.T
+            assert np.linalg.norm(P.T @ (lhs - rhs) @ P) < 1e-8 * np.linalg.norm(P.T @ rhs @ P)

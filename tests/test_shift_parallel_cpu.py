@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from optconpy_amd import problems as pb
-from optconpy_amd.shift_parallel import lyap_adi_shift_parallel, sweep_shifts
+from optconpy_amd.shift_parallel import item_layout, lyap_adi_shift_parallel, plan_items, sweep_shifts
 from oracle import lin_alg_utils as olau, proj_ric_utils as opru
 
 
@@ -82,6 +82,44 @@ def test_blocked_equals_sequential_fixed_steps(G):
     assert np.linalg.norm(Kb - Ks) <= 1e-11 * np.linalg.norm(Ks)
 
 
+def test_item_layout_and_plan():
+    """Work items (shift, column part) of a sweep: every item has exactly one owner and one
+    position in the rank-major gathered buffer; ranks differ by at most one item."""
+    assert plan_items(16, 1) == 1 and plan_items(16, 8) == 1       # shifts cover the ranks
+    assert plan_items(4, 8) == 2 and plan_items(1, 2) == 2         # more ranks than shifts
+    assert plan_items(16, 8, col_parts=2) == 2
+    for G, parts, world in ((16, 1, 8), (16, 2, 8), (8, 2, 3), (4, 2, 8), (5, 1, 2)):
+        items, per_rank = item_layout(G, parts, world)
+        assert len(items) == G * parts and per_rank == -(-G * parts // world)
+        assert sorted((it["g"], it["q"]) for it in items) == [(g, q) for g in range(G) for q in range(parts)]
+        pos = [it["pos"] for it in items]
+        assert len(set(pos)) == len(pos) and max(pos) < world * per_rank
+        for it in items:
+            assert it["pos"] == it["rank"] * per_rank + it["slot"] and it["slot"] < per_rank
+        load = np.bincount([it["rank"] for it in items], minlength=world)
+        assert load.max() - load.min() <= 1
+
+
+@pytest.mark.parametrize("G,parts", [(4, 2), (8, 4), (2, 1)])
+def test_column_split_equals_sequential(G, parts):
+    """Column parts of the residual factor solved as separate work items (SURVEY.md 8e,
+    "alternative axis"): same X as sequential LR-ADI."""
+    pr, F, W, tb = _problem()
+    assert W.shape[1] % parts == 0
+    ms = pb.logshifts(1.0, 500.0, 8)
+    steps = 16
+    d = dict(adi_max_steps=steps, adi_newZ_reltol=0.0, ms=ms)
+    Zs = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=W, adi_dict=d)
+    ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    blocks, info = lyap_adi_shift_parallel(ops, ms, torch.from_numpy(W.copy()), adi_max_steps=steps,
+                                           adi_newZ_reltol=0.0, width=G, col_parts=parts)
+    Zb = torch.cat(blocks, dim=1).numpy()
+    assert info["adi_steps"] == steps and info["col_parts"] == parts and Zb.shape == Zs["zfac"].shape
+    Xs = Zs["zfac"] @ Zs["zfac"].T
+    assert np.linalg.norm(Zb @ Zb.T - Xs) <= 1e-11 * np.linalg.norm(Xs)
+    assert np.isclose(info["res_fro"], Zs["res_hist"][-1], rtol=1e-8, atol=1e-18)
+
+
 def test_rejects_repeated_shift_in_sweep():
     pr, F, W, tb = _problem(4)
     ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
@@ -114,7 +152,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, width=4, col_parts=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -124,7 +162,7 @@ def _worker(rank, world, port, outdir):
         ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
         blocks, info = lyap_adi_shift_parallel(ops, ms, torch.from_numpy(W.copy()),
                                                adi_max_steps=200, adi_newZ_reltol=1e-9,
-                                               width=4)
+                                               width=width, col_parts=col_parts)
         Zb = torch.cat(blocks, dim=1).numpy()
         K = opru.get_mTzzTtb(pr.M.T, Zb, tb)
         # every rank must hold the same replicated result
@@ -133,7 +171,7 @@ def _worker(rank, world, port, outdir):
         dist.broadcast(ref, src=0)
         same = bool(torch.allclose(ref, Kt, rtol=0, atol=0))
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), K=K, steps=info["adi_steps"],
-                 solved=len(ops.lus), same=same)
+                 solved=len(ops.lus), same=same, parts=info["col_parts"])
     finally:
         dist.destroy_process_group()
 
@@ -149,6 +187,25 @@ def test_two_ranks_gloo(tmp_path):
     assert np.array_equal(r0["K"], r1["K"])
     # each rank only ever factorised its own half of the shifts
     assert int(r0["solved"]) == 4 and int(r1["solved"]) == 4
+    pr, F, W, tb = _problem()
+    ms = pb.logshifts(1.0, 500.0, 8)
+    d = dict(adi_max_steps=200, adi_newZ_reltol=1e-9, ms=ms)
+    Zs = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=W, adi_dict=d)["zfac"]
+    Ks = opru.get_mTzzTtb(pr.M.T, Zs, tb)
+    assert np.linalg.norm(r0["K"] - Ks) <= 1e-6 * np.linalg.norm(Ks)
+
+
+@pytest.mark.parametrize("width,col_parts", [(4, 2), (1, 0)])
+def test_two_ranks_gloo_column_split(tmp_path, width, col_parts):
+    """world_size 2 with column parts: (4 shifts x 2 parts per sweep, 4 items per rank) and
+    (1 shift per sweep -> automatically 2 parts, so that the second rank has work).  All-gather
+    into the rank-major buffer, recombination with permuted coefficients; K as the oracle's."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), width, col_parts), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert bool(r0["same"]) and bool(r1["same"]) and np.array_equal(r0["K"], r1["K"])
+    assert int(r0["parts"]) == 2
     pr, F, W, tb = _problem()
     ms = pb.logshifts(1.0, 500.0, 8)
     d = dict(adi_max_steps=200, adi_newZ_reltol=1e-9, ms=ms)
