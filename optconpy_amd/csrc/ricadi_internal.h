@@ -284,6 +284,9 @@ void launch_tsqr_local(hipStream_t st, int nrows, int w, const double* A, int ld
                        double* Rstack);
 void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, const double* G,
                        double* Qout, int ldq);
+void launch_cholqr_small(hipStream_t st, int w, const double* G, const double* Rprev, double* T,
+                         double* R, int* flag);
+void launch_select_evecs(hipStream_t st, int c, int k, const double* evec, double* sel);
 void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);

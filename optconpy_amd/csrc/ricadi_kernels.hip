@@ -1927,6 +1927,121 @@ void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, con
                      Qloc, G, Qout, ldq);
 }
 
+// ---------------------------------------------------------------------------
+// K5, fast panel factorisation: Cholesky QR on the matrix cores.
+//
+// For a tall n x w panel P (w <= 32) whose column-normalised Gram matrix is safely
+// positive definite, two rounds of
+//     G = P^T P (MFMA),  Ghat = D G D = L L^T  (D = diag(G)^-1/2),  Q = P (D L^-T) (MFMA)
+// give Householder-quality orthogonality (CholQR2) at GEMM speed: the 32 x 32 part below is
+// this one-wave kernel, everything tall is gemm_tn / gemm_nn.  The kernel raises `flag` --
+// the caller then falls back to the Householder TSQR tree -- when a normalised pivot drops
+// below 1e-12 (cond(P D) beyond ~1e6: the second round could not repair the first) or a
+// column is exactly zero; it never produces Inf / NaN (a failed pivot is replaced by 1, the
+// column's transformation by 0).
+//   in : G (32 x 32, ld 32; only the leading w x w block is meaningful), Rprev (or NULL)
+//   out: T (32 x 32): Q = P T;   R (32 x 32 upper): P = Q R for the first round, and
+//        R = R_this * Rprev for the second (Rprev = first round's R)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cholqr_small_kernel(int w, const double* __restrict__ G,
+                                                          const double* __restrict__ Rprev,
+                                                          double* __restrict__ T, double* __restrict__ R,
+                                                          int* __restrict__ flag) {
+  __shared__ double A[32][33];      // Ghat, then L (lower)
+  __shared__ double X[32][33];      // U^-1, U = L^T
+  __shared__ double dsc[32], dinv[32];
+  const int lane = threadIdx.x;
+  bool bad = false;
+  if (lane < 32) {
+    const double gjj = lane < w ? G[lane * 32 + lane] : 1.0;
+    if (lane < w && !(gjj > 0.0)) bad = true;
+    dsc[lane] = (lane < w && gjj > 0.0) ? 1.0 / sqrt(gjj) : 0.0;
+    dinv[lane] = (lane < w && gjj > 0.0) ? sqrt(gjj) : 0.0;
+  }
+  __syncthreads();
+  for (int e = lane; e < 1024; e += 64) {
+    const int i = e >> 5, j = e & 31;
+    double v;
+    if (i < w && j < w && dsc[i] > 0.0 && dsc[j] > 0.0)
+      v = dsc[i] * dsc[j] * G[i * 32 + j];
+    else
+      v = (i == j) ? 1.0 : 0.0;      // identity padding (columns beyond w, zero columns)
+    A[i][j] = v;
+    X[i][j] = 0.0;
+  }
+  __syncthreads();
+  // right-looking Cholesky, one wave
+  for (int k = 0; k < 32; ++k) {
+    double piv = A[k][k];
+    if (!(piv > 1e-12)) {
+      bad = true;
+      piv = 1.0;
+    }
+    const double lkk = sqrt(piv);
+    __syncthreads();
+    if (lane == k) A[k][k] = lkk;
+    if (lane > k && lane < 32) A[lane][k] /= lkk;
+    __syncthreads();
+    for (int e = lane; e < 1024; e += 64) {
+      const int i = e >> 5, j = e & 31;
+      if (j > k && i >= j) A[i][j] -= A[i][k] * A[j][k];
+    }
+    __syncthreads();
+  }
+  // X = U^-1 with U = L^T (upper): column j by back substitution, one lane per column
+  if (lane < 32) {
+    const int j = lane;
+    X[j][j] = 1.0 / A[j][j];
+    for (int i = j - 1; i >= 0; --i) {
+      double sacc = 0.0;
+      for (int t = i + 1; t <= j; ++t) sacc = fma(A[t][i], X[t][j], sacc);   // U[i][t] = L[t][i]
+      X[i][j] = -sacc / A[i][i];
+    }
+  }
+  __syncthreads();
+  // T = D X (zero for failed / padded columns), Rcur = U D^-1
+  for (int e = lane; e < 1024; e += 64) {
+    const int i = e >> 5, j = e & 31;
+    const bool okc = j < w && dsc[j] > 0.0;
+    T[e] = (okc && i <= j) ? dsc[i] * X[i][j] : 0.0;
+    X[i][j] = (i <= j && i < w && okc) ? A[j][i] * dinv[j] : 0.0;   // X now holds Rcur
+  }
+  __syncthreads();
+  for (int e = lane; e < 1024; e += 64) {
+    const int i = e >> 5, j = e & 31;
+    double v;
+    if (Rprev) {
+      v = 0.0;
+      for (int t = i; t <= j; ++t) v = fma(X[i][t], Rprev[t * 32 + j], v);
+    } else {
+      v = X[i][j];
+    }
+    R[e] = (i <= j) ? v : 0.0;
+  }
+  if (__any(bad) && lane == 0) atomicExch(flag, 1);
+}
+void launch_cholqr_small(hipStream_t st, int w, const double* G, const double* Rprev, double* T,
+                         double* R, int* flag) {
+  hipLaunchKernelGGL(cholqr_small_kernel, dim3(1), dim3(64), 0, st, w, G, Rprev, T, R, flag);
+}
+
+// sel[i, jj] = evec[(c - 1 - jj), i]   (c x k, row-major): the k eigenvectors of the largest
+// eigenvalues, as columns, from the row-major view of a column-major eigenvector matrix with
+// ascending eigenvalues (row j of the view = eigenvector j).
+__global__ void select_evecs_kernel(int c, int k, const double* __restrict__ evec, double* __restrict__ sel) {
+  const size_t n = (size_t)c * k;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / k), jj = (int)(e % k);
+    sel[e] = evec[(size_t)(c - 1 - jj) * c + i];
+  }
+}
+void launch_select_evecs(hipStream_t st, int c, int k, const double* evec, double* sel) {
+  const size_t n = (size_t)c * k;
+  if (!n) return;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(select_evecs_kernel, dim3(grid), dim3(256), 0, st, c, k, evec, sel);
+}
+
 // out[j, i] = sgn(j) * in[i, j]  for a k x k matrix; sgn(j) = +1 for j < k1, sneg otherwise
 __global__ void transpose_sign_kernel(int k, int k1, double sneg, const double* __restrict__ in,
                                       double* __restrict__ out) {

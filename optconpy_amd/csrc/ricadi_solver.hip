@@ -6,7 +6,9 @@
 // reference call site behind each entry point.
 #include <rocsolver/rocsolver.h>
 
+#include <chrono>
 #include <cmath>
+#include <future>
 #include <numeric>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +69,91 @@ struct DArr {
   }
 };
 
+// Device scratch of a context: buffers handed out by take() come back with give() and are
+// kept for the next request instead of going through hipMalloc / hipFree (a hipFree drains
+// the device; the recompression, the block QR and the TSQR tree allocate dozens of
+// temporaries per Newton step).  Everything a pool serves runs on ONE stream, so a buffer
+// may be reused as soon as the host has released it: the kernels are ordered.
+struct DevPool {
+  struct Buf {
+    void* p;
+    size_t bytes;
+  };
+  std::vector<Buf> free_;
+  size_t held = 0;
+  ~DevPool() { trim(); }
+  void trim() {
+    for (Buf& b : free_) (void)hipFree(b.p);
+    free_.clear();
+    held = 0;
+  }
+  Buf take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)free_.size(); ++i)
+      if (free_[i].bytes >= bytes && free_[i].bytes <= 2 * bytes + 4096 &&
+          (best < 0 || free_[i].bytes < free_[best].bytes))
+        best = i;
+    if (best >= 0) {
+      Buf b = free_[best];
+      free_.erase(free_.begin() + best);
+      held -= b.bytes;
+      return b;
+    }
+    Buf b{nullptr, bytes};
+    if (hipMalloc(&b.p, bytes) != hipSuccess) {
+      trim();                                   // give cached buffers back and retry once
+      HIPCHK(hipMalloc(&b.p, bytes));
+    }
+    return b;
+  }
+  void give(Buf b) {
+    if (!b.p) return;
+    free_.push_back(b);
+    held += b.bytes;
+  }
+};
+
+// Temporary device array from a pool (scope bound, like DArr).
+template <class T>
+struct TArr {
+  DevPool* pool = nullptr;
+  DevPool::Buf b{nullptr, 0};
+  T* p = nullptr;
+  size_t n = 0;
+  TArr() = default;
+  explicit TArr(DevPool& pl) : pool(&pl) {}
+  TArr(DevPool& pl, size_t count) : pool(&pl) { alloc(count); }
+  TArr(const TArr&) = delete;
+  TArr& operator=(const TArr&) = delete;
+  TArr(TArr&& o) noexcept : pool(o.pool), b(o.b), p(o.p), n(o.n) {
+    o.b = DevPool::Buf{nullptr, 0};
+    o.p = nullptr;
+    o.n = 0;
+  }
+  ~TArr() { release(); }
+  void release() {
+    if (pool && b.p) pool->give(b);
+    b = DevPool::Buf{nullptr, 0};
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count) {
+      b = pool->take(count * sizeof(T));
+      p = static_cast<T*>(b.p);
+    }
+    n = count;
+  }
+  void swap(TArr& o) {
+    std::swap(pool, o.pool);
+    std::swap(b, o.b);
+    std::swap(p, o.p);
+    std::swap(n, o.n);
+  }
+};
+
 // Restores a value when the scope is left, also by an exception (a throw between a
 // temporary change of the context's state and its restoration must not leak the change).
 template <class T>
@@ -77,6 +164,16 @@ struct Restore {
   ~Restore() { ref = saved; }
   Restore(const Restore&) = delete;
   Restore& operator=(const Restore&) = delete;
+};
+
+struct Tick {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double lap() {
+    const auto t1 = std::chrono::steady_clock::now();
+    const double s = std::chrono::duration<double>(t1 - t0).count();
+    t0 = t1;
+    return s;
+  }
 };
 
 struct ShiftData {
@@ -103,6 +200,17 @@ struct DevCsr {
     ci.upload(h.ci, st);
     v.upload(h.v, st);
   }
+};
+
+// Where a dense stage runs: stream, rocBLAS / rocSOLVER handle bound to it, scratch pool and
+// info word.  The context has two: its main one and an auxiliary one on a second stream, on
+// which the in-ADI recompressions run concurrently with the next sweeps (a helper thread
+// issues them: rocSOLVER's eigensolver is thousands of tiny launches, bound by the host).
+struct Exec {
+  hipStream_t st = nullptr;
+  rocblas_handle rb = nullptr;
+  DevPool* pool = nullptr;
+  int* info = nullptr;
 };
 
 }  // namespace ricadi
@@ -168,14 +276,29 @@ struct ricadi_ctx {
   // factor
   DArr<double> Z;
   int zc = 0, zld = 0;
+  // scratch of the dense stages (recompression, block QR, gain): see DevPool
+  DevPool pool;
+  // auxiliary execution resources for the asynchronous recompression (created on first use)
+  hipStream_t st2 = nullptr;
+  rocblas_handle rb2 = nullptr;
+  DevPool pool2;
+  DArr<int> info2;
+  hipEvent_t ev_z = nullptr;
   // stats
   long total_iters = 0, total_solves = 0;
+  // wall-clock split of the drivers (RICADI_TIMING=1 prints it per Newton step; the stream is
+  // drained at the section ends only in that mode)
+  bool timing = false;
+  double t_setup = 0, t_solve = 0, t_recomb = 0, t_compress = 0, t_updnorm = 0, t_proj = 0, t_gain = 0;
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
     for (int i = 0; i < 2; ++i)
       if (ev_res[i]) (void)hipEventDestroy(ev_res[i]);
     if (rb) rocblas_destroy_handle(rb);
+    if (rb2) rocblas_destroy_handle(rb2);
+    if (ev_z) (void)hipEventDestroy(ev_z);
+    if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
 };
@@ -994,6 +1117,25 @@ static void load_rhs(ricadi_ctx* c, const double* dR, int m, double* b) {
     HIPCHK(hipMemsetAsync(b + (size_t)c->nv * m, 0, sizeof(double) * (size_t)c->np * m, c->st));
 }
 
+// Per-shift data of the ADI shifts an iteration is about to use -- and of the projection
+// operator (alpha, beta) = (1, 0) when `with_projection` -- built in ONE setup pass: the
+// coarse matrices of all of them go through the same batched factorisation (a matrix set
+// up alone costs ~8x its share of a batch of 16).
+static void prefetch_setup(ricadi_ctx* c, const double* shifts, int nuse, bool with_projection) {
+  std::vector<double> al, be;
+  if (with_projection && c->np > 0) {
+    al.push_back(1.0);
+    be.push_back(0.0);
+  }
+  for (int i = 0; i < nuse; ++i) {
+    al.push_back(shifts[i]);
+    be.push_back(1.0);
+  }
+  if (al.empty()) return;
+  std::vector<ShiftData*> sds(al.size());
+  get_shifts(c, al.data(), be.data(), (int)al.size(), sds.data());
+}
+
 // W (NV x m, device, in place) <- P^T W  through one saddle solve with cal E
 static void project_panel(ricadi_ctx* c, double* dW, int m) {
   if (c->np == 0) return;
@@ -1041,13 +1183,79 @@ static const double kInternalRelThresh = 3e-8;
 // Recompress the device factor in place (columns [0, zc) of c->Z).
 static void factor_recompress(ricadi_ctx* c) {
   if (c->zc == 0) return;
-  DArr<double> tmp;
-  tmp.alloc((size_t)c->nv * c->zc);
+  TArr<double> tmp(c->pool, (size_t)c->nv * c->zc);
   const int k = compress_dev(c, c->Z.p, c->zc, c->zld, kInternalRelThresh, 0, true, tmp.p, nullptr);
   if (k > 0) launch_copy_cols(c->st, c->nv, k, tmp.p, k, 0, c->Z.p, c->zld, 0, 1.0);
   HIPCHK(hipStreamSynchronize(c->st));
   c->zc = k;
 }
+
+static int compress_gram_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz,
+                              double thresh, int kmax, bool thresh_relative, double* dOut,
+                              std::vector<double>* sv_host);
+
+// Auxiliary stream + handle for work that runs beside the main stream (created on first use).
+static Exec aux_exec(ricadi_ctx* c) {
+  if (!c->st2) {
+    HIPCHK(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    RBCHK(rocblas_create_handle(&c->rb2));
+    RBCHK(rocblas_set_stream(c->rb2, c->st2));
+    c->info2.alloc(4);
+    HIPCHK(hipEventCreateWithFlags(&c->ev_z, hipEventDisableTiming));
+  }
+  Exec ex;
+  ex.st = c->st2;
+  ex.rb = c->rb2;
+  ex.pool = &c->pool2;
+  ex.info = c->info2.p;
+  return ex;
+}
+
+// In-ADI recompression that does not stall the sweeps: the columns [0, snap) of the factor are
+// compressed on the auxiliary stream by a helper thread (same arithmetic as
+// factor_recompress) while the main stream goes on appending columns behind them; finish()
+// splices the result in:  Z <- [compressed prefix | columns appended meanwhile].
+// Member order matters: `fut` is destroyed first and waits for the helper, then `out`.
+struct AsyncRecompress {
+  ricadi_ctx* c;
+  TArr<double> out;
+  int snap = 0;
+  bool active = false;
+  std::future<int> fut;
+  explicit AsyncRecompress(ricadi_ctx* ctx) : c(ctx), out(ctx->pool) {}
+  void start() {
+    if (active || c->zc == 0) return;
+    const Exec ex = aux_exec(c);
+    snap = c->zc;
+    out.alloc((size_t)c->nv * snap);
+    HIPCHK(hipEventRecord(c->ev_z, c->st));            // the prefix is complete on the main stream
+    HIPCHK(hipStreamWaitEvent(c->st2, c->ev_z, 0));
+    ricadi_ctx* cc = c;
+    const double* Zp = c->Z.p;
+    const int ld = c->zld, sn = snap, dev = c->dev;
+    double* op = out.p;
+    fut = std::async(std::launch::async, [cc, ex, Zp, ld, sn, dev, op]() {
+      (void)hipSetDevice(dev);
+      return compress_gram_exec(cc, ex, Zp, sn, ld, kInternalRelThresh, 0, true, op, nullptr);
+    });
+    active = true;
+  }
+  void finish() {
+    if (!active) return;
+    active = false;
+    const int k = fut.get();                            // the auxiliary stream is drained in there
+    hipStream_t st = c->st;
+    const int nv = c->nv, tail = c->zc - snap;
+    if (tail > 0) {
+      TArr<double> tmp(c->pool, (size_t)nv * tail);
+      launch_copy_cols(st, nv, tail, c->Z.p, c->zld, snap, tmp.p, tail, 0, 1.0);
+      launch_copy_cols(st, nv, tail, tmp.p, tail, 0, c->Z.p, c->zld, k, 1.0);
+    }
+    if (k > 0) launch_copy_cols(st, nv, k, out.p, k, 0, c->Z.p, c->zld, 0, 1.0);
+    c->zc = k + tail;
+    out.release();
+  }
+};
 
 // ---- low-rank ADI (device resident) -------------------------------------------------
 struct AdiStats {
@@ -1094,7 +1302,17 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   const int n = c->n, nv = c->nv;
   const size_t nm = (size_t)n * m;
   ensure_work(c, m, G);
+  Tick tk;
+  auto lap = [&](double& acc) {
+    if (c->timing) {
+      (void)hipStreamSynchronize(st);
+      acc += tk.lap();
+    }
+  };
+  prefetch_setup(c, shifts, std::min(ns, prm.adi_max_steps), prm.project_w != 0);
+  lap(c->t_setup);
   if (prm.project_w) project_panel(c, dW, m);
+  lap(c->t_proj);
   const long it0 = c->total_iters;
   c->sweep_u.ensure(nm * G);
   c->sweep_t.ensure((size_t)nv * m);
@@ -1104,14 +1322,18 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   std::vector<double> be(G, 1.0), coef((size_t)(G + 1) * G * m);
   std::vector<ShiftData*> sds(G);
   std::vector<GmresResult> res(G);
+  static const bool sync_recompress = getenv("RICADI_SYNC_RECOMPRESS") != nullptr;
+  AsyncRecompress job(c);
   int steps = 0;
   for (int sw = 0; steps + G <= prm.adi_max_steps; ++sw) {
     const std::vector<double>& ps = pss[sw % ncyc];
     const std::vector<double>& rinv = rinvs[sw % ncyc];
     const std::vector<double>& cinv1 = cinvs[sw % ncyc];
     get_shifts(c, ps.data(), be.data(), G, sds.data());
+    lap(c->t_setup);
     load_rhs(c, dW, m, c->bvec.p);
     solve_batch(c, sds.data(), G, c->bvec.p, 0, c->sweep_u.p, m, true, nullptr, res.data());
+    lap(c->t_solve);
     for (int g = 0; g < G; ++g)
       if (!res[g].converged) {
         stt.nonconverged++;
@@ -1147,6 +1369,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     steps += G;
     stt.steps = steps;
     stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / G / znorm2) : 0.0;
+    lap(c->t_recomb);
     if (prm.verbose) {
       int its = 0;
       for (int g = 0; g < G; ++g) its = std::max(its, res[g].iters);
@@ -1155,10 +1378,19 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     }
     if (stt.rel < prm.adi_newZ_reltol) break;
     if (prm.compress_cols > 0 && c->zc - zc_last >= prm.compress_cols) {
-      factor_recompress(c);
+      if (sync_recompress) {
+        factor_recompress(c);
+      } else {
+        // splice in what the helper finished during the last sweeps, hand it the next prefix
+        job.finish();
+        job.start();
+      }
       zc_last = c->zc;
+      lap(c->t_compress);
     }
   }
+  job.finish();
+  lap(c->t_compress);
   stt.gmres_iters = c->total_iters - it0;
   DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
   return true;
@@ -1171,21 +1403,13 @@ static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double
   stt = AdiStats();
   hipStream_t st = c->st;
   ensure_work(c, m);
+  // per-shift data of the whole shift cycle (and of the projection) up front: the coarse
+  // inverses then come out of one batched factorisation instead of one at a time
+  prefetch_setup(c, shifts, std::min(ns, prm.adi_max_steps), prm.project_w != 0);
   if (prm.project_w) project_panel(c, dW, m);
   const long it0 = c->total_iters;
   double znorm2 = 0.0;
   int zc_last = c->zc;
-  {
-    // per-shift data of the whole shift cycle up front: the coarse inverses then come
-    // out of batched factorisations (16 shifts each) instead of one at a time
-    const int nuse = std::min(ns, prm.adi_max_steps);
-    std::vector<double> al(shifts, shifts + nuse), be(nuse, 1.0);
-    std::vector<ShiftData*> sds(nuse);
-    for (int s0 = 0; s0 < nuse; s0 += RICADI_MAX_GROUPS) {
-      const int cnt = std::min(RICADI_MAX_GROUPS, nuse - s0);
-      get_shifts(c, al.data() + s0, be.data() + s0, cnt, sds.data() + s0);
-    }
-  }
   for (int step = 1; step <= prm.adi_max_steps; ++step) {
     const double p = shifts[(step - 1) % ns];
     ShiftData* sd = get_shift(c, p, 1.0);
@@ -1237,6 +1461,53 @@ static void factor_reserve(ricadi_ctx* c, int ld) {
 // ---- compression: Gram matrix on the matrix cores, eigendecomposition, Z * V_k -----
 // dZ: NV x cz (ld = ldz).  Returns k and writes Zc (NV x k, ld = k) into dOut
 // (which must hold NV*cz doubles).  Singular values (descending) to sv_host.
+static Exec main_exec(ricadi_ctx* c) {
+  Exec ex;
+  ex.st = c->st;
+  ex.rb = c->rb;
+  ex.pool = &c->pool;
+  ex.info = c->info.p;
+  return ex;
+}
+
+// Gram route of the compression on the given execution resources:  G = Z^T Z on the FP64
+// matrix cores, symmetric eigendecomposition (rocSOLVER), Zc = Z V_k.  Returns k; dOut is
+// NV x k (ld = k).  Synchronises ex.st before it returns.
+static int compress_gram_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz,
+                              double thresh, int kmax, bool thresh_relative, double* dOut,
+                              std::vector<double>* sv_host) {
+  hipStream_t st = ex.st;
+  if (cz == 0) return 0;
+  TArr<double> G(*ex.pool, (size_t)cz * cz), ev(*ex.pool, cz), work(*ex.pool, cz), sel(*ex.pool);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
+  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
+  RBCHK(rocsolver_dsyevd(ex.rb, rocblas_evect_original, rocblas_fill_upper, cz, G.p, cz, ev.p,
+                         work.p, ex.info));
+  std::vector<double> lam(cz);
+  HIPCHK(hipMemcpyAsync(lam.data(), ev.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // eigenvalues ascending; singular values descending
+  std::vector<double> sv(cz);
+  for (int i = 0; i < cz; ++i) sv[i] = std::sqrt(std::max(lam[cz - 1 - i], 0.0));
+  int k = std::min(cz, c->nv);
+  if (thresh >= 0.0) {
+    const double t = thresh_relative ? thresh * sv[0] : thresh;
+    int cnt = 0;
+    while (cnt < cz && sv[cnt] > t) ++cnt;
+    k = std::min(k, cnt);
+  }
+  if (kmax > 0) k = std::min(k, kmax);
+  if (sv_host) *sv_host = sv;
+  if (k == 0) return 0;
+  // row-major view of syevd's output: row j = eigenvector j (ascending); the cz x k
+  // selection of the k largest is formed on the device
+  sel.alloc((size_t)cz * k);
+  launch_select_evecs(st, cz, k, G.p, sel.p);
+  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
+  HIPCHK(hipStreamSynchronize(st));
+  return k;
+}
+
 static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
                         bool thresh_relative, double* dOut, std::vector<double>* sv_host,
                         bool use_qr) {
@@ -1245,12 +1516,8 @@ static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double
   if (use_qr && cz <= c->nv) {
     // Z = Q R (TSQR panels), R^T = U' S V'^T (rocSOLVER, column-major view of the
     // row-major R), right singular vectors of R = U'; Zc = Z V_k.
-    DArr<double> Q, R, S, U, E5;
-    Q.alloc((size_t)c->nv * cz);
-    R.alloc((size_t)cz * cz);
-    S.alloc(cz);
-    U.alloc((size_t)cz * cz);
-    E5.alloc(cz);
+    TArr<double> Q(c->pool, (size_t)c->nv * cz), R(c->pool, (size_t)cz * cz), S(c->pool, cz),
+        U(c->pool, (size_t)cz * cz), E5(c->pool, cz);
     block_qr_dev(c, dZ, ldz, c->nv, cz, Q.p, R.p);
     RBCHK(rocsolver_dgesvd(c->rb, rocblas_svect_all, rocblas_svect_none, cz, cz, R.p, cz, S.p, U.p, cz,
                            nullptr, 1, E5.p, rocblas_outofplace, c->info.p));
@@ -1272,51 +1539,13 @@ static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double
     std::vector<double> Ch((size_t)cz * k);
     for (int jj = 0; jj < k; ++jj)
       for (int i = 0; i < cz; ++i) Ch[(size_t)i * k + jj] = Uh[(size_t)jj * cz + i];
-    DArr<double> sel;
-    sel.alloc((size_t)cz * k);
+    TArr<double> sel(c->pool, (size_t)cz * k);
     HIPCHK(hipMemcpyAsync(sel.p, Ch.data(), sizeof(double) * cz * k, hipMemcpyHostToDevice, st));
     launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
     HIPCHK(hipStreamSynchronize(st));
     return k;
   }
-  DArr<double> G, ev, work, sel;
-  G.alloc((size_t)cz * cz);
-  ev.alloc(cz);
-  work.alloc(cz);
-  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
-  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
-  RBCHK(rocsolver_dsyevd(c->rb, rocblas_evect_original, rocblas_fill_upper, cz, G.p, cz, ev.p,
-                         work.p, c->info.p));
-  std::vector<double> lam(cz);
-  HIPCHK(hipMemcpyAsync(lam.data(), ev.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  // eigenvalues ascending; singular values descending
-  std::vector<double> sv(cz);
-  for (int i = 0; i < cz; ++i) sv[i] = std::sqrt(std::max(lam[cz - 1 - i], 0.0));
-  int k = std::min(cz, c->nv);
-  if (thresh >= 0.0) {
-    const double t = thresh_relative ? thresh * sv[0] : thresh;
-    int cnt = 0;
-    while (cnt < cz && sv[cnt] > t) ++cnt;
-    k = std::min(k, cnt);
-  }
-  if (kmax > 0) k = std::min(k, kmax);
-  if (sv_host) *sv_host = sv;
-  if (k == 0) return 0;
-  // row-major view of syevd output: row j = eigenvector j (ascending).  Build the
-  // cz x k selection  C[i][jj] = evec_{cz-1-jj}[i]  on the host (small).
-  std::vector<double> Gh((size_t)cz * cz), Ch((size_t)cz * k);
-  HIPCHK(hipMemcpyAsync(Gh.data(), G.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  for (int jj = 0; jj < k; ++jj) {
-    const double* e = Gh.data() + (size_t)(cz - 1 - jj) * cz;
-    for (int i = 0; i < cz; ++i) Ch[(size_t)i * k + jj] = e[i];
-  }
-  sel.alloc((size_t)cz * k);
-  HIPCHK(hipMemcpyAsync(sel.p, Ch.data(), sizeof(double) * cz * k, hipMemcpyHostToDevice, st));
-  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
-  HIPCHK(hipStreamSynchronize(st));
-  return k;
+  return compress_gram_exec(c, main_exec(c), dZ, cz, ldz, thresh, kmax, thresh_relative, dOut, sv_host);
 }
 
 // ---- K5: Householder TSQR tree and block QR ----------------------------------------
@@ -1329,10 +1558,13 @@ static void tsqr_dev(ricadi_ctx* c, const double* P, int ldp, int n, int w, doub
   rows.push_back(n);
   while (tsqr_num_blocks(rows.back()) > 1) rows.push_back(tsqr_num_blocks(rows.back()) * 32);
   const int L = (int)rows.size();
-  std::vector<DArr<double>> qloc(L), rst(L), qfin(L);
+  std::vector<TArr<double>> qloc, rst, qfin;
   for (int l = 0; l < L; ++l) {
-    qloc[l].alloc((size_t)rows[l] * 32);
-    rst[l].alloc((size_t)tsqr_num_blocks(rows[l]) * 32 * 32);
+    qloc.emplace_back(c->pool, (size_t)rows[l] * 32);
+    rst.emplace_back(c->pool, (size_t)tsqr_num_blocks(rows[l]) * 32 * 32);
+    qfin.emplace_back(c->pool);
+  }
+  for (int l = 0; l < L; ++l) {
     launch_tsqr_local(st, rows[l], w, l == 0 ? P : rst[l - 1].p, l == 0 ? ldp : 32, qloc[l].p,
                       rst[l].p);
   }
@@ -1359,38 +1591,73 @@ static void tsqr_dev(ricadi_ctx* c, const double* P, int ldp, int n, int w, doub
     }
     // tsqr_apply writes all 32 columns; columns >= w of Q are exact zeros
   }
-  HIPCHK(hipStreamSynchronize(st));
+  // no synchronisation: the temporaries go back to the context's pool and are reused in
+  // stream order
+}
+
+// One panel by Cholesky QR, twice (CholQR2): Gram matrices and Q = P T on the MFMA GEMMs,
+// the 32 x 32 Cholesky / triangular inverse in cholqr_small_kernel.  Raises c->flag[1] when
+// the panel is too ill-conditioned for it (the caller then redoes the factorisation with the
+// Householder TSQR tree).
+static void panel_cholqr2(ricadi_ctx* c, const double* P, int n, int w, double* Q, int ldq, double* R,
+                          int ldr) {
+  hipStream_t st = c->st;
+  TArr<double> G(c->pool, 1024), T1(c->pool, 1024), R1(c->pool, 1024), T2(c->pool, 1024),
+      R2(c->pool, 1024), Q1(c->pool, (size_t)n * 32);
+  int* flag = c->flag.p + 1;
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * 1024, st));
+  launch_gemm_tn(st, n, 32, 32, P, 32, P, 32, G.p, 32);
+  launch_cholqr_small(st, w, G.p, nullptr, T1.p, R1.p, flag);
+  launch_gemm_nn(st, n, 32, 32, P, 32, T1.p, 32, Q1.p, 32, 1.0, 0.0);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * 1024, st));
+  launch_gemm_tn(st, n, 32, 32, Q1.p, 32, Q1.p, 32, G.p, 32);
+  launch_cholqr_small(st, w, G.p, R1.p, T2.p, R2.p, flag);
+  launch_gemm_nn(st, n, 32, w, Q1.p, 32, T2.p, 32, Q, ldq, 1.0, 0.0);
+  launch_copy_cols(st, w, w, R2.p, 32, 0, R, ldr, 0, 1.0);
 }
 
 // D = Q R for a tall n x kk matrix (ldd): block classical Gram-Schmidt with
 // re-orthogonalisation between 32-column panels (both passes on the FP64 MFMA
-// GEMMs), Householder TSQR inside a panel.  Q: n x kk (ld kk), R: kk x kk
-// row-major upper triangular.  Q may be NULL-free scratch of the caller.
+// GEMMs).  Inside a panel: CholQR2 on the matrix cores (panel_cholqr2) when the panel
+// allows it -- checked once, after the last panel -- else the whole factorisation is
+// redone with the Householder TSQR tree (numerically rank-deficient panels, e.g. raw
+// ADI blocks; RICADI_TSQR_HOUSEHOLDER=1 forces it).  Q: n x kk (ld kk), R: kk x kk
+// row-major upper triangular.
 static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
                          double* R) {
   hipStream_t st = c->st;
-  DArr<double> P, C1, C2;
-  P.alloc((size_t)n * 32);
-  C1.alloc((size_t)kk * 32);
-  C2.alloc((size_t)kk * 32);
-  HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * kk * kk, st));
-  for (int c0 = 0; c0 < kk; c0 += 32) {
-    const int w = std::min(32, kk - c0);
-    HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));
-    launch_copy_cols(st, n, w, D, ldd, c0, P.p, 32, 0, 1.0);
-    if (c0 > 0) {
-      for (int pass = 0; pass < 2; ++pass) {
-        double* C = pass == 0 ? C1.p : C2.p;
-        HIPCHK(hipMemsetAsync(C, 0, sizeof(double) * c0 * w, st));
-        launch_gemm_tn(st, n, c0, w, Q, kk, P.p, 32, C, w);
-        launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, 32, -1.0, 1.0);
+  static const bool hh_only = getenv("RICADI_TSQR_HOUSEHOLDER") != nullptr;
+  TArr<double> P(c->pool, (size_t)n * 32), C1(c->pool, (size_t)kk * 32), C2(c->pool, (size_t)kk * 32);
+  for (int attempt = hh_only ? 1 : 0; attempt < 2; ++attempt) {
+    const bool fast = attempt == 0;
+    if (fast) HIPCHK(hipMemsetAsync(c->flag.p + 1, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * kk * kk, st));
+    for (int c0 = 0; c0 < kk; c0 += 32) {
+      const int w = std::min(32, kk - c0);
+      HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));
+      launch_copy_cols(st, n, w, D, ldd, c0, P.p, 32, 0, 1.0);
+      if (c0 > 0) {
+        for (int pass = 0; pass < 2; ++pass) {
+          double* C = pass == 0 ? C1.p : C2.p;
+          HIPCHK(hipMemsetAsync(C, 0, sizeof(double) * c0 * w, st));
+          launch_gemm_tn(st, n, c0, w, Q, kk, P.p, 32, C, w);
+          launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, 32, -1.0, 1.0);
+        }
+        launch_axpby(st, (size_t)c0 * w, 1.0, C2.p, 1.0, C1.p);
+        launch_copy_cols(st, c0, w, C1.p, w, 0, R, kk, c0, 1.0);
       }
-      launch_axpby(st, (size_t)c0 * w, 1.0, C2.p, 1.0, C1.p);
-      launch_copy_cols(st, c0, w, C1.p, w, 0, R, kk, c0, 1.0);
+      if (fast)
+        panel_cholqr2(c, P.p, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
+      else
+        tsqr_dev(c, P.p, 32, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
     }
-    tsqr_dev(c, P.p, 32, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
+    if (!fast) break;
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->flag.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!flag) break;
+    if (c->opts.verbose) fprintf(stderr, "[ricadi] block QR: ill-conditioned panel, Householder TSQR instead\n");
   }
-  HIPCHK(hipStreamSynchronize(st));
 }
 
 // || Z1 Z1^T - Z0 Z0^T ||_F  via an LQ factorisation of [Z1, Z0]^T (Householder,
@@ -1402,13 +1669,8 @@ static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const dou
   // is that of the small matrix R S R^T -- updates far below 1e-8 are resolved.
   hipStream_t st = c->st;
   const int kk = k1 + k0, nv = c->nv;
-  DArr<double> D, Q, R, Rt, Rts, T;
-  D.alloc((size_t)nv * kk);
-  Q.alloc((size_t)nv * kk);
-  R.alloc((size_t)kk * kk);
-  Rt.alloc((size_t)kk * kk);
-  Rts.alloc((size_t)kk * kk);
-  T.alloc((size_t)kk * kk);
+  TArr<double> D(c->pool, (size_t)nv * kk), Q(c->pool, (size_t)nv * kk), R(c->pool, (size_t)kk * kk),
+      Rt(c->pool, (size_t)kk * kk), Rts(c->pool, (size_t)kk * kk), T(c->pool, (size_t)kk * kk);
   launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
   if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
   block_qr_dev(c, D.p, kk, nv, kk, Q.p, R.p);
@@ -1433,9 +1695,7 @@ static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const dou
 static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, int ldz,
                      const double* dB, int nb, double* dK) {
   hipStream_t st = c->st;
-  DArr<double> ZtB, T;
-  ZtB.alloc((size_t)std::max(cz, 1) * nb);
-  T.alloc((size_t)c->nv * nb);
+  TArr<double> ZtB(c->pool, (size_t)std::max(cz, 1) * nb), T(c->pool, (size_t)c->nv * nb);
   HIPCHK(hipMemsetAsync(ZtB.p, 0, sizeof(double) * std::max(cz, 1) * nb, st));
   launch_gemm_tn(st, c->nv, cz, nb, dZ, ldz, dB, nb, ZtB.p, nb);
   launch_gemm_nn(st, c->nv, cz, nb, dZ, ldz, ZtB.p, nb, T.p, nb, 1.0, 0.0);
@@ -1524,6 +1784,7 @@ int ricadi_create(int device_id, ricadi_ctx** out) {
   c->dev = device_id;
   ricadi_default_opts(&c->opts);
   c->precond32 = getenv("RICADI_PRECOND64") == nullptr;
+  c->timing = getenv("RICADI_TIMING") != nullptr;
   if (const char* e = getenv("RICADI_SMW")) c->smw = e[0] != '0';
   HIPCHK(hipStreamCreate(&c->st));
   RBCHK(rocblas_create_handle(&c->rb));
@@ -2299,12 +2560,9 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     }
   } lowrank_reset{c};
   ensure_work(c, mfull);
-  DArr<double> dB, dWm, dOld, dK, dKall, dRhs, Zk, Znew;
-  dB.alloc((size_t)nv * nb);
-  dWm.alloc((size_t)nv * mw);
-  dK.alloc((size_t)nv * nb);
-  dKall.alloc((size_t)nv * nb);
-  dRhs.alloc((size_t)nv * mfull);
+  TArr<double> dB(c->pool, (size_t)nv * nb), dWm(c->pool, (size_t)nv * mw), dOld(c->pool),
+      dK(c->pool, (size_t)nv * nb), dKall(c->pool, (size_t)nv * nb), dRhs(c->pool, (size_t)nv * mfull),
+      Zk(c->pool), Znew(c->pool);
   HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(dWm.p, W, sizeof(double) * nv * mw, hipMemcpyHostToDevice, st));
   if (oldB) {
@@ -2319,7 +2577,15 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   }
   // the rhs factor W is projected once here; the K_k part is in range(P^T) already
   ricadi_adi_params p2 = *prm;
+  Tick tk0;
+  prefetch_setup(c, shifts, std::min(ns, prm->adi_max_steps), prm->project_w != 0);
+  const double t_pre = c->timing ? ((void)hipStreamSynchronize(st), tk0.lap()) : 0.0;
   if (prm->project_w) project_panel(c, dWm.p, mw);
+  if (c->timing) {
+    (void)hipStreamSynchronize(st);
+    fprintf(stderr, "[ricadi timing] per-shift setup of %d shifts + projection operator %.1f ms, projection solve %.1f ms\n",
+            std::min(ns, prm->adi_max_steps), 1e3 * t_pre, 1e3 * tk0.lap());
+  }
   p2.project_w = 0;
   if (p2.compress_cols <= 0) p2.compress_cols = 512;
   double upd = 0, updrel = 0;
@@ -2328,8 +2594,11 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   int steps = 0;
   for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
     int m = mw;
+    Tick tkn;
+    if (c->timing) c->t_setup = c->t_solve = c->t_recomb = c->t_compress = c->t_updnorm = c->t_proj = c->t_gain = 0;
     if (kk > 0) {
       gain_dev(c, c->E, Zk.p, kk, kk, dB.p, nb, dK.p);
+      if (c->timing) c->t_gain += tkn.lap();
       m = mfull;
     } else {
       HIPCHK(hipMemsetAsync(dK.p, 0, sizeof(double) * nv * nb, st));
@@ -2357,18 +2626,27 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     nonconv += s.nonconverged;
     worst = std::max(worst, s.worst_relres);
     // compressed copy of the new iterate (truncation at the Gram noise floor)
+    const int zraw = c->zc;
+    Tick tkc;
     factor_recompress(c);
+    if (c->timing) c->t_compress += tkc.lap();
     Znew.alloc((size_t)nv * c->zc);
     const int knew = c->zc;
     launch_copy_cols(st, nv, knew, c->Z.p, c->zld, 0, Znew.p, knew, 0, 1.0);
     double x1 = 0.0;
     upd = diff_zzt_fnorm(c, Znew.p, knew, Zk.p, kk, &x1);
     updrel = x1 > 0.0 ? upd / x1 : 0.0;
+    if (c->timing) {
+      c->t_updnorm += tkc.lap();
+      fprintf(stderr, "[ricadi timing] Newton step %d: total %.1f ms = setup %.1f + projection %.1f + solves %.1f + "
+              "recombination %.1f + recompression %.1f + update norm %.1f + gain %.1f (+ rest); %d raw columns at the end\n",
+              steps, 1e3 * tkn.lap(), 1e3 * c->t_setup, 1e3 * c->t_proj, 1e3 * c->t_solve, 1e3 * c->t_recomb,
+              1e3 * c->t_compress, 1e3 * c->t_updnorm, 1e3 * c->t_gain, zraw);
+    }
     if (prm->verbose)
       fprintf(stderr, "[ricadi] Newton step %2d: |upd| %9.3e rel %9.3e (%d ADI steps, %d -> %d columns)\n",
               steps, upd, updrel, s.steps, c->zc, knew);
-    std::swap(Zk.p, Znew.p);
-    std::swap(Zk.n, Znew.n);
+    Zk.swap(Znew);
     kk = knew;
     if (upd < prm->nwtn_upd_abstol || updrel < prm->nwtn_upd_reltol) break;
   }

@@ -399,6 +399,14 @@ def test_tsqr_block_qr(n, c):
         got = np.linalg.norm((Rd * S) @ Rd.T)
         ref = opru.comp_diff_zzt_fnorm(Zd[:, :h], Zd[:, h:])
         assert np.isclose(got, ref, rtol=1e-6)
+        # an exactly zero column cannot go through the Cholesky-QR panels: the factorisation
+        # falls back to the Householder TSQR tree and still delivers Z = Q R, Q^T Q = I
+        Zz = Z[:, :2 * h].copy()
+        Zz[:, 1] = 0.0
+        Qz, Rz = ctx.qr(Zz)
+        assert np.linalg.norm(Qz @ Rz - Zz) <= 1e-13 * np.linalg.norm(Zz)
+        assert np.linalg.norm(Qz.T @ Qz - np.eye(2 * h)) <= 1e-12
+        assert abs(Rz[1, 1]) <= 1e-14 * np.linalg.norm(Zz)
     ctx.close()
 
 
