@@ -335,6 +335,13 @@ def main():
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     os.environ["RICADI_DEVICE"] = str(local)
 
+    # developer hook for option sweeps: RICADI_OPTS="gmres_restart=40,agg_v=24"
+    xopts = {}
+    for kv in filter(None, os.environ.get("RICADI_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        xopts[k] = float(v) if "tol" in k else int(v)
+    if xopts:
+        backend.configure(**xopts)
     t0 = time.time()
     pr, tb, trct, ms = build_inputs(args.N, args.nu, args.shifts)
     F = (-pr.A - pr.Nc).tocsr()

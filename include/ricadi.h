@@ -51,7 +51,7 @@ typedef struct ricadi_opts {
   double gmres_tol;      /* relative residual per column (default 1e-10, the
                             unit of work of SURVEY.md section 8d)            */
   int gmres_restart;     /* max Krylov vectors per cycle (default 30); cycles
-                            start at 12 vectors and grow to this whenever a
+                            start at 10 vectors and grow to this whenever a
                             cycle gains less than a factor 10 on some column */
   int gmres_maxit;       /* max iterations per solve (default 3000)         */
   int bj_block;          /* block-Jacobi block size, <= 64 (default 32)     */

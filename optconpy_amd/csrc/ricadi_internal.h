@@ -92,6 +92,7 @@ struct GroupPtrsT {
 };
 typedef GroupPtrsT<double> GroupPtrs;
 typedef GroupPtrsT<float> GroupPtrsF;   // FP32-stored preconditioner operands
+typedef GroupPtrsT<_Float16> GroupPtrsH;   // FP16-stored (row-scaled) coarse inverse
 struct GroupInts {            // one small integer per group id (by value)
   int v[RICADI_MAX_GROUPS];
 };
@@ -165,6 +166,16 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
                            int ldy, size_t gsy, const double* r, int ldr, size_t gsr, double alpha,
                            double beta_r, int m, int max_cols,
                            const LowRankArgs& lr = LowRankArgs());
+// multi-shift form: one read of the value arrays (tile order; vAJ = A part + J part, vE) for
+// all active groups; lidx carries the velocity-velocity flag in bit 15; alphas / betas:
+// RICADI_MAX_GROUPS coefficients indexed by group id
+bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows);
+void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
+                            int nblk, const int* rows2, const int* rp2, const int* cols2,
+                            const uint16_t* lidx, const double* vAJ, const double* vE,
+                            const double* x, int ldx, size_t gsx, double* y, int ldy, size_t gsy,
+                            const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
+                            int max_cols);
 void launch_axpby_b(hipStream_t st, const GroupTab& gt, size_t n, double a, const double* x,
                     size_t gsx, double b, double* y, size_t gsy);
 void launch_colscale_b(hipStream_t st, const GroupTab& gt, size_t nrows, int m, const double* a,
@@ -238,6 +249,10 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
                           const ProlongArgs& pa = ProlongArgs(), const CsrInArgs& ci = CsrInArgs());
+// FP16-stored coarse inverse, tile-major, one scale per row (Einv[i][:] = rowscale[i] * stored[i][:])
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsH& Einv,
+                          const GroupPtrs& rowscale, const double* rc, double* ec);
+void launch_to_f16_tiled(hipStream_t st, int k, const double* src, double* rowscale, _Float16* dst);
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
 void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst);

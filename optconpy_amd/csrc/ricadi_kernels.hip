@@ -458,6 +458,219 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 #undef RICADI_TILE_LAUNCH
 }
 
+// ---------------------------------------------------------------------------
+// K1, multi-shift form of the LDS-tiled kernel (the "batched shifted" kernel of SURVEY.md
+// App. C.4 / section 8d): the shifted matrices of a sweep differ by two scalars only,
+//     S(alpha_g, beta_g) = alpha_g * E + beta_g * A + J      on one sparsity pattern,
+// so ONE workgroup serves a row block for ALL active groups: the block's slice of the three
+// value arrays (block order) and its 16-bit local indices are loaded into registers once,
+// the tile's column list once, and the groups are then walked in a software pipeline --
+// while group g is accumulated out of LDS tile (g & 1), the x rows of group g+1 are already
+// in flight into registers and go to the other tile behind the barrier.  Per launch the
+// matrix is read once instead of once per group (26 B per non-zero instead of 10 B x G),
+// and only the first group of a workgroup pays the dependent-load latency of the metadata.
+// Panels up to 16 columns (one column per lane of a 16-lane row group).
+// grid.y splits the active groups (blockIdx.y, blockIdx.y + gridDim.y, ...) when there are
+// too few row blocks to fill the chip.
+// ---------------------------------------------------------------------------
+struct GroupCoefs {
+  double alpha[RICADI_MAX_GROUPS], beta[RICADI_MAX_GROUPS];
+};
+
+// Value sources: vE (cal E part) and vAJ = (cal A part) + (J / J^T part) -- the two have
+// disjoint supports (velocity-velocity entries vs. constraint entries), so
+//     value = alpha_g * vE + (entry in the velocity-velocity block ? beta_g : 1) * vAJ,
+// the block membership riding in bit 15 of the 16-bit local column index (tiles have at
+// most 160 columns).
+template <bool HAS_R>
+__global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
+    const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
+    const uint16_t* __restrict__ lidx, GroupTab gt, GroupCoefs cf,
+    const double* __restrict__ vAJ, const double* __restrict__ vE,
+    const double* __restrict__ x, int ldx, size_t gsx, double* __restrict__ y, int ldy, size_t gsy,
+    const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r, int m,
+    int max_cols) {
+  extern __shared__ double xs[];                             // 2 tiles of max_cols x 16
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
+  const int b = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (orig >> 3);
+  const int g = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int* __restrict__ bcols = cols2 + (size_t)b * max_cols;
+  constexpr int NR = 2, NCH = 3;               // rows per 16-lane group, 16-entry chunks in registers
+  constexpr int XJ = 5, XP = 2;                // tile rows per thread: XP passes of XJ (16 * 10 = 160 slots)
+  int ka[NR], kb[NR], grow[NR];
+  double mAJ[NR][NCH], mE[NR][NCH];
+  int myl[NR][NCH];                            // byte offset in the tile | velocity-velocity flag (bit 30)
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    const int q = gq + 16 * rr;
+    ka[rr] = rp2[b * 33 + q];
+    kb[rr] = rp2[b * 33 + q + 1];
+    grow[rr] = rows2[b * 32 + q];
+  }
+  const int gc = g < m ? g : 0;                // lanes beyond m shadow column 0 (kept in the broadcasts)
+  // tile slots of this thread (the same for every group): byte offsets into a panel, -1 = none
+  int xoff[XP][XJ];
+#pragma unroll
+  for (int pp = 0; pp < XP; ++pp)
+#pragma unroll
+    for (int t = 0; t < XJ; ++t) {
+      const int j = pp * 16 * XJ + gq + 16 * t;
+      const int ci = (j < max_cols) ? bcols[j] : -1;
+      xoff[pp][t] = ci >= 0 ? (ci * ldx + gc) * 8 : -1;
+    }
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int k = ka[rr] + ch * 16 + g;
+      const bool ok = k < kb[rr];
+      mAJ[rr][ch] = ok ? vAJ[k] : 0.0;
+      mE[rr][ch] = ok ? vE[k] : 0.0;
+      myl[rr][ch] = ok ? (int)lidx[k] : 0;
+    }
+  const int ystep = gridDim.y;
+  int gi = blockIdx.y;
+  if (gi >= gt.ng) return;
+  double xv[XP][XJ];
+  auto fetch = [&](int grp) {
+    const char* __restrict__ xg = reinterpret_cast<const char*>(x + (size_t)grp * gsx);
+#pragma unroll
+    for (int pp = 0; pp < XP; ++pp)
+#pragma unroll
+      for (int t = 0; t < XJ; ++t)
+        xv[pp][t] = (xoff[pp][t] >= 0) ? *reinterpret_cast<const double*>(xg + (unsigned)xoff[pp][t]) : 0.0;
+  };
+  auto stash = [&](int buf) {
+    double* __restrict__ tile = xs + (size_t)buf * max_cols * 16;
+#pragma unroll
+    for (int pp = 0; pp < XP; ++pp)
+#pragma unroll
+      for (int t = 0; t < XJ; ++t) {
+        const int j = pp * 16 * XJ + gq + 16 * t;
+        if (j < max_cols) tile[j * 16 + g] = xv[pp][t];
+      }
+  };
+  fetch(gt.gid[gi]);
+  stash(0);
+  // local index -> byte offset within a tile (row = 16 doubles); flag moves to bit 30
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int v = myl[rr][ch];
+      myl[rr][ch] = ((v & 0x7fff) << 7) | ((v & 0x8000) << 15);
+    }
+  __syncthreads();
+  typedef __attribute__((address_space(3))) const double lds_cdouble;
+  const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) double*)xs;
+  int nchr[NR];
+#pragma unroll
+  for (int rr = 0; rr < NR; ++rr) {
+    int nch = (kb[rr] - ka[rr] + 15) >> 4;     // chunks needed by any of the wave's four groups
+    nch = max(nch, __shfl_xor(nch, 16, 64));
+    nch = max(nch, __shfl_xor(nch, 32, 64));
+    nchr[rr] = nch;
+  }
+  int buf = 0;
+#define RICADI_MS_STEP(T)                                                                    \
+  {                                                                                          \
+    unsigned ad;                                                                             \
+    asm("v_add_u32_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf"            \
+        : "=v"(ad)                                                                           \
+        : "v"(lcur), "v"(lane_base));                                                        \
+    const double xval = *(lds_cdouble*)(size_t)ad;                                           \
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf"           \
+        : "+v"(acc[(T)&3])                                                                   \
+        : "v"(vcur), "v"(xval));                                                             \
+  }
+  for (; gi < gt.ng; gi += ystep) {
+    const int grp = gt.gid[gi];
+    const bool more = gi + ystep < gt.ng;
+    if (more) fetch(gt.gid[gi + ystep]);       // next group's x rows in flight during the accumulation
+    const double ag = cf.alpha[grp], bg = cf.beta[grp];
+    const unsigned lane_base = xs_lds + (unsigned)(buf * max_cols * 128) + (unsigned)gc * 8u;
+    double* __restrict__ yg = y + (size_t)grp * gsy;
+    const double* __restrict__ rg = HAS_R ? r + (size_t)grp * gsr : nullptr;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        if (ch < nchr[rr]) {
+          const int lraw = myl[rr][ch];
+          const int lcur = lraw & 0x3fffffff;
+          const double vcur = fma(ag, mE[rr][ch], ((lraw >> 30) ? bg : 1.0) * mAJ[rr][ch]);
+          // the DPP operands are read by hand-written DPP instructions: keep the VALU
+          // writes above two wait states away from them (hipcc pads nothing for asm)
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 2");
+          __builtin_amdgcn_sched_barrier(0);
+          RICADI_FOR16(RICADI_MS_STEP)
+        }
+      }
+      // rows longer than NCH*16 entries: stream the rest
+      for (int ch = NCH; ch < nchr[rr]; ++ch) {
+        const int k = ka[rr] + ch * 16 + g;
+        int lcur = 0;
+        double vcur = 0.0;
+        if (k < kb[rr]) {
+          const int v = (int)lidx[k];
+          lcur = (v & 0x7fff) << 7;
+          vcur = fma(ag, vE[k], ((v & 0x8000) ? bg : 1.0) * vAJ[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 2");
+        __builtin_amdgcn_sched_barrier(0);
+        RICADI_FOR16(RICADI_MS_STEP)
+      }
+      if (grow[rr] >= 0 && g < m) {
+        const int row = grow[rr];
+        double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (HAS_R) out += beta_r * rg[(size_t)row * ldr + g];
+        yg[(size_t)row * ldy + g] = out;
+      }
+    }
+    if (more) {
+      stash(buf ^ 1);
+      __syncthreads();                         // tile (buf^1) complete; everybody is done with tile (buf)
+      buf ^= 1;
+    }
+  }
+#undef RICADI_MS_STEP
+}
+size_t spmm_blocked_ms_lds_bytes(int max_cols) { return (size_t)2 * max_cols * 16 * sizeof(double) + 16; }
+// max_cols <= 160 (tile slots per thread: 16 x XP x XJ), m <= 16, panel offsets in 31 bits
+bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows) {
+  return m <= 16 && max_cols <= 160 && panel_rows * (size_t)m * 8 < ((size_t)1 << 31);
+}
+void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
+                            int nblk, const int* rows2, const int* rp2, const int* cols2,
+                            const uint16_t* lidx, const double* vAJ, const double* vE,
+                            const double* x, int ldx, size_t gsx, double* y, int ldy, size_t gsy,
+                            const double* r, int ldr, size_t gsr, double alpha, double beta_r, int m,
+                            int max_cols) {
+  if (nblk <= 0 || gt.ng <= 0) return;
+  GroupCoefs cf;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) {
+    cf.alpha[i] = alphas[i];
+    cf.beta[i] = betas[i];
+  }
+  // enough workgroups for ~4 per CU (1024): split the groups over grid.y when the row
+  // blocks alone do not fill the chip
+  int ysplit = 1;
+  while (ysplit < gt.ng && (long)nblk * ysplit < 900 && ysplit < 8) ysplit *= 2;
+  ysplit = std::min(ysplit, gt.ng);
+  const dim3 grid(nblk, ysplit, 1), block(256);
+  const size_t lds = spmm_blocked_ms_lds_bytes(max_cols);
+  if (r)
+    hipLaunchKernelGGL((spmm_blocked_ms_kernel<true>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
+                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols);
+  else
+    hipLaunchKernelGGL((spmm_blocked_ms_kernel<false>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
+                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols);
+}
+
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)
 __global__ void gather_vals_kernel(int nnz, const int* __restrict__ perm,
                                    const double* __restrict__ src, double* __restrict__ dst) {
@@ -1436,86 +1649,153 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
   dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
   hipLaunchKernelGGL(dense_apply_kernel<double>, grid, dim3(512), 0, st, gt, k, m, Einv, k, rc, ec);
 }
-// FP32-stored inverse in TILE-MAJOR layout: 16 x 16 tiles of 256 contiguous floats,
+// Low-precision-stored inverse in TILE-MAJOR layout: 16 x 16 tiles of 256 contiguous entries,
 // tile (it, jt) at (it * kp + jt) * 256, kp = ceil(k / 16), zero padded.  The A operand
 // of one MFMA chunk -- lane (r, q) needs Einv[16 it + r][16 jt + 4q .. 4q+3] -- is then
-// ONE fully coalesced 1-KB read per wave (lane offset (16 r + 4 q) floats) instead of
-// sixteen 64-B row segments 4k bytes apart.
+// ONE fully coalesced read per wave (1 KB for FP32, 512 B for FP16; lane offset
+// (16 r + 4 q) entries) instead of sixteen row segments 4k bytes apart.
+// FP16 storage carries one scale per ROW (Einv[i][:] = rowscale[i] * stored[i][:], the row
+// maximum mapped to 6e4), applied to the finished row sums: same GMRES iteration counts as
+// FP32 / FP64 storage on the numpy mirror (tools/precond_lab.py), half the bytes of the
+// largest operand of the preconditioner.
+__device__ __forceinline__ void load4t(const float* p, double (&a)[4]) {
+  const float4 u = *reinterpret_cast<const float4*>(p);
+  a[0] = (double)u.x; a[1] = (double)u.y; a[2] = (double)u.z; a[3] = (double)u.w;
+}
+__device__ __forceinline__ void load4t(const _Float16* p, double (&a)[4]) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 u = *reinterpret_cast<const h4*>(p);
+  a[0] = (double)(float)u.x; a[1] = (double)(float)u.y; a[2] = (double)(float)u.z; a[3] = (double)(float)u.w;
+}
+// Register blocking: a workgroup owns TI row tiles (16 TI output rows) x 16 columns; per
+// 16-column chunk of the inverse a lane loads its 4 values of rc ONCE and feeds them to the
+// MFMAs of all TI row tiles -- the rc gathers, four per chunk, were the larger part of the
+// kernel's load instructions (the inverse itself is one vector load per chunk and tile).
+template <class T, int TI>
 __global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int k, int m,
-                                                                GroupPtrsF Einvs,
+                                                                GroupPtrsT<T> Einvs, GroupPtrs rowscales,
                                                                 const double* __restrict__ rc,
                                                                 double* __restrict__ ec) {
-  __shared__ double red[8][16][17];
+  __shared__ double red[8][16 * TI][17];
   const int grp = gt.gid[blockIdx.z];
-  const float* __restrict__ Einv = Einvs.p[grp];
+  const T* __restrict__ Einv = Einvs.p[grp];
+  const double* __restrict__ rsc = rowscales.p[grp];
   rc += (size_t)grp * k * m;
   ec += (size_t)grp * k * m;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int it = blockIdx.x, c0 = blockIdx.y * 16;
+  const int it0 = blockIdx.x * TI, c0 = blockIdx.y * 16;
   const int kp = (k + 15) / 16;
   const int per = (kp + 7) / 8;
   const int ch0 = w * per, ch1 = min(kp, ch0 + per);
   const int col = c0 + r;
-  const float* __restrict__ trow = Einv + (size_t)it * kp * 256 + r * 16 + 4 * q;
-  d4v acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-  auto fetch = [&](int ch, float4& a, double (&bb)[4]) {
-    if (ch < ch1) {
-      a = *reinterpret_cast<const float4*>(trow + (size_t)ch * 256);
+  d4v acc[TI];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int jj = ch * 16 + 4 * q + t;
-        bb[t] = (jj < k && col < m) ? rc[(size_t)jj * m + col] : 0.0;
-      }
-    } else {
-      a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < TI; ++t) acc[t] = (d4v){0.0, 0.0, 0.0, 0.0};
+  const size_t lane_off = (size_t)r * 16 + 4 * q;
+  for (int ch = ch0; ch < ch1; ch += 2) {
+    double b0[4], b1[4];
+    const bool two = ch + 1 < ch1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) bb[t] = 0.0;
+    for (int t = 0; t < 4; ++t) {
+      const int j0 = ch * 16 + 4 * q + t, j1 = j0 + 16;
+      b0[t] = (j0 < k && col < m) ? rc[(size_t)j0 * m + col] : 0.0;
+      b1[t] = (two && j1 < k && col < m) ? rc[(size_t)j1 * m + col] : 0.0;
     }
-  };
-  for (int ch = ch0; ch < ch1; ch += 4) {
-    float4 a0, a1, a2, a3;
-    double b0[4], b1[4], b2[4], b3[4];
-    fetch(ch, a0, b0);
-    fetch(ch + 1, a1, b1);
-    fetch(ch + 2, a2, b2);
-    fetch(ch + 3, a3, b3);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.x, b0[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.x, b1[0], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.y, b0[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.y, b1[1], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.z, b0[2], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.z, b1[2], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0.w, b0[3], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1.w, b1[3], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.x, b2[0], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.x, b3[0], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.y, b2[1], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.y, b3[1], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.z, b2[2], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.z, b3[2], acc2, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a2.w, b2[3], acc, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a3.w, b3[3], acc2, 0, 0, 0);
+    double a0[TI][4], a1[TI][4];
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+      const int it = it0 + ti;
+      if (it < kp) {
+        const T* __restrict__ trow = Einv + ((size_t)it * kp + ch) * 256 + lane_off;
+        load4t(trow, a0[ti]);
+        if (two) {
+          load4t(trow + 256, a1[ti]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a1[ti][t] = 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a0[ti][t] = a1[ti][t] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < TI; ++ti) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ti][t], b0[t], acc[ti], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ti][t], b1[t], acc[ti], 0, 0, 0);
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
+  for (int ti = 0; ti < TI; ++ti)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) red[w][q + 4 * e][r] = acc[e];
+    for (int e = 0; e < 4; ++e) red[w][16 * ti + q + 4 * e][r] = acc[ti][e];
   __syncthreads();
-  if (threadIdx.x < 256) {
-    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+  for (int o = threadIdx.x; o < 16 * TI * 16; o += 512) {
+    const int rr = o >> 4, cc = o & 15;
     double sum = 0.0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) sum += red[t][rr][cc];
-    if (it * 16 + rr < k && c0 + cc < m) ec[(size_t)(it * 16 + rr) * m + c0 + cc] = sum;
+    const int row = it0 * 16 + rr;
+    if (row < k && c0 + cc < m) ec[(size_t)row * m + c0 + cc] = rsc ? rsc[row] * sum : sum;
   }
+}
+template <class T>
+static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, int m,
+                                     const GroupPtrsT<T>& Einv, const GroupPtrs& rowscale, const double* rc,
+                                     double* ec) {
+  if (k <= 0 || gt.ng <= 0) return;
+  const int kp = (k + 15) / 16;
+  // one row tile per workgroup: four tiles per workgroup (rc values loaded once for four MFMA
+  // groups) measured no faster -- 133 VGPRs, 3 waves per SIMD: 63 vs 57-63 us at cfg2, G = 16
+  dim3 grid(kp, (m + 15) / 16, gt.ng);
+  hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rowscale, rc, ec);
 }
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
                           int ldf, const double* rc, double* ec) {
   (void)ldf;   // tile-major storage (launch_to_f32_tiled)
-  if (k <= 0 || gt.ng <= 0) return;
-  dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
-  hipLaunchKernelGGL(dense_apply_tiled_kernel, grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
+  dense_apply_tiled_launch(st, gt, k, m, Einv, same_ptr((const double*)nullptr), rc, ec);
+}
+void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsH& Einv,
+                          const GroupPtrs& rowscale, const double* rc, double* ec) {
+  dense_apply_tiled_launch(st, gt, k, m, Einv, rowscale, rc, ec);
+}
+// FP16 tile-major copy with one scale per row: rowscale[i] = max_j |src[i][j]| / 6e4
+__global__ __launch_bounds__(256) void rowscale_kernel(int k, const double* __restrict__ src,
+                                                       double* __restrict__ rowscale) {
+  __shared__ double red[256];
+  const int i = blockIdx.x;
+  double mx = 0.0;
+  for (int j = threadIdx.x; j < k; j += 256) mx = fmax(mx, fabs(src[(size_t)i * k + j]));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) rowscale[i] = red[0] > 0.0 ? red[0] / 6e4 : 1.0;
+}
+__global__ void to_f16_tiled_kernel(int k, const double* __restrict__ src,
+                                    const double* __restrict__ rowscale, _Float16* __restrict__ dst) {
+  const int kp = (k + 15) / 16;
+  const size_t n = (size_t)kp * kp * 256;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t tile = i >> 8;
+    const int r = (int)((i >> 4) & 15), cc = (int)(i & 15);
+    const int row = (int)(tile / kp) * 16 + r, col = (int)(tile % kp) * 16 + cc;
+    dst[i] = (row < k && col < k) ? (_Float16)(float)(src[(size_t)row * k + col] / rowscale[row]) : (_Float16)0.f;
+  }
+}
+void launch_to_f16_tiled(hipStream_t st, int k, const double* src, double* rowscale, _Float16* dst) {
+  const int kp = (k + 15) / 16;
+  const size_t n = (size_t)kp * kp * 256;
+  if (!n) return;
+  hipLaunchKernelGGL(rowscale_kernel, dim3(k), dim3(256), 0, st, k, src, rowscale);
+  int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(to_f16_tiled_kernel, dim3(grid), dim3(256), 0, st, k, src, rowscale, dst);
 }
 // dst = FP32 copy of the k x k row-major src in 16 x 16 tile-major layout, zero padded
 __global__ void to_f32_tiled_kernel(int k, const double* __restrict__ src, float* __restrict__ dst) {

@@ -184,6 +184,9 @@ struct ShiftData {
   // operator either way; halves its HBM traffic).  einvf is stored in 16 x 16 tiles
   // (dense_apply_tiled_kernel).  RICADI_PRECOND64=1 applies the FP64 originals instead.
   DArr<float> bvinvf, bpinvf, einvf;
+  // FP16 copy of the coarse inverse with one scale per row (default; RICADI_COARSE16=0: FP32)
+  DArr<_Float16> einvh;
+  DArr<double> einvs;
   // Sherman-Morrison-Woodbury data for the current low-rank term (ctx->lr_epoch):
   // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
   DArr<double> smw_w;
@@ -252,6 +255,12 @@ struct ricadi_ctx {
   // rp2 [nblk][33], cols2 [nblk][sb_max_cols], colsm2 = cols2 through the aggregate map
   DArr<int> sb_rows2, sb_rp2, sb_cols2, sb_colsm2;
   DArr<uint16_t> sb_lidx;
+  // the three value sources in tile order, for the multi-shift kernel (values of all shifts
+  // from ONE read): saddle operator and prolongated operator
+  DArr<double> sbAJ, sbE, sybAJ, sybE;
+  DArr<uint16_t> sb_lidx_ms, syb_lidx_ms;
+  bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
+  int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
   // low rank
   int q = 0;
   DArr<double> U, V, lrc, scratch;
@@ -268,6 +277,7 @@ struct ricadi_ctx {
   bool basis32 = true;
   bool basis16 = true;        // FP16-stored Krylov basis (default for n <= 2^21)
   bool precond32 = true;
+  bool coarse16 = false;      // RICADI_COARSE16=1: coarse inverse stored in FP16 with row scales (experimental)
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
   DArr<double*> eptrs;
@@ -496,8 +506,14 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       }
       if (k > 0) {
         const size_t kp = (size_t)(k + 15) / 16;
-        if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
-        launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
+        if (c->coarse16) {
+          if (sd->einvh.n != kp * kp * 256) sd->einvh.alloc(kp * kp * 256);
+          if (sd->einvs.n != (size_t)k) sd->einvs.alloc(k);
+          launch_to_f16_tiled(st, k, sd->einv.p, sd->einvs.p, sd->einvh.p);
+        } else {
+          if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
+          launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
+        }
       }
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -519,8 +535,11 @@ struct Batch {
   int G = 0;                 // groups in the solve (ids 0 .. G-1)
   int m = 0;                 // panel width of every group
   GroupTab tab;              // groups the next launches act on
+  double alpha[RICADI_MAX_GROUPS], beta[RICADI_MAX_GROUPS];   // shift of every group id
   GroupPtrs sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
+  GroupPtrsH einvh;
+  GroupPtrs einvs;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
   void all() {
@@ -544,10 +563,17 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.tab = GroupTab{};
   bt.sval = bt.svalb = bt.syval = bt.syvalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
+  bt.einvh = same_ptr((const _Float16*)nullptr);
+  bt.einvs = same_ptr((const double*)nullptr);
+  for (int g = 0; g < RICADI_MAX_GROUPS; ++g) bt.alpha[g] = bt.beta[g] = 0.0;
   for (int g = 0; g < G; ++g) {
+    bt.alpha[g] = sds[g]->alpha;
+    bt.beta[g] = sds[g]->beta;
     bt.bvinvf.p[g] = sds[g]->bvinvf.p;
     bt.bpinvf.p[g] = sds[g]->bpinvf.p;
     bt.einvf.p[g] = sds[g]->einvf.p;
+    bt.einvh.p[g] = sds[g]->einvh.p;
+    bt.einvs.p[g] = sds[g]->einvs.p;
     bt.sval.p[g] = sds[g]->sval.p;
     bt.syval.p[g] = sds[g]->syval.p;
     bt.syvalb.p[g] = sds[g]->syvalb.p;
@@ -565,6 +591,17 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
 }
 static Batch make_batch(ricadi_ctx* c, ShiftData* sd, int m) { return make_batch(c, &sd, 1, m); }
 
+// Multi-shift tile kernel or one workgroup per (row block, group)?  The multi-shift kernel
+// reads the matrix once for all groups (26 -> 18 B per non-zero in total instead of 10 B per
+// group) but walks the groups of a row block one after the other at 4 waves per SIMD; it
+// pays where the per-shift value arrays of the active groups no longer fit the caches
+// (measured: n = 5e5, 16 groups: 1.53 -> 1.25 ms per launch; n = 3e4: 83 -> 87 us).
+static bool ms_pays(const ricadi_ctx* c, int ng, size_t nnz) {
+  if (!c->ms_spmm) return false;
+  if (c->ms_force) return true;
+  return ng >= 4 && (double)nnz * 10.0 * ng > 256e6;      // beyond the 256 MB infinity cache
+}
+
 // ---- operator and preconditioner on device panels ---------------------------------
 // y = beta_r * r + alpha * S x on the saddle operator (optionally through the
 // prolongation map): LDS-tiled kernel when the block tiles fit, else the CSR one.
@@ -577,7 +614,13 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
   const bool fits =
       c->sb_ok && !force_csr &&
       spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
-  if (fits)
+  const bool has_lr = lr.q > 0 && lr.nrows > 0;
+  if (fits && ms_pays(c, bt.tab.ng, c->snnz) && !xmap && !has_lr &&
+      spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n))
+    launch_spmm_blocked_ms(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
+                           c->sb_cols2.p, c->sb_lidx_ms.p, c->sbAJ.p, c->sbE.p, x, m, gsx, y, m, gsy,
+                           r, m, gsr, alpha, beta_r, m, c->sb_max_cols);
+  else if (fits)
     launch_spmm_blocked_b(c->st, bt.tab, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
                           xmap ? c->sb_colsm2.p : c->sb_cols2.p, c->sb_lidx.p, bt.svalb, x, m, gsx, y,
                           m, gsy, r, m, gsr, alpha, beta_r, m, c->sb_max_cols, lr);
@@ -620,7 +663,9 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
                   bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
-    if (c->precond32)
+    if (c->precond32 && c->coarse16)
+      launch_dense_apply_b(st, gt, c->kc, m, bt.einvh, bt.einvs, c->rc.p, c->ec.p);
+    else if (c->precond32)
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
@@ -631,7 +676,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
     // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
     static const bool sy_csr = getenv("RICADI_SY_CSR") != nullptr;
-    if (c->syb_ok && !sy_csr &&
+    if (c->syb_ok && !sy_csr && ms_pays(c, gt.ng, c->snnz) &&
+        spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
+      launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
+                             c->syb_cols2.p, c->syb_lidx_ms.p, c->sybAJ.p, c->sybE.p, c->ec.p, m,
+                             bt.gsc, c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, c->syb_max_cols);
+    else if (c->syb_ok && !sy_csr &&
         spmm_blocked_lds_bytes(m, c->syb_max_cols, 0) <= (size_t)40 * 1024)
       launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
                             c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, bt.gs, r, m, gsr,
@@ -703,7 +753,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     } else {
       double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
       launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
-                    nullptr, 0, 0, 1.0, 0.0, m);
+                    nullptr, 0, 0, 1.0, 0.0, m, LowRankArgs(), 8);    // J^T has ~5 entries per row
       vel_apply(tmp, bt.gs, 1, true);
     }
   }
@@ -793,7 +843,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
   // iteration: three passes over it) small; a cycle that gains less than a factor 10
   // on some column lengthens the following ones, up to gmres_restart.
-  static const int cyc0 = getenv("RICADI_CYC0") ? std::max(2, atoi(getenv("RICADI_CYC0"))) : 12;
+  static const int cyc0 = getenv("RICADI_CYC0") ? std::max(2, atoi(getenv("RICADI_CYC0"))) : 10;
   int cyc = std::min(restart, cyc0);
   std::vector<double> rstart(GM, 0.0);
   while (!act.empty()) {
@@ -833,6 +883,11 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       }
     }
     if (slow) cyc = std::min(restart, cyc + (cyc + 1) / 2);
+    // Few groups left (the stragglers of the sweep): the launches are latency bound then and
+    // the traffic of a longer Krylov basis costs nothing -- let the cycles run to the full
+    // restart length instead of throwing the subspace away every `cyc` vectors.
+    static const int tail_groups = getenv("RICADI_TAIL_GROUPS") ? atoi(getenv("RICADI_TAIL_GROUPS")) : 0;
+    if ((int)next.size() <= tail_groups) cyc = restart;
     act.swap(next);
     if (act.empty()) break;
     bt.set(act);
@@ -1785,6 +1840,7 @@ int ricadi_create(int device_id, ricadi_ctx** out) {
   ricadi_default_opts(&c->opts);
   c->precond32 = getenv("RICADI_PRECOND64") == nullptr;
   c->timing = getenv("RICADI_TIMING") != nullptr;
+  if (const char* e = getenv("RICADI_COARSE16")) c->coarse16 = e[0] != '0';
   if (const char* e = getenv("RICADI_SMW")) c->smw = e[0] != '0';
   HIPCHK(hipStreamCreate(&c->st));
   RBCHK(rocblas_create_handle(&c->rb));
@@ -1958,6 +2014,42 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->sb_perm.upload(hs.sb_perm, st);
   c->sb_lidx.upload(hs.sb_lidx, st);
   c->sb_ok = hs.sb_nblk > 0 && hs.sb_max_cols < 65536;
+  if (const char* e = getenv("RICADI_MS_SPMM")) {
+    c->ms_spmm = e[0] != '0';
+    c->ms_force = e[0] == '2';
+  }
+  // multi-shift kernel operands: vAJ = A part + J part (disjoint supports) and vE in tile
+  // order; velocity-velocity flag in bit 15 of the local index
+  auto ms_arrays = [&](const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& a,
+                       const std::vector<double>& e, const std::vector<double>& j, const std::vector<int>& perm,
+                       const std::vector<uint16_t>& lidx, int ncol_v, DArr<double>& dAJ, DArr<double>& dE,
+                       DArr<uint16_t>& dl) {
+    const size_t nnz = perm.size();
+    std::vector<int> rowof(ci.size());
+    for (int i = 0; i + 1 < (int)rp.size(); ++i)
+      for (int k = rp[i]; k < rp[i + 1]; ++k) rowof[k] = i;
+    std::vector<double> aj(nnz), ee(nnz);
+    std::vector<uint16_t> lm(nnz);
+    for (size_t kb = 0; kb < nnz; ++kb) {
+      const int k = perm[kb];
+      aj[kb] = a[k] + j[k];
+      ee[kb] = e[k];
+      const bool vv = rowof[k] < nv && ci[k] < ncol_v;
+      lm[kb] = (uint16_t)(lidx[kb] | (vv ? 0x8000 : 0));
+    }
+    dAJ.upload(aj, st);
+    dE.upload(ee, st);
+    dl.upload(lm, st);
+  };
+  if (c->sb_ok && hs.sb_max_cols <= 160)
+    ms_arrays(hs.s_rp, hs.s_ci, hs.s_srcA, hs.s_srcE, hs.s_srcJ, hs.sb_perm, hs.sb_lidx, nv, c->sbAJ, c->sbE,
+              c->sb_lidx_ms);
+  else
+    c->ms_spmm = false;
+  if (c->syb_ok && hs.syb_max_cols <= 160 && c->ms_spmm)
+    ms_arrays(hs.sy_rp, hs.sy_ci, hs.sy_A, hs.sy_E, hs.sy_J, hs.syb_perm, hs.syb_lidx, hs.kcv, c->sybAJ, c->sybE,
+              c->syb_lidx_ms);
+  HIPCHK(hipStreamSynchronize(st));
   c->q = 0;
   c->wcols = 0;  // workspaces depend on n
   c->zc = 0;
@@ -2374,13 +2466,20 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         break;
       case 3:
         if (c->kc <= 0) throw HipError{"no coarse level"};
-        if (c->precond32)
+        if (c->precond32 && c->coarse16)
+          launch_dense_apply_b(st, gt, c->kc, m, bt.einvh, bt.einvs, c->rc.p, c->ec.p);
+        else if (c->precond32)
           launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
         else
           launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
         break;
       case 4:
         if (!c->syb_ok) throw HipError{"no tiled S*Y"};
+        if (ms_pays(c, gt.ng, c->snnz) && spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
+          launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
+                                 c->syb_cols2.p, c->syb_lidx_ms.p, c->sybAJ.p, c->sybE.p, c->ec.p,
+                                 m, bt.gsc, c->r2.p, m, nm, c->wv.p, m, nm, -1.0, 1.0, m, c->syb_max_cols);
+        else
         launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
                               c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, nm, c->wv.p, m, nm,
                               -1.0, 1.0, m, c->syb_max_cols);

@@ -461,8 +461,8 @@ def test_newton_parity_other_ordering_and_viscosity():
 def test_batched_shift_solve_matches_single():
     """ricadi_shift_solve_batch_dev: all shifts of a sweep in one lockstep launch sequence give
     the same solutions as one solve per shift -- shared and per-group right-hand sides, with
-    the low-rank term.  (Iteration counts are close but not equal: the restart-cycle length
-    adapts to the slowest group of the batch.)"""
+    the low-rank term.  (Iteration counts are of the same order but not equal: the restart-cycle
+    length adapts to the slowest group of the batch.)"""
     import torch
     pr = pb.ricc_problem(15, 0.05)
     ctx = _lib.Context(0)
