@@ -290,6 +290,82 @@ def cpu_baseline(pr, ms, m, adi_steps, full=False):
     return out
 
 
+# BASELINE.json configs 3-5: fixed-work units for runs at their sizes.  One step =
+# ONE pass over the whole shift list of the open-loop projected Lyapunov ADI (s shift-solves with
+# an NV x m panel each, sweeps of 16 shifts, Cauchy recombination and residual hand-off included).
+WORKLOADS = {
+    "cfg3": dict(N=75, nu=0.15 / 40.0, shifts=32, m=16, dre=False, pmin=1.0, pmax=3e3,
+                 note="cylinder-wake surrogate, n = 50 177, 32 shifts (BASELINE: 4 GPUs)"),
+    "cfg4": dict(N=106, nu=0.15 / 60.0, shifts=64, m=66, dre=True, pmin=0.5, pmax=2e3,
+                 note="n = 100 490, time-varying DRE operator -(M^T/2 + tau (A+N)^T) at the largest step "
+                      "of the sine-squeezed mesh (Nts = 16), panel m = 66, 64 shifts (BASELINE: 8 GPUs)"),
+    "cfg5": dict(N=236, nu=0.05, shifts=128, m=16, dre=False, pmin=1.0, pmax=3e3,
+                 note="n = 499 850, nnz(S) = 14.4e6, 128 shifts (BASELINE: 8 GPUs)"),
+}
+
+
+def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_fn):
+    """Times `steps` shift cycles of a WORKLOADS entry with the shift-parallel sweep driver (one
+    process per GPU; at world size 1 the same code on one GPU).  Returns the result dict (rank 0)."""
+    import torch
+    import torch.distributed as dist
+    from optconpy_amd import _lib, problems as pb
+    from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel, plan_items
+    w = WORKLOADS[name]
+    pr = pb.ricc_problem(w["N"], w["nu"])
+    MT = pr.M.T.tocsr()
+    if w["dre"]:
+        tau = float(np.diff(pb.get_tint(0.0, 1.0, 16, True)).max())
+        calA = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
+    else:
+        calA = (-pr.A - pr.Nc).T.tocsr()
+    ms = pb.logshifts(w["pmin"], w["pmax"], w["shifts"])
+    ctx = _lib.Context(local)
+    ctx.set_operator(calA, MT, pr.J)
+    ops = HipOps(ctx)
+    # right-hand-side factor: seeded random panel, Leray-projected on the device
+    R = np.random.default_rng(1234).standard_normal((pr.NV, w["m"]))
+    X, _, _ = ctx.shift_solve(1.0, 0.0, R)
+    W = ops.to_panel(MT @ X[:pr.NV])
+    n = pr.NV + pr.NP
+    G = min(16, len(ms))
+    parts = plan_items(G, world, col_split)
+
+    def step():
+        ops.clear_cache()
+        ops.gmres_iters = ops.shift_solves = ops.nonconverged = 0
+        ops.worst_relres = 0.0
+        blocks, info = lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=len(ms), adi_newZ_reltol=0.0,
+                                               width=G, col_parts=parts)
+        return info
+
+    for _ in range(warmup):
+        step()
+    barrier_fn(ctx)
+    t0 = time.perf_counter()
+    units = 0
+    info = None
+    for _ in range(steps):
+        info = step()
+        units += info["adi_steps"]
+    barrier_fn(ctx)
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    res = dict(workload="%s: driven-cavity pattern N=%d (%s), nu=%g; one step = one pass over the %d-shift list of "
+                        "the open-loop Lyapunov ADI, panel m=%d, GMRES tol 1e-10, per-shift setup inside the step"
+                        % (name, w["N"], w["note"], w["nu"], len(ms), w["m"]),
+               value=round(units / el, 3), unit="shift-solves/s", ms_per_step=round(1e3 * el / steps, 1),
+               steps=steps, warmup=warmup, n=int(n), m=int(w["m"]), shifts=len(ms), col_parts=parts,
+               gmres_nonconverged=info["gmres_nonconverged"], gmres_worst_relres=info["gmres_worst_relres"],
+               gmres_iters_per_shift_solve=round(ops.gmres_iters / max(ops.shift_solves, 1), 1),
+               final_residual_fro=info["res_fro"])
+    ctx.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -309,6 +385,12 @@ def main():
                     help="N>1: column parts per shift (0 = automatic: 2 when the ranks would otherwise "
                          "hold fewer than 4 groups)")
     ap.add_argument("--streams", type=int, default=1, help="Python driver only: concurrent batches per rank")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2"] + sorted(WORKLOADS),
+                    help="cfg2 (default): the metric's configuration, one Newton step to K.  cfg3 / cfg4 / cfg5: "
+                         "the larger BASELINE.json configurations as fixed-work shift cycles (see WORKLOADS)")
+    ap.add_argument("--also-baseline-config", action="store_true",
+                    help="N>1: after the cfg2 headline also time one shift cycle of the BASELINE configuration "
+                         "quoted for this GPU count (cfg3 @ 4, cfg4 @ 8) and add it as `baseline_config_for_n`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true",
                     help="cpu_baseline: run the whole single-core step (all LUs, all panel solves, ~100 s)")
@@ -334,6 +416,24 @@ def main():
     if args.gpus != world and rank == 0:
         log("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
     os.environ["RICADI_DEVICE"] = str(local)
+
+    def bar(cx):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        cx.synchronize()
+
+    if args.workload != "cfg2":
+        res = cycle_workload(args.workload, world, rank, local, args.steps, args.warmup, args.col_split, bar)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "ADI shift-solves/sec", "value": res["value"], "unit": "shift-solves/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic", "config": res}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # developer hook for option sweeps: RICADI_OPTS="gmres_restart=40,agg_v=24"
     xopts = {}
@@ -569,6 +669,16 @@ def main():
         items = G * sp["parts"]
         g_loc = max(1, -(-items // world))
         out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m // sp["parts"], [float(p) for p in ms[:min(g_loc, G)]])
+    if world > 1 and args.also_baseline_config:
+        cfg_for_n = {4: "cfg3", 8: "cfg4"}.get(world)
+        if cfg_for_n:
+            try:
+                extra = cycle_workload(cfg_for_n, world, rank, local, 1, 0, args.col_split, bar)
+                if rank == 0:
+                    out["baseline_config_for_n"] = extra
+            except Exception as e:
+                if rank == 0:
+                    out["baseline_config_for_n"] = {"error": str(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pr, ms, m, units // args.steps, full=args.cpu_full)

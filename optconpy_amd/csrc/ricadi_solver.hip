@@ -1378,60 +1378,129 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   std::vector<ShiftData*> sds(G);
   std::vector<GmresResult> res(G);
   static const bool sync_recompress = getenv("RICADI_SYNC_RECOMPRESS") != nullptr;
+  static const bool narrow_tail = getenv("RICADI_FULL_SWEEPS") == nullptr;
   AsyncRecompress job(c);
   int steps = 0;
-  for (int sw = 0; steps + G <= prm.adi_max_steps; ++sw) {
-    const std::vector<double>& ps = pss[sw % ncyc];
-    const std::vector<double>& rinv = rinvs[sw % ncyc];
-    const std::vector<double>& cinv1 = cinvs[sw % ncyc];
-    get_shifts(c, ps.data(), be.data(), G, sds.data());
+  // relative block norm of the last two visits of every position of the shift cycle
+  std::vector<double> rel_h1(ns, 0.0), rel_h2(ns, 0.0);
+  std::vector<double> ps_var, rinv_var, cinv_var;
+  for (int sw = 0;; ++sw) {
+    // Width of this sweep.  With C = R^T R (R upper triangular) column block j of U R^-1 lies in
+    // span{U_1..U_j}: it IS the block the step-by-step iteration appends at step j (up to its
+    // sign), so the reference's stopping rule -- relative norm of the new block below
+    // adi_newZ_reltol (optcont_main.py:123-124) -- is applied block by block below, and the
+    // iteration ends after the same step as the sequential one.  So that the solves behind
+    // the stopping step are not spent in vain, the block norms of the last two passes over
+    // the shift cycle predict that step (per cycle position: same shift, geometric decay)
+    // and the sweep is cut there (any run of consecutive, distinct shifts is a valid sweep;
+    // its Cauchy data are computed on the spot).
+    int g_now = G;
+    if (narrow_tail && prm.adi_newZ_reltol > 0.0) {
+      for (int g = 0; g < G; ++g) {
+        const int pos = (steps + g) % ns;
+        if (rel_h1[pos] > 0.0 && rel_h2[pos] > rel_h1[pos]) {
+          const double pred = rel_h1[pos] * (rel_h1[pos] / rel_h2[pos]);
+          if (pred < prm.adi_newZ_reltol) {
+            g_now = g + 1;
+            break;
+          }
+        }
+      }
+    }
+    g_now = std::min(g_now, prm.adi_max_steps - steps);
+    if (g_now < 1) break;
+    const std::vector<double>* psp;
+    const std::vector<double>* rinvp;
+    const std::vector<double>* cinvp;
+    if (g_now == G && steps % G == 0) {
+      psp = &pss[(steps / G) % ncyc];
+      rinvp = &rinvs[(steps / G) % ncyc];
+      cinvp = &cinvs[(steps / G) % ncyc];
+    } else {
+      ps_var.resize(g_now);
+      for (int g = 0; g < g_now; ++g) ps_var[g] = shifts[(steps + g) % ns];
+      rinv_var.assign((size_t)g_now * g_now, 0.0);
+      cinv_var.assign(g_now, 0.0);
+      if (cauchy_data(ps_var.data(), g_now, rinv_var.data(), cinv_var.data()) != RICADI_OK)
+        throw HipError{"Cauchy matrix of a partial ADI sweep is numerically singular"};
+      psp = &ps_var;
+      rinvp = &rinv_var;
+      cinvp = &cinv_var;
+    }
+    const std::vector<double>& ps = *psp;
+    const std::vector<double>& rinv = *rinvp;
+    const std::vector<double>& cinv1 = *cinvp;
+    const int Gs = g_now;
+    get_shifts(c, ps.data(), be.data(), Gs, sds.data());
     lap(c->t_setup);
     load_rhs(c, dW, m, c->bvec.p);
-    solve_batch(c, sds.data(), G, c->bvec.p, 0, c->sweep_u.p, m, true, nullptr, res.data());
+    solve_batch(c, sds.data(), Gs, c->bvec.p, 0, c->sweep_u.p, m, true, nullptr, res.data());
     lap(c->t_solve);
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < Gs; ++g)
       if (!res[g].converged) {
         stt.nonconverged++;
         stt.worst_relres = std::max(stt.worst_relres, res[g].max_relres);
       }
-    stt.shift_solves += G;
-    // coefficient rows (replicated over the m columns): G columns of R^-1, then C^-1 1
-    for (int j = 0; j <= G; ++j)
-      for (int i = 0; i < G; ++i) {
-        const double v = j < G ? rinv[(size_t)i * G + j] : cinv1[i];
-        for (int cidx = 0; cidx < m; ++cidx) coef[((size_t)j * G + i) * m + cidx] = v;
+    stt.shift_solves += Gs;
+    // coefficient rows (replicated over the m columns): Gs columns of R^-1, then C^-1 1
+    for (int j = 0; j <= Gs; ++j)
+      for (int i = 0; i < Gs; ++i) {
+        const double v = j < Gs ? rinv[(size_t)i * Gs + j] : cinv1[i];
+        for (int cidx = 0; cidx < m; ++cidx) coef[((size_t)j * Gs + i) * m + cidx] = v;
       }
-    HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * coef.size(),
+    HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * (size_t)(Gs + 1) * Gs * m,
                           hipMemcpyHostToDevice, st));
     // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
-    for (int j = 0; j < G; ++j) {
-      launch_cols_update(st, nv, m, G, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)j * G * m, 1.0,
+    for (int j = 0; j < Gs; ++j) {
+      launch_cols_update(st, nv, m, Gs, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)j * Gs * m, 1.0,
                          nullptr, nullptr, c->sweep_t.p);
       launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, c->Z.p, c->zld, c->zc + j * m, 1.0);
       col_norms2(c, c->sweep_t.p, nv, m, c->nrm2.p + (size_t)j * m);
     }
     // W <- W + E (U C^-1 1)
-    launch_cols_update(st, nv, m, G, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)G * G * m, 1.0,
+    launch_cols_update(st, nv, m, Gs, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)Gs * Gs * m, 1.0,
                        nullptr, nullptr, c->sweep_t.p);
     launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0,
                 1.0, nullptr, m);
-    HIPCHK(hipMemcpyAsync(c->h_resid, c->nrm2.p, sizeof(double) * G * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_resid, c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    double n2 = 0.0;
-    for (int j = 0; j < G * m; ++j) n2 += c->h_resid[j];
-    znorm2 += n2;
-    c->zc += G * m;
-    steps += G;
+    // the reference's rule, block by block; blocks behind the stopping step are dropped
+    int kept = Gs;
+    bool stop = false;
+    for (int j = 0; j < Gs; ++j) {
+      double b2 = 0.0;
+      for (int cc = 0; cc < m; ++cc) b2 += c->h_resid[(size_t)j * m + cc];
+      znorm2 += b2;
+      const double relj = znorm2 > 0.0 ? std::sqrt(b2 / znorm2) : 0.0;
+      const int pos = (steps + j) % ns;
+      rel_h2[pos] = rel_h1[pos];
+      rel_h1[pos] = relj;
+      stt.rel = relj;
+      if (narrow_tail && relj < prm.adi_newZ_reltol) {
+        kept = j + 1;
+        stop = true;
+        break;
+      }
+    }
+    if (!narrow_tail) {
+      // sweep granularity (RICADI_FULL_SWEEPS=1): mean block norm of the sweep
+      double n2 = 0.0;
+      for (int j = 0; j < Gs * m; ++j) n2 += c->h_resid[j];
+      stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / Gs / znorm2) : 0.0;
+      stop = stt.rel < prm.adi_newZ_reltol;
+    }
+    c->zc += kept * m;
+    steps += kept;
     stt.steps = steps;
-    stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / G / znorm2) : 0.0;
     lap(c->t_recomb);
     if (prm.verbose) {
       int its = 0;
-      for (int g = 0; g < G; ++g) its = std::max(its, res[g].iters);
+      for (int g = 0; g < Gs; ++g) its = std::max(its, res[g].iters);
       fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d\n",
-              sw + 1, steps - G + 1, steps, stt.rel, its);
+              sw + 1, steps - Gs + 1, steps, stt.rel, its);
     }
-    if (stt.rel < prm.adi_newZ_reltol) break;
+    if (stop) break;
+    if (steps >= prm.adi_max_steps) break;
     if (prm.compress_cols > 0 && c->zc - zc_last >= prm.compress_cols) {
       if (sync_recompress) {
         factor_recompress(c);

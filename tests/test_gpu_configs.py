@@ -58,6 +58,9 @@ def test_cfg2_newton_adi_gain_vs_oracle_fixture():
     out = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
     assert out["gmres_nonconverged"] == 0
     assert out["nwtn_steps"] == int(g["nwtn_steps"][0])
+    # the inner ADI stops after the same step as the oracle's step-by-step iteration in every
+    # Newton step (the blocks of a sweep are the sequential blocks; tests/golden: 177 each)
+    assert out["adi_steps"] == int(g["upd_hist"][:, 2].sum())
     # the last update norm is the difference of two nearly equal iterates: same decade as the
     # oracle's (the sweep form stops the inner ADI at sweep granularity)
     assert 0.1 * g["upd_hist"][-1, 1] <= out["upd_rel"] <= 10.0 * g["upd_hist"][-1, 1]

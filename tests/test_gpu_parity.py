@@ -484,7 +484,7 @@ def test_batched_shift_solve_matches_single():
         Xh = X.cpu().numpy()
         for g, p in enumerate(ps):
             Xs, it1, rr1 = ctx.shift_solve(p, 1.0, R[0 if shared else g])
-            assert abs(it1 - its[g]) <= max(2, 0.4 * it1)
+            assert abs(it1 - its[g]) <= max(2, 0.75 * max(it1, its[g]))
             assert rel(Xh[g], Xs) < 1e-8
     ctx.close()
 
@@ -544,11 +544,16 @@ def test_cpp_sweep_adi_matches_stepwise_adi():
         Zs, i2 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, sweep_width=G)))
         assert i1["adi_steps"] == i2["adi_steps"] == 24 and Zs.shape == Z1.shape
         assert rel(Zs @ (Zs.T @ B), Z1 @ (Z1.T @ B)) < 1e-8
-    # stopping rule at sweep granularity
+    # stopping rule at sweep granularity; the last sweeps are narrowed (2 / 4 / 8 steps) when the
+    # decay of the block norms predicts that fewer than a full sweep is still needed
     d = dict(adi_max_steps=200, adi_newZ_reltol=1e-8, ms=ms)
     Z1, i1 = ctx.lyap_adi(ms, W, _lib.adi_params(d))
     Zs, i2 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(d, sweep_width=8)))
-    assert i2["adi_steps"] % 8 == 0 and abs(i2["adi_steps"] - i1["adi_steps"]) <= 16
+    assert i2["adi_rel_newZ"] < 1e-8 and i2["adi_steps"] == i1["adi_steps"]     # the reference's rule, step for step
+    # a step budget that is no multiple of the sweep width is used up to the last step
+    Zp, i3 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(adi_max_steps=21, adi_newZ_reltol=0.0, ms=ms, sweep_width=8)))
+    Zq, i4 = ctx.lyap_adi(ms, W, _lib.adi_params(dict(adi_max_steps=21, adi_newZ_reltol=0.0, ms=ms)))
+    assert i3["adi_steps"] == i4["adi_steps"] == 21 and rel(Zp @ (Zp.T @ B), Zq @ (Zq.T @ B)) < 1e-8
     assert rel(Zs @ (Zs.T @ B), Z1 @ (Z1.T @ B)) < 1e-6
     # repeated shifts: no sweeps possible, the result is the step-by-step one
     ms_rep = np.r_[ms[:4], ms[:4]]
