@@ -265,10 +265,13 @@ int ricadi_sweep_recombine_dev(ricadi_ctx* ctx, int G, const double* dU, int m,
  * C^-1 1 of the shift each slot carries (zero rows for padding slots and for slots that
  * belong to another column part):  dZ (NV x G*m) = sum_i coefz[i][:] (x) U_i,
  * dW (NV x m) += E sum_i coefw[i] U_i.  The data are consumed where the collective put
- * them; only the small coefficient table is permuted.                                  */
+ * them; only the small coefficient table is permuted.  block_n2_out (G doubles, may be
+ * NULL): squared Frobenius norm of every column block of dZ -- with coefz the rows of the
+ * upper triangular R^-1 these are the blocks of the step-by-step iteration, which is what
+ * the reference's stopping rule looks at.                                               */
 int ricadi_sweep_recombine_slots_dev(ricadi_ctx* ctx, int nslot, int G, const double* dU, int m,
                                      const double* coefz, const double* coefw,
-                                     double* dZ, double* dW, double* n2_out);
+                                     double* dZ, double* dW, double* n2_out, double* block_n2_out);
 /* dK (NV x nb) = coef * E * (Z * (Z^T B)) for a device-resident factor dZ
  * (NV x c, row-major with leading dimension ldz) and dB (NV x nb).          */
 int ricadi_gain_dev(ricadi_ctx* ctx, double coef, const double* dZ, int c, int ldz,

@@ -83,7 +83,7 @@ SIGNATURES = {
     "ricadi_sweep_recombine_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _dp, _dp, _vp, _vp,
                                              C.POINTER(C.c_double)]),
     "ricadi_sweep_recombine_slots_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _dp, _dp, _vp, _vp,
-                                                   C.POINTER(C.c_double)]),
+                                                   C.POINTER(C.c_double), _dp]),
     "ricadi_apply_e_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_lincomb_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64, _dp, _vp]),
     "ricadi_gain_dev": (C.c_int, [_vp, C.c_double, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
@@ -527,9 +527,10 @@ class Context:
         if cz.shape != (nslot, G) or cw.shape != (nslot,):
             raise ValueError("coefficient tables do not match (nslot, G)")
         n2 = C.c_double(0.0)
+        bn = np.zeros(int(G))
         _chk(self._lib.ricadi_sweep_recombine_slots_dev(self._h, int(nslot), int(G), u_ptr, m, _d(cz),
-                                                        _d(cw), z_ptr, w_ptr, C.byref(n2)))
-        return n2.value
+                                                        _d(cw), z_ptr, w_ptr, C.byref(n2), _d(bn)))
+        return n2.value, bn
 
     def apply_e_dev(self, coef, v_ptr, m, w_ptr):
         _chk(self._lib.ricadi_apply_e_dev(self._h, coef, v_ptr, m, w_ptr))

@@ -2347,7 +2347,7 @@ int ricadi_lincomb_dev(ricadi_ctx* c, int nrows, int m, int nvec, const double* 
 
 int ricadi_sweep_recombine_slots_dev(ricadi_ctx* c, int nslot, int G, const double* dU, int m,
                                      const double* coefz, const double* coefw, double* dZ, double* dW,
-                                     double* n2_out) {
+                                     double* n2_out, double* block_n2_out) {
   if (int rc = check_panel(c, m)) return rc;
   REQUIRE(dU && coefz && coefw && dZ && dW && n2_out, RICADI_EINVAL, "NULL argument");
   REQUIRE(G >= 1 && G <= 64 && nslot >= 1 && nslot <= 128 && G * m <= 2048, RICADI_EINVAL,
@@ -2387,12 +2387,18 @@ int ricadi_sweep_recombine_slots_dev(ricadi_ctx* c, int nslot, int G, const doub
   double n2 = 0.0;
   for (double v : nr) n2 += v;
   *n2_out = n2;
+  if (block_n2_out)
+    for (int j = 0; j < G; ++j) {
+      double b2 = 0.0;
+      for (int cc = 0; cc < m; ++cc) b2 += nr[(size_t)j * m + cc];
+      block_n2_out[j] = b2;
+    }
   API_END
 }
 
 int ricadi_sweep_recombine_dev(ricadi_ctx* c, int G, const double* dU, int m, const double* rinv,
                                const double* cinv1, double* dZ, double* dW, double* n2_out) {
-  return ricadi_sweep_recombine_slots_dev(c, G, G, dU, m, rinv, cinv1, dZ, dW, n2_out);
+  return ricadi_sweep_recombine_slots_dev(c, G, G, dU, m, rinv, cinv1, dZ, dW, n2_out, nullptr);
 }
 
 int ricadi_gain_dev(ricadi_ctx* c, double coef, const double* dZ, int cz, int ldz, const double* dB,

@@ -152,9 +152,9 @@ class HipOps:
         G = np.asarray(coefz).shape[1]
         Zb = self.empty(nv, G * m)
         self._sync_in()
-        n2 = self.ctx.sweep_recombine_slots_dev(nslot, G, U_all.data_ptr(), m, coefz, coefw,
-                                                Zb.data_ptr(), W.data_ptr())
-        return Zb, n2
+        n2, bn = self.ctx.sweep_recombine_slots_dev(nslot, G, U_all.data_ptr(), m, coefz, coefw,
+                                                    Zb.data_ptr(), W.data_ptr())
+        return Zb, n2, bn
 
     def to_panel(self, W):
         return torch.as_tensor(np.ascontiguousarray(W), dtype=torch.float64).to(self.device)
@@ -176,7 +176,8 @@ class HipOps:
 
     def recombine(self, U_all, rinv, cinv1, W):
         """Recombination with the solutions in sweep order (``U_all``: G x NV x m)."""
-        return self.recombine_slots(U_all, np.asarray(rinv), np.asarray(cinv1), W)
+        Zb, n2, _ = self.recombine_slots(U_all, np.asarray(rinv), np.asarray(cinv1), W)
+        return Zb, n2
 
     def lincomb(self, coef, U_all):
         """``sum_i coef[i] * U_all[i]``; ``U_all`` is G x NV x m, contiguous."""
@@ -246,20 +247,27 @@ def item_layout(G, parts, world):
 
 
 def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
-                            group=None, width=None, max_width=8, verbose=False, col_parts=0):
+                            group=None, width=None, max_width=8, verbose=False, col_parts=0,
+                            stop_rule="step"):
     """Shift-parallel LR-ADI; returns ``(Z_blocks, info)``.
 
     ``W`` is the (already projected) NV x m residual factor as a tensor on the
-    ops' device, replicated on every rank.  Each sweep handles ``G`` distinct
+    ops' device, replicated on every rank.  Each sweep handles up to ``G`` distinct
     shifts, ``G = width`` or ``min(world_size, len(ms), max_width)`` (Cauchy
     conditioning limits ``G``: SURVEY.md F8).  The sweep's work items -- (shift,
     column part) pairs, :func:`plan_items` / :func:`item_layout` -- are dealt to the
     ranks; a rank solves all its items in ONE batched solve, the solutions are
     all-gathered into one preallocated rank-major buffer that the recombination
     reads in place (the Cauchy coefficients are permuted, not the data).
-    Stops after the sweep in which the mean new-block norm falls below
-    ``adi_newZ_reltol`` (the sequential rule of ``optcont_main.py:123-124`` at
-    sweep granularity) or after ``adi_max_steps`` steps.
+
+    Stopping (``stop_rule="step"``): with ``C = R^T R``, column block ``j`` of ``U R^-1`` lies
+    in ``span{U_1..U_j}`` -- it is the block the step-by-step iteration appends at step ``j``
+    -- so the reference's rule, relative norm of the new block below ``adi_newZ_reltol``
+    (``optcont_main.py:123-124``), is applied block by block: the iteration ends after the
+    same step as the sequential one and the blocks behind it are dropped.  The block norms
+    of the last two passes over the shift cycle predict the stopping step, and the sweep
+    that would contain it is cut there.  ``stop_rule="sweep"``: mean block norm per sweep.
+    Rank 0 takes the decisions for everybody.
     """
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
@@ -284,67 +292,108 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
     if m % parts:
         raise ValueError("panel width {0} is not divisible into {1} column parts".format(m, parts))
     mp_ = m // parts
-    items, per_rank = item_layout(G, parts, world)
-    mine = [it for it in items if it["rank"] == rank]
-    nslot = world * per_rank
     # residual factor kept as `parts` contiguous NV x m' panels (the right-hand sides of the
     # items and the operands of the recombination)
     Wq = [W[:, q * mp_:(q + 1) * mp_].contiguous().clone() for q in range(parts)]
-    U_loc = W.new_zeros((per_rank, nv, mp_))          # padding slots stay zero
-    U_all = W.new_zeros((nslot, nv, mp_)) if world > 1 else U_loc
+    buffers = {}                      # per sweep width: (items, per_rank, U_loc, U_all)
+
+    def layout(g):
+        if g not in buffers:
+            items, per_rank = item_layout(g, parts, world)
+            U_loc = W.new_zeros((per_rank, nv, mp_))          # padding slots stay zero
+            U_all = W.new_zeros((world * per_rank, nv, mp_)) if world > 1 else U_loc
+            buffers[g] = (items, per_rank, U_loc, U_all)
+        return buffers[g]
+
+    step_rule = stop_rule == "step" and adi_newZ_reltol > 0.0
+    rel_h1, rel_h2 = np.zeros(ns), np.zeros(ns)
     blocks = []
     znorm2 = 0.0
     steps = 0
     rel = float("inf")
     nsweeps = 0
-    while steps + G <= adi_max_steps or steps == 0:
-        ps = sweep_shifts(ms, nsweeps, G)
-        if len(set(ps)) != G:
+    items_solved = 0
+    while steps < adi_max_steps:
+        # width of this sweep: cut at the predicted stopping step (see the docstring)
+        g_now = min(G, adi_max_steps - steps)
+        if step_rule:
+            for g in range(g_now):
+                pos = (steps + g) % ns
+                if rel_h1[pos] > 0.0 and rel_h2[pos] > rel_h1[pos] and \
+                        rel_h1[pos] * (rel_h1[pos] / rel_h2[pos]) < adi_newZ_reltol:
+                    g_now = g + 1
+                    break
+        if world > 1:
+            gw = W.new_tensor([float(g_now)])
+            dist.broadcast(gw, src=0, group=group)
+            g_now = int(round(gw.item()))
+        ps = [float(ms[(steps + g) % ns]) for g in range(g_now)]
+        if len(set(ps)) != g_now:
             raise ValueError("shifts within one sweep must be distinct: {0}".format(ps))
+        items, per_rank, U_loc, U_all = layout(g_now)
+        mine = [it for it in items if it["rank"] == rank]
+        nslot = world * per_rank
         if hasattr(ops, "solve_items"):
             ops.solve_items([(ps[it["g"]], Wq[it["q"]]) for it in mine], U_loc)
         else:
             for it in mine:
                 U_loc[it["slot"]].copy_(ops.solve(ps[it["g"]], Wq[it["q"]]))
+        items_solved += len(mine)
         if world > 1:
             dist.all_gather_into_tensor(U_all.view(-1), U_loc.view(-1), group=group)
         rinv, cinv1 = _lib.host_cauchy(ps)
-        n2 = 0.0
+        bn2 = np.zeros(g_now)             # squared norm of every (sequential) block of the sweep
         zparts = []
         for q in range(parts):
             # coefficients in BUFFER order: slot `pos` carries shift g (other parts / padding: 0)
-            coefz = np.zeros((nslot, G))
+            coefz = np.zeros((nslot, g_now))
             coefw = np.zeros(nslot)
             for it in items:
                 if it["q"] == q:
                     coefz[it["pos"], :] = rinv[it["g"], :]
                     coefw[it["pos"]] = cinv1[it["g"]]
             if hasattr(ops, "recombine_slots"):
-                Zq, n2q = ops.recombine_slots(U_all, coefz, coefw, Wq[q])
-                zparts.append(Zq)
-                n2 += n2q
+                Zq, _, bq = ops.recombine_slots(U_all, coefz, coefw, Wq[q])
+                zparts.append([Zq[:, j * mp_:(j + 1) * mp_] for j in range(g_now)])
+                bn2 += np.asarray(bq)
             else:
-                for j in range(G):
+                zj = []
+                for j in range(g_now):
                     Zj = ops.lincomb(coefz[:, j], U_all)
-                    n2 += ops.fro2(Zj)
-                    zparts.append(Zj)
+                    bn2[j] += ops.fro2(Zj)
+                    zj.append(Zj)
+                zparts.append(zj)
                 T = ops.lincomb(coefw, U_all)
                 ops.apply_E(1.0, T, Wq[q])
-        blocks.extend(zparts)
-        znorm2 += n2
-        steps += G
-        nsweeps += 1
-        rel = float(np.sqrt(n2 / G / znorm2)) if znorm2 > 0 else 0.0
-        if verbose and rank == 0:
-            print("sweep {0:3d}: shifts {1} rel new Z {2:9.3e}".format(nsweeps, ps, rel))
-        stop = rel < adi_newZ_reltol
+        # stopping decision (rank 0's numbers: the norms come from kernels with atomic
+        # accumulation, ranks may differ in the last bits and must not disagree)
+        kept, stop = g_now, False
+        if step_rule:
+            z2 = znorm2
+            for j in range(g_now):
+                z2 += bn2[j]
+                rel = float(np.sqrt(bn2[j] / z2)) if z2 > 0 else 0.0
+                pos = (steps + j) % ns
+                rel_h2[pos], rel_h1[pos] = rel_h1[pos], rel
+                if rel < adi_newZ_reltol:
+                    kept, stop = j + 1, True
+                    break
+        else:
+            n2 = float(bn2.sum())
+            rel = float(np.sqrt(n2 / g_now / (znorm2 + n2))) if znorm2 + n2 > 0 else 0.0
+            stop = rel < adi_newZ_reltol
         if world > 1:
-            # The norms above come from kernels with atomic accumulation: ranks may
-            # differ in the last bits and must not disagree on leaving the loop
-            # (the next all-gather would hang).  Rank 0 decides for everybody.
-            flag = W.new_tensor([1.0 if stop else 0.0])
-            dist.broadcast(flag, src=0, group=group)
-            stop = bool(flag.item() > 0.5)
+            dec = W.new_tensor([float(kept), 1.0 if stop else 0.0, rel])
+            dist.broadcast(dec, src=0, group=group)
+            kept, stop, rel = int(round(dec[0].item())), bool(dec[1].item() > 0.5), float(dec[2].item())
+        znorm2 += float(bn2[:kept].sum())
+        for j in range(kept):
+            for q in range(parts):
+                blocks.append(zparts[q][j])
+        steps += kept
+        nsweeps += 1
+        if verbose and rank == 0:
+            print("sweep {0:3d}: {1} shifts, kept {2}, rel new Z {3:9.3e}".format(nsweeps, g_now, kept, rel))
         if stop:
             break
     Wend = Wq[0] if parts == 1 else torch.cat(Wq, dim=1).contiguous()
@@ -352,14 +401,14 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
                 res_fro=ops.gram_fro(Wend), resfac=Wend,
                 gmres_nonconverged=int(getattr(ops, "nonconverged", 0)),
                 gmres_worst_relres=float(getattr(ops, "worst_relres", 0.0)),
-                shift_solves=int(getattr(ops, "shift_solves", 0)))
+                shift_solves=items_solved / float(parts))
     if world > 1:
         # a rank only sees its own solves: the counts are summed, the worst residual maximised
         t = W.new_tensor([info["gmres_nonconverged"], info["shift_solves"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         w = W.new_tensor([info["gmres_worst_relres"]], dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX, group=group)
-        info["gmres_nonconverged"], info["shift_solves"] = int(t[0].item()), int(t[1].item())
+        info["gmres_nonconverged"], info["shift_solves"] = int(t[0].item()), float(t[1].item())
         info["gmres_worst_relres"] = float(w.item())
     if info["gmres_nonconverged"] and rank == 0:
         _lib._warn_nonconverged(info)

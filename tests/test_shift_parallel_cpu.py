@@ -120,6 +120,30 @@ def test_column_split_equals_sequential(G, parts):
     assert np.isclose(info["res_fro"], Zs["res_hist"][-1], rtol=1e-8, atol=1e-18)
 
 
+@pytest.mark.parametrize("G,parts", [(4, 1), (8, 2)])
+def test_stops_after_the_same_step_as_the_sequential_iteration(G, parts):
+    """The blocks of a sweep are the blocks of the step-by-step iteration, so the reference's
+    rule (relative norm of the new block, optcont_main.py:123-124) ends the sweep form after
+    exactly the oracle's step; the sweep containing that step is cut short by prediction or
+    its surplus blocks are dropped."""
+    pr, F, W, tb = _problem()
+    ms = pb.logshifts(1.0, 500.0, 8)
+    for tol in (1e-6, 1e-9):
+        d = dict(adi_max_steps=200, adi_newZ_reltol=tol, ms=ms)
+        Zs = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=W, adi_dict=d)
+        ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+        blocks, info = lyap_adi_shift_parallel(ops, ms, torch.from_numpy(W.copy()), adi_max_steps=200,
+                                               adi_newZ_reltol=tol, width=G, col_parts=parts)
+        Zb = torch.cat(blocks, dim=1).numpy()
+        assert info["adi_steps"] == Zs["adi_steps"] and Zb.shape == Zs["zfac"].shape
+        Xs = Zs["zfac"] @ Zs["zfac"].T
+        assert np.linalg.norm(Zb @ Zb.T - Xs) <= 1e-10 * np.linalg.norm(Xs)
+        # the old sweep-granular rule is still there and never stops earlier
+        _, info2 = lyap_adi_shift_parallel(ops, ms, torch.from_numpy(W.copy()), adi_max_steps=200,
+                                           adi_newZ_reltol=tol, width=G, col_parts=parts, stop_rule="sweep")
+        assert info2["adi_steps"] >= info["adi_steps"] and info2["adi_steps"] % G == 0
+
+
 def test_rejects_repeated_shift_in_sweep():
     pr, F, W, tb = _problem(4)
     ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
