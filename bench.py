@@ -197,10 +197,11 @@ def gram_mfma(ctx, nv, c, reps=20):
 
 
 def tsqr_mfma(ctx, nv, c, reps=3):
-    """K5 (TSQR route, north_star's "MFMA utilisation on the TSQR"): thin QR of an NV x c factor
-    by ricadi_qr's device path -- Householder TSQR panels (LDS) inside a block Gram-Schmidt on
-    the MFMA GEMMs.  Algorithmic flops 2 NV c^2 - 2/3 c^3 over the whole
-    factorisation's duration (HIP events)."""
+    """K5 (tall-skinny QR, north_star's "MFMA utilisation on the TSQR"): thin QR of an NV x c factor
+    by ricadi_qr's device path -- 32-column panels by CholQR2 on the MFMA GEMMs (Householder
+    TSQR tree when a panel is too ill-conditioned for it) inside a block Gram-Schmidt with
+    re-orthogonalisation, also on the MFMA GEMMs.  Algorithmic flops 2 NV c^2 - 2/3 c^3
+     over the whole factorisation's duration (HIP events)."""
     import torch
     z = torch.randn(nv, c, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
@@ -210,7 +211,8 @@ def tsqr_mfma(ctx, nv, c, reps=3):
     tf = flops / (med * 1e-3) / 1e12
     return dict(bound="mfma", achieved=round(tf, 3), peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
                 frac=round(tf / FP64_MFMA_PEAK_TF, 4),
-                kernel="ricadi block QR: tsqr_local/tsqr_apply (LDS Householder) + gemm_tn/gemm_nn (MFMA)",
+                kernel="ricadi block QR: CholQR2 panels (gemm_tn / gemm_nn on MFMA + cholqr_small) inside block "
+                       "Gram-Schmidt (gemm_tn / gemm_nn); Householder TSQR tree as fallback",
                 ms_per_factorisation=round(med, 2), ms_best=round(best, 2), nv=int(nv), c=int(c))
 
 
@@ -244,7 +246,7 @@ def cpu_baseline(pr, ms, m, adi_steps, full=False):
     M = pr.M.T.tocsr()
     R = np.random.default_rng(0).standard_normal((pr.NV, m))
     ns = len(ms)
-    per_shift = max(1, adi_steps // ns)
+    per_shift = max(1, -(-adi_steps // ns))
     pick = list(ms) if full else [ms[0], ms[ns // 3], ms[(2 * ns) // 3], ms[-1]]
     nsol_each = per_shift if full else 2
     t_lu, t_sol = 0.0, 0.0

@@ -367,8 +367,11 @@ def test_two_ranks_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     errs = [float(x) for x in re.findall(r"K rel diff vs golden ([0-9.e+-]+)", out.stdout)]
     solves = [int(x) for x in re.findall(r"local solves (\d+)", out.stdout)]
+    steps = [int(x) for x in re.findall(r"(\d+) ADI steps", out.stdout)]
     assert len(errs) == 2 and max(errs) < K_TOL
-    assert len(solves) == 2 and solves[0] == solves[1] and solves[0] > 0
+    # the two ranks share the work (sweeps cut at the stopping step may leave one item of difference
+    # per sweep); together they solved every ADI step once
+    assert len(solves) == 2 and min(solves) > 0 and steps[0] == steps[1] <= sum(solves) <= steps[0] + 16
 
 
 @pytest.mark.parametrize("n,c", [(300, 7), (3000, 70), (26450, 456)])
