@@ -253,6 +253,18 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsH& Einv,
                           const GroupPtrs& rowscale, const double* rc, double* ec);
 void launch_to_f16_tiled(hipStream_t st, int k, const double* src, double* rowscale, _Float16* dst);
+// rectangular block sweep  out[rows_b] (-)= mats[b] (bs x ks) * in[irows_b]  (+ fused prolongation)
+bool block_apply_rect_ok(int bs, int ks);
+void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                               const int* bptr, const int* rows, const int* iptr, const int* irows,
+                               const GroupPtrs& mats, const double* in, int ldi, size_t gsi, double* out,
+                               int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa);
+void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                               const int* bptr, const int* rows, const int* iptr, const int* irows,
+                               const GroupPtrsF& mats, const double* in, int ldi, size_t gsi, double* out,
+                               int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa);
+void launch_gt_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* jtd,
+                      const GroupPtrs& ainv, const GroupPtrs& out);
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,
                    int ldd);
 void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst);

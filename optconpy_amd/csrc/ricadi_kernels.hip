@@ -1415,6 +1415,148 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
                    ci);
 }
 
+// ---------------------------------------------------------------------------
+// K2, rectangular form: the last velocity sweep of the SIMPLE cycle,
+//     z_v[rows_b] -= G_b * z_p[pcols_b],      G_b = Ahat_b^-1 * J^T[rows_b, pcols_b]   (BS x KS)
+// with the per-shift product G_b formed once at setup (gt_blocks_kernel) from the block-Jacobi
+// inverse and the dense slice of J^T over the block's rows and the pressure dofs they touch.
+// Replaces the same sweep with the J^T rows gathered entry by entry inside the kernel (CsrInArgs:
+// ~17 dependent loads per operand element, 89 us per 16-group launch at cfg2 against 34 us for
+// a plain sweep).  One wave per block, FP64 MFMA 16x16x4 as in block_apply_kernel; the input
+// rows come from their own list (pressure-local indices), the output rows from the block's.
+// ---------------------------------------------------------------------------
+template <int BS, int KS, class T>
+__global__ __launch_bounds__(256) void block_apply_rect_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
+    const int* __restrict__ iptr, const int* __restrict__ irows, GroupPtrsT<T> mats,
+    const double* __restrict__ in, int ldi, size_t gsi, double* __restrict__ out, int ldo,
+    size_t gso, int m, int subtract, ProlongArgs pa) {
+  const int grp = gt.gid[blockIdx.z];
+  const T* __restrict__ mat = mats.p[grp];
+  in += (size_t)grp * gsi;
+  out += (size_t)grp * gso;
+  const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  if (wave >= nblocks) {
+    // surplus waves: coarse-level prolongation of the rows outside the blocks
+    const int e0 = (wave - nblocks) * 32;
+    for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
+      const int row = pa.row0 + rr;
+      for (int col = r; col < m; col += 16)
+        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+    }
+    return;
+  }
+  const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
+  const int i0 = iptr[wave], ni = iptr[wave + 1] - i0;
+  const T* Gi = mat + (size_t)wave * BS * KS;
+  constexpr int NT = BS / 16, NK = KS / 16;
+  for (int c0 = 0; c0 < m; c0 += 16) {
+    const int col = c0 + r;
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) {
+      if (kc * 16 >= ni) break;                 // wave-uniform: chunks beyond the block's inputs
+      double xb[4];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int kk = kc * 16 + 4 * q + s2;
+        xb[s2] = (kk < ni && col < m) ? in[(size_t)irows[i0 + kk] * ldi + col] : 0.0;
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        double a4[4];
+        load4(Gi + (size_t)(16 * t + r) * KS + kc * 16 + 4 * q, a4);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xb[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xb[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xb[2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xb[3], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int il = 16 * t + q + 4 * e;
+        if (il < nb && col < m) {
+          const int row = rows[b0 + il];
+          double* o = &out[(size_t)row * ldo + col];
+          double v = subtract ? *o - acc[t][e] : acc[t][e];
+          if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
+          *o = v;
+        }
+      }
+  }
+}
+template <class T>
+static void block_apply_rect_impl(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                                  const int* bptr, const int* rows, const int* iptr, const int* irows,
+                                  const GroupPtrsT<T>& mats, const double* in, int ldi, size_t gsi, double* out,
+                                  int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa) {
+  if (nblocks <= 0 || gt.ng <= 0) return;
+  const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
+  dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
+#define RICADI_RECT(B, K)                                                                           \
+  hipLaunchKernelGGL((block_apply_rect_kernel<B, K, T>), grid, block, 0, st, gt, nblocks, bptr, rows, \
+                     iptr, irows, mats, in, ldi, gsi, out, ldo, gso, m, subtract, pa)
+  if (bs == 32 && ks == 32) RICADI_RECT(32, 32);
+  else if (bs == 32 && ks == 64) RICADI_RECT(32, 64);
+  else if (bs == 16 && ks == 32) RICADI_RECT(16, 32);
+  else if (bs == 16 && ks == 64) RICADI_RECT(16, 64);
+  else if (bs == 64 && ks == 64) RICADI_RECT(64, 64);
+  else RICADI_RECT(64, 128);
+#undef RICADI_RECT
+}
+bool block_apply_rect_ok(int bs, int ks) {
+  return (bs == 32 && (ks == 32 || ks == 64)) || (bs == 16 && (ks == 32 || ks == 64)) ||
+         (bs == 64 && (ks == 64 || ks == 128));
+}
+void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                               const int* bptr, const int* rows, const int* iptr, const int* irows,
+                               const GroupPtrs& mats, const double* in, int ldi, size_t gsi, double* out,
+                               int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa) {
+  block_apply_rect_impl(st, gt, bs, ks, nblocks, bptr, rows, iptr, irows, mats, in, ldi, gsi, out, ldo, gso, m,
+                        subtract, pa);
+}
+void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                               const int* bptr, const int* rows, const int* iptr, const int* irows,
+                               const GroupPtrsF& mats, const double* in, int ldi, size_t gsi, double* out,
+                               int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa) {
+  block_apply_rect_impl(st, gt, bs, ks, nblocks, bptr, rows, iptr, irows, mats, in, ldi, gsi, out, ldo, gso, m,
+                        subtract, pa);
+}
+
+// G[b] = Ainv[b] (bs x bs) * JTd[b] (bs x ks)  for every velocity block b and every shift of the
+// setup (blockIdx.y); JTd is the dense slice of J^T (shift independent).  One workgroup per block.
+__global__ __launch_bounds__(256) void gt_blocks_kernel(int bs, int ks, const double* __restrict__ jtd,
+                                                        GroupPtrs ainvs, GroupPtrs outs) {
+  extern __shared__ double sm[];            // Ai (bs x bs), Jd (bs x ks)
+  double* Ai = sm;
+  double* Jd = sm + bs * bs;
+  const double* __restrict__ ainv = ainvs.p[blockIdx.y] + (size_t)blockIdx.x * bs * bs;
+  const double* __restrict__ jsrc = jtd + (size_t)blockIdx.x * bs * ks;
+  double* __restrict__ out = const_cast<double*>(outs.p[blockIdx.y]) + (size_t)blockIdx.x * bs * ks;
+  for (int e = threadIdx.x; e < bs * bs; e += 256) Ai[e] = ainv[e];
+  for (int e = threadIdx.x; e < bs * ks; e += 256) Jd[e] = jsrc[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < bs * ks; e += 256) {
+    const int i = e / ks, j = e - i * ks;
+    double sacc = 0.0;
+    for (int t = 0; t < bs; ++t) sacc = fma(Ai[i * bs + t], Jd[t * ks + j], sacc);
+    out[e] = sacc;
+  }
+}
+void launch_gt_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* jtd,
+                      const GroupPtrs& ainv, const GroupPtrs& out) {
+  if (nblocks <= 0 || nshift <= 0) return;
+  hipLaunchKernelGGL(gt_blocks_kernel, dim3(nblocks, nshift), dim3(256),
+                     (size_t)(bs * bs + bs * ks) * sizeof(double), st, bs, ks, jtd, ainv, out);
+}
+
 // blocks[b] = alpha*Be[b] + beta*Ba[b]  (dense, bs x bs each)
 __global__ void block_combine_kernel(size_t n, const double* Ba, const double* Be, double alpha,
                                      double beta, double* out) {

@@ -184,6 +184,9 @@ struct ShiftData {
   // operator either way; halves its HBM traffic).  einvf is stored in 16 x 16 tiles
   // (dense_apply_tiled_kernel).  RICADI_PRECOND64=1 applies the FP64 originals instead.
   DArr<float> bvinvf, bpinvf, einvf;
+  // G_b = Ahat_b^-1 J^T[rows_b, pcols_b] of the last velocity sweep (block_apply_rect_kernel)
+  DArr<double> gtm;
+  DArr<float> gtmf;
   // FP16 copy of the coarse inverse with one scale per row (default; RICADI_COARSE16=0: FP32)
   DArr<_Float16> einvh;
   DArr<double> einvs;
@@ -236,6 +239,12 @@ struct ricadi_ctx {
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
   DArr<double> bvA, bvE, jd_val;
   DArr<int> agg_ptr, agg_rows, aggof;
+  // last velocity sweep in rectangular form: per velocity block the pressure dofs its rows touch
+  // and the dense slice of J^T over (block rows x those dofs); gt_ks = padded slice width
+  bool gt_ok = false;
+  int gt_ks = 0;
+  DArr<int> gt_ptr, gt_cols;
+  DArr<double> gt_jtd;
   DArr<double> E0, EM, EJ, ones;
   // prolongated operator S*Y (CSR, n x kc) for the residual after the coarse correction
   size_t synnz = 0;
@@ -422,6 +431,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     stable_alloc(sd->bvinv, (size_t)c->nbv * bsz);
     launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
     if (c->nbp > 0) stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
+    if (c->gt_ok) stable_alloc(sd->gtm, (size_t)c->nbv * c->bs * c->gt_ks);
     if (k > 0) {
       stable_alloc(sd->einv, (size_t)k * k);
       launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
@@ -443,6 +453,11 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       pp.p[i] = todo[t0 + i]->bpinv.p;
     }
     launch_block_invert(st, cnt, c->nbv, c->bs, c->bv_ptr.p, pv, c->flag.p);
+    if (c->gt_ok) {
+      GroupPtrs pg = same_ptr((const double*)nullptr);
+      for (int i = 0; i < cnt; ++i) pg.p[i] = todo[t0 + i]->gtm.p;
+      launch_gt_blocks(st, cnt, c->nbv, c->bs, c->gt_ks, c->gt_jtd.p, pv, pg);
+    }
     if (c->nbp > 0) {
       launch_schur_blocks_bj(st, cnt, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p,
                              c->jd_val.p, pv, pp);
@@ -504,6 +519,11 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         if (sd->bpinvf.n != sd->bpinv.n) sd->bpinvf.alloc(sd->bpinv.n);
         launch_to_f32(st, c->nbp, bs2, sd->bpinv.p, bs2, sd->bpinvf.p, bs2);
       }
+      if (c->gt_ok) {
+        const int gsz = c->bs * c->gt_ks;
+        if (sd->gtmf.n != sd->gtm.n) sd->gtmf.alloc(sd->gtm.n);
+        launch_to_f32(st, c->nbv, gsz, sd->gtm.p, gsz, sd->gtmf.p, gsz);
+      }
       if (k > 0) {
         const size_t kp = (size_t)(k + 15) / 16;
         if (c->coarse16) {
@@ -539,7 +559,8 @@ struct Batch {
   GroupPtrs sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
   GroupPtrsH einvh;
-  GroupPtrs einvs;
+  GroupPtrs einvs, gtm;
+  GroupPtrsF gtmf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
   void all() {
@@ -564,7 +585,8 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.sval = bt.svalb = bt.syval = bt.syvalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   bt.einvh = same_ptr((const _Float16*)nullptr);
-  bt.einvs = same_ptr((const double*)nullptr);
+  bt.einvs = bt.gtm = same_ptr((const double*)nullptr);
+  bt.gtmf = same_ptr((const float*)nullptr);
   for (int g = 0; g < RICADI_MAX_GROUPS; ++g) bt.alpha[g] = bt.beta[g] = 0.0;
   for (int g = 0; g < G; ++g) {
     bt.alpha[g] = sds[g]->alpha;
@@ -574,6 +596,8 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
     bt.einvf.p[g] = sds[g]->einvf.p;
     bt.einvh.p[g] = sds[g]->einvh.p;
     bt.einvs.p[g] = sds[g]->einvs.p;
+    bt.gtm.p[g] = sds[g]->gtm.p;
+    bt.gtmf.p[g] = sds[g]->gtmf.p;
     bt.sval.p[g] = sds[g]->sval.p;
     bt.syval.p[g] = sds[g]->syval.p;
     bt.syvalb.p[g] = sds[g]->syvalb.p;
@@ -741,7 +765,17 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks; the
     // J^T product is formed inside the sweep, row by row as the blocks gather them
     // (z_p is small and L2 resident), instead of through an intermediate panel
-    if (fuse_jt) {
+    static const bool rect = getenv("RICADI_NO_RECT") == nullptr;
+    if (fuse_jt && rect && c->gt_ok) {
+      // z_v -= G z_p with the per-shift blocks G_b = Ahat_b^-1 J^T[rows_b, pcols_b] formed at setup
+      pro.nextra = 0;            // the pressure rows already carry their coarse part
+      if (c->precond32)
+        launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
+                                  c->gt_cols.p, bt.gtmf, c->tp.p, m, bt.gsp, z, m, bt.gs, m, 1, pro);
+      else
+        launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
+                                  c->gt_cols.p, bt.gtm, c->tp.p, m, bt.gsp, z, m, bt.gs, m, 1, pro);
+    } else if (fuse_jt) {
       CsrInArgs cin;
       cin.rp = c->JT.rp.p;
       cin.ci = c->JT.ci.p;
@@ -2000,6 +2034,50 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->J.upload(J, st);
   HostCsr JT = transpose(J);
   c->JT.upload(JT, st);
+  {
+    // rectangular last sweep: pressure dofs touched by every velocity block, dense J^T slices
+    c->gt_ok = false;
+    if (np > 0 && hs.nbv > 0) {
+      std::vector<int> gptr(hs.nbv + 1, 0), gcols;
+      int kmax = 0;
+      std::vector<int> tmp;
+      for (int b = 0; b < hs.nbv; ++b) {
+        tmp.clear();
+        for (int q = hs.bv_ptr[b]; q < hs.bv_ptr[b + 1]; ++q) {
+          const int row = hs.bv_rows[q];
+          for (int k = JT.rp[row]; k < JT.rp[row + 1]; ++k) tmp.push_back(JT.ci[k]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        gcols.insert(gcols.end(), tmp.begin(), tmp.end());
+        gptr[b + 1] = (int)gcols.size();
+        kmax = std::max(kmax, (int)tmp.size());
+      }
+      const int ks = kmax <= 32 ? 32 : (kmax <= 64 ? 64 : (kmax <= 128 ? 128 : 0));
+      if (ks > 0 && block_apply_rect_ok(hs.bs, ks)) {
+        std::vector<double> jtd((size_t)hs.nbv * hs.bs * ks, 0.0);
+        for (int b = 0; b < hs.nbv; ++b) {
+          const int* cb = gcols.data() + gptr[b];
+          const int nc = gptr[b + 1] - gptr[b];
+          for (int q = hs.bv_ptr[b]; q < hs.bv_ptr[b + 1]; ++q) {
+            const int row = hs.bv_rows[q], il = q - hs.bv_ptr[b];
+            for (int k = JT.rp[row]; k < JT.rp[row + 1]; ++k) {
+              const int jl = (int)(std::lower_bound(cb, cb + nc, JT.ci[k]) - cb);
+              jtd[((size_t)b * hs.bs + il) * ks + jl] += JT.v[k];
+            }
+          }
+        }
+        c->gt_ptr.upload(gptr, st);
+        c->gt_cols.upload(gcols, st);
+        c->gt_jtd.upload(jtd, st);
+        c->gt_ks = ks;
+        c->gt_ok = true;
+        if (c->opts.verbose)
+          fprintf(stderr, "[ricadi] last velocity sweep in rectangular form: <= %d pressure dofs per block (slice width %d)\n",
+                  kmax, ks);
+      }
+    }
+  }
   c->bv_ptr.upload(hs.bv_ptr, st);
   c->bv_rows.upload(hs.bv_rows, st);
   c->bp_ptr.upload(hs.bp_ptr, st);

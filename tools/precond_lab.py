@@ -50,7 +50,7 @@ def gmres_right(S, P, b, tol=1e-10, restart=30, maxit=600):
 
 
 def build(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, smooth=0.0, smooth_p=0.0, nsm=1, two_sweeps=False,
-          omega_bj=1.0, coarse="agg", vcycle=False, post_only=False, bs_p=None, einv_dtype=None,
+          omega_bj=1.0, coarse="agg", vcycle=False, post_only=False, bs_p=None, einv_dtype=None, additive=False,
           binv_dtype=None):
     nv, npp = calA.shape[0], J.shape[0]
     pat = (abs(calA) + abs(calE)).tocsr()
@@ -120,6 +120,8 @@ def build(calA, calE, J, alpha, beta, bs=32, av=16, ap=24, smooth=0.0, smooth_p=
             z = omega_bj * P1(r)
             z = z + Y @ (Einv @ (Y.T @ (r - S @ z)))
             return z + omega_bj * P1(r - S @ z)
+        if additive:
+            return Y @ (Einv @ (Y.T @ r)) + omega_bj * P1(r)
         if post_only:
             z = P1(r)
             return z + Y @ (Einv @ (Y.T @ (r - S @ z)))
@@ -155,6 +157,8 @@ if __name__ == "__main__":
         "Einv f16 rowscale": dict(einv_dtype="f16row"),
         "Einv bf16": dict(einv_dtype="bf16"),
         "Einv+blocks f16": dict(einv_dtype="f16row", binv_dtype="f16"),
+        "additive": dict(additive=True),
+        "additive w=0.7": dict(additive=True, omega_bj=0.7),
         "base w=0.8": dict(omega_bj=0.8),
         "base w=0.7": dict(omega_bj=0.7),
         "base w=0.6": dict(omega_bj=0.6),
