@@ -152,6 +152,18 @@ struct CsrInArgs {
   double scale = 1.0;
 };
 
+// One input segment of the two-term block sweep (block_apply2_kernel):
+//   iptr == NULL: the block's own rows; moff == NULL: matrix of block b at b * BS * kstride;
+//   kstride == 0: row stride = the block's input count.
+struct Seg2 {
+  const int* iptr = nullptr;
+  const int* irows = nullptr;
+  const int* moff = nullptr;
+  int kstride = 0;
+  const double* in = nullptr;
+  size_t gs = 0;
+};
+
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
 // The *_b launchers are the batched forms (GroupTab + group strides `gs*`, in
 // doubles); the plain ones run a single panel.
@@ -263,6 +275,17 @@ void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int k
                                const int* bptr, const int* rows, const int* iptr, const int* irows,
                                const GroupPtrsF& mats, const double* in, int ldi, size_t gsi, double* out,
                                int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa);
+// out[rows_b] = M1_b in1[list1_b] - M2_b in2[list2_b]  (+ fused prolongation / plain copy via pa)
+void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                           const int* rows, const GroupPtrs& m1, const Seg2& s1, const GroupPtrs& m2,
+                           const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa);
+void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                           const int* rows, const GroupPtrsF& m1, const Seg2& s1, const GroupPtrsF& m2,
+                           const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa);
+// per shift:  out[b] = Ainv[b] * (alpha dE[b] + beta dA[b] + dJ[b])   (dense slices of S*Y, bs x ks)
+void launch_ady_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* dA,
+                       const double* dE, const double* dJ, const double* alphas, const double* betas,
+                       const GroupPtrs& ainv, const GroupPtrs& out);
 void launch_gt_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* jtd,
                       const GroupPtrs& ainv, const GroupPtrs& out);
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,

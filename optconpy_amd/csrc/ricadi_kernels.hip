@@ -1530,6 +1530,159 @@ void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int k
                         subtract, pa);
 }
 
+// ---------------------------------------------------------------------------
+// K2, two-term form:   out[rows_b] = M1_b * in1[list1_b] - M2_b * in2[list2_b]
+// (+ prolongation / plain copy through ProlongArgs).  Used for the FIRST velocity sweep with the
+// residual of the coarse correction folded in,
+//     z_v = Ahat_b^-1 (r_v - (S Y e)_v)[rows_b] = Ahat_b^-1 r_v[rows_b] - (Ahat_b^-1 D_b) e[ccols_b],
+// D_b = the dense slice of the prolongated operator S*Y over the block's rows and the <= 32
+// coarse columns they touch, Ahat_b^-1 D_b formed per shift at setup (ady_blocks_kernel): the
+// pass that wrote r - (S Y) e for all n rows and the re-read of it disappear (only the pressure
+// rows still go through a small CSR product).  A segment with list == NULL takes the block's
+// own rows.  One wave per block, FP64 MFMA 16x16x4 as in block_apply_kernel.
+// ---------------------------------------------------------------------------
+template <int BS, class T>
+__global__ __launch_bounds__(256) void block_apply2_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
+    GroupPtrsT<T> m1s, Seg2 s1, GroupPtrsT<T> m2s, Seg2 s2, double* __restrict__ out, int ldo, size_t gso,
+    int m, ProlongArgs pa) {
+  const int grp = gt.gid[blockIdx.z];
+  out += (size_t)grp * gso;
+  const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  if (wave >= nblocks) {
+    const int e0 = (wave - nblocks) * 32;
+    for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
+      const int row = pa.row0 + rr;
+      for (int col = r; col < m; col += 16)
+        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+    }
+    return;
+  }
+  const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
+  constexpr int NT = BS / 16;
+  for (int c0 = 0; c0 < m; c0 += 16) {
+    const int col = c0 + r;
+    d4 acc[2][NT];
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[sg][t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+      const Seg2& sd = sg == 0 ? s1 : s2;
+      const T* __restrict__ mat = (sg == 0 ? m1s : m2s).p[grp];
+      const double* __restrict__ in = sd.in + (size_t)grp * sd.gs;
+      const int* __restrict__ lst = sd.iptr ? sd.irows + sd.iptr[wave] : rows + b0;
+      const int ni = sd.iptr ? sd.iptr[wave + 1] - sd.iptr[wave] : nb;
+      const int ks = sd.kstride > 0 ? sd.kstride : ni;
+      const T* __restrict__ Mb = mat + (sd.moff ? (size_t)sd.moff[wave] : (size_t)wave * BS * ks);
+      for (int k0 = 0; k0 < ni; k0 += 16) {
+        double xb[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int kk = k0 + 4 * q + s4;
+          int irow = -1;
+          if (kk < ni && col < m) irow = lst[kk];
+          xb[s4] = irow >= 0 ? in[(size_t)irow * m + col] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          double a4[4];
+          load4(Mb + (size_t)(16 * t + r) * ks + k0 + 4 * q, a4);
+          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xb[0], acc[sg][t], 0, 0, 0);
+          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xb[1], acc[sg][t], 0, 0, 0);
+          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xb[2], acc[sg][t], 0, 0, 0);
+          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xb[3], acc[sg][t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int il = 16 * t + q + 4 * e;
+        if (il < nb && col < m) {
+          const int row = rows[b0 + il];
+          double v = acc[0][t][e] - acc[1][t][e];
+          if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
+          if (ec) v += ec[(size_t)pa.aggof[row] * m + col];
+          out[(size_t)row * ldo + col] = v;
+        }
+      }
+  }
+}
+template <class T>
+static void block_apply2_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                              const int* rows, const GroupPtrsT<T>& m1, const Seg2& s1,
+                              const GroupPtrsT<T>& m2, const Seg2& s2, double* out, int ldo, size_t gso, int m,
+                              const ProlongArgs& pa) {
+  if (nblocks <= 0 || gt.ng <= 0) return;
+  const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
+  dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
+  if (bs == 16)
+    hipLaunchKernelGGL((block_apply2_kernel<16, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
+                       out, ldo, gso, m, pa);
+  else if (bs == 32)
+    hipLaunchKernelGGL((block_apply2_kernel<32, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
+                       out, ldo, gso, m, pa);
+  else
+    hipLaunchKernelGGL((block_apply2_kernel<64, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
+                       out, ldo, gso, m, pa);
+}
+void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                           const int* rows, const GroupPtrs& m1, const Seg2& s1, const GroupPtrs& m2,
+                           const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa) {
+  block_apply2_impl(st, gt, bs, nblocks, bptr, rows, m1, s1, m2, s2, out, ldo, gso, m, pa);
+}
+void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
+                           const int* rows, const GroupPtrsF& m1, const Seg2& s1, const GroupPtrsF& m2,
+                           const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa) {
+  block_apply2_impl(st, gt, bs, nblocks, bptr, rows, m1, s1, m2, s2, out, ldo, gso, m, pa);
+}
+
+// out[b] = Ainv[b] (bs x bs) * (alpha_s dE[b] + beta_s dA[b] + dJ[b]) (bs x ks)  for every velocity block
+// b and every shift s of the setup (blockIdx.y): the dense slices of the prolongated operator S*Y
+// combined for the shift, times the block-Jacobi inverse.  One workgroup per block.
+struct ShiftCoefs {
+  double alpha[RICADI_MAX_GROUPS], beta[RICADI_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void ady_blocks_kernel(int bs, int ks, const double* __restrict__ dA,
+                                                         const double* __restrict__ dE,
+                                                         const double* __restrict__ dJ, ShiftCoefs cf,
+                                                         GroupPtrs ainvs, GroupPtrs outs) {
+  extern __shared__ double sm[];            // Ai (bs x bs), D (bs x ks)
+  double* Ai = sm;
+  double* D = sm + bs * bs;
+  const double al = cf.alpha[blockIdx.y], be = cf.beta[blockIdx.y];
+  const double* __restrict__ ainv = ainvs.p[blockIdx.y] + (size_t)blockIdx.x * bs * bs;
+  const size_t off = (size_t)blockIdx.x * bs * ks;
+  double* __restrict__ out = const_cast<double*>(outs.p[blockIdx.y]) + off;
+  for (int e = threadIdx.x; e < bs * bs; e += 256) Ai[e] = ainv[e];
+  for (int e = threadIdx.x; e < bs * ks; e += 256) D[e] = al * dE[off + e] + be * dA[off + e] + dJ[off + e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < bs * ks; e += 256) {
+    const int i = e / ks, j = e - i * ks;
+    double sacc = 0.0;
+    for (int t = 0; t < bs; ++t) sacc = fma(Ai[i * bs + t], D[t * ks + j], sacc);
+    out[e] = sacc;
+  }
+}
+void launch_ady_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* dA,
+                       const double* dE, const double* dJ, const double* alphas, const double* betas,
+                       const GroupPtrs& ainv, const GroupPtrs& out) {
+  if (nblocks <= 0 || nshift <= 0) return;
+  ShiftCoefs cf;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) {
+    cf.alpha[i] = i < nshift ? alphas[i] : 0.0;
+    cf.beta[i] = i < nshift ? betas[i] : 0.0;
+  }
+  hipLaunchKernelGGL(ady_blocks_kernel, dim3(nblocks, nshift), dim3(256),
+                     (size_t)(bs * bs + bs * ks) * sizeof(double), st, bs, ks, dA, dE, dJ, cf, ainv, out);
+}
+
 // G[b] = Ainv[b] (bs x bs) * JTd[b] (bs x ks)  for every velocity block b and every shift of the
 // setup (blockIdx.y); JTd is the dense slice of J^T (shift independent).  One workgroup per block.
 __global__ __launch_bounds__(256) void gt_blocks_kernel(int bs, int ks, const double* __restrict__ jtd,

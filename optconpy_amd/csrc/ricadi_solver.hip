@@ -187,6 +187,9 @@ struct ShiftData {
   // G_b = Ahat_b^-1 J^T[rows_b, pcols_b] of the last velocity sweep (block_apply_rect_kernel)
   DArr<double> gtm;
   DArr<float> gtmf;
+  // Ahat_b^-1 D_b (D_b: dense slice of S*Y) of the first velocity sweep with the coarse residual folded in
+  DArr<double> adym;
+  DArr<float> adymf;
   // FP16 copy of the coarse inverse with one scale per row (default; RICADI_COARSE16=0: FP32)
   DArr<_Float16> einvh;
   DArr<double> einvs;
@@ -241,6 +244,12 @@ struct ricadi_ctx {
   DArr<int> agg_ptr, agg_rows, aggof;
   // last velocity sweep in rectangular form: per velocity block the pressure dofs its rows touch
   // and the dense slice of J^T over (block rows x those dofs); gt_ks = padded slice width
+  // first velocity sweep with the residual of the coarse correction folded in: per velocity block
+  // the coarse columns its S*Y rows touch and the dense slices of the three value sources
+  bool ady_ok = false;
+  int ady_ks = 0;
+  DArr<int> cy_ptr, cy_cols;
+  DArr<double> cy_dA, cy_dE, cy_dJ;
   bool gt_ok = false;
   int gt_ks = 0;
   DArr<int> gt_ptr, gt_cols;
@@ -432,6 +441,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     launch_block_combine(st, (size_t)c->nbv * bsz, c->bvA.p, c->bvE.p, alpha, beta, sd->bvinv.p);
     if (c->nbp > 0) stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
     if (c->gt_ok) stable_alloc(sd->gtm, (size_t)c->nbv * c->bs * c->gt_ks);
+    if (c->ady_ok && k > 0) stable_alloc(sd->adym, (size_t)c->nbv * c->bs * c->ady_ks);
     if (k > 0) {
       stable_alloc(sd->einv, (size_t)k * k);
       launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
@@ -457,6 +467,16 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       GroupPtrs pg = same_ptr((const double*)nullptr);
       for (int i = 0; i < cnt; ++i) pg.p[i] = todo[t0 + i]->gtm.p;
       launch_gt_blocks(st, cnt, c->nbv, c->bs, c->gt_ks, c->gt_jtd.p, pv, pg);
+    }
+    if (c->ady_ok && k > 0) {
+      GroupPtrs pa_ = same_ptr((const double*)nullptr);
+      double al[RICADI_MAX_GROUPS], be[RICADI_MAX_GROUPS];
+      for (int i = 0; i < cnt; ++i) {
+        pa_.p[i] = todo[t0 + i]->adym.p;
+        al[i] = todo[t0 + i]->alpha;
+        be[i] = todo[t0 + i]->beta;
+      }
+      launch_ady_blocks(st, cnt, c->nbv, c->bs, c->ady_ks, c->cy_dA.p, c->cy_dE.p, c->cy_dJ.p, al, be, pv, pa_);
     }
     if (c->nbp > 0) {
       launch_schur_blocks_bj(st, cnt, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p,
@@ -524,6 +544,11 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         if (sd->gtmf.n != sd->gtm.n) sd->gtmf.alloc(sd->gtm.n);
         launch_to_f32(st, c->nbv, gsz, sd->gtm.p, gsz, sd->gtmf.p, gsz);
       }
+      if (c->ady_ok && k > 0) {
+        const int gsz = c->bs * c->ady_ks;
+        if (sd->adymf.n != sd->adym.n) sd->adymf.alloc(sd->adym.n);
+        launch_to_f32(st, c->nbv, gsz, sd->adym.p, gsz, sd->adymf.p, gsz);
+      }
       if (k > 0) {
         const size_t kp = (size_t)(k + 15) / 16;
         if (c->coarse16) {
@@ -559,8 +584,8 @@ struct Batch {
   GroupPtrs sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
   GroupPtrsH einvh;
-  GroupPtrs einvs, gtm;
-  GroupPtrsF gtmf;
+  GroupPtrs einvs, gtm, adym;
+  GroupPtrsF gtmf, adymf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
   void all() {
@@ -585,8 +610,8 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.sval = bt.svalb = bt.syval = bt.syvalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   bt.einvh = same_ptr((const _Float16*)nullptr);
-  bt.einvs = bt.gtm = same_ptr((const double*)nullptr);
-  bt.gtmf = same_ptr((const float*)nullptr);
+  bt.einvs = bt.gtm = bt.adym = same_ptr((const double*)nullptr);
+  bt.gtmf = bt.adymf = same_ptr((const float*)nullptr);
   for (int g = 0; g < RICADI_MAX_GROUPS; ++g) bt.alpha[g] = bt.beta[g] = 0.0;
   for (int g = 0; g < G; ++g) {
     bt.alpha[g] = sds[g]->alpha;
@@ -598,6 +623,8 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
     bt.einvs.p[g] = sds[g]->einvs.p;
     bt.gtm.p[g] = sds[g]->gtm.p;
     bt.gtmf.p[g] = sds[g]->gtmf.p;
+    bt.adym.p[g] = sds[g]->adym.p;
+    bt.adymf.p[g] = sds[g]->adymf.p;
     bt.sval.p[g] = sds[g]->sval.p;
     bt.syval.p[g] = sds[g]->syval.p;
     bt.syvalb.p[g] = sds[g]->syvalb.p;
@@ -683,6 +710,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   const GroupPtrs ones = same_ptr(c->ones.p), jv = same_ptr(c->J.v.p), jtv = same_ptr(c->JT.v.p);
   const double* rr = r;
   size_t gsrr = gsr;
+  bool folded = false;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
@@ -693,26 +721,36 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
-    // Residual after the coarse correction, r2 = r - (S Y) ec, with the prolongated
-    // operator (short rows over the L2-resident coarse vector) -- not a full saddle SpMM
-    // through the prolongation map.  (Forming the velocity rows of r2 inside the first
-    // velocity sweep instead, like the J^T product below, was measured slower: 249 vs
-    // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
-    // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
-    static const bool sy_csr = getenv("RICADI_SY_CSR") != nullptr;
-    if (c->syb_ok && !sy_csr && ms_pays(c, gt.ng, c->snnz) &&
-        spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
-      launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
-                             c->syb_cols2.p, c->syb_lidx_ms.p, c->sybAJ.p, c->sybE.p, c->ec.p, m,
-                             bt.gsc, c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, c->syb_max_cols);
-    else if (c->syb_ok && !sy_csr &&
-        spmm_blocked_lds_bytes(m, c->syb_max_cols, 0) <= (size_t)40 * 1024)
-      launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
-                            c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, bt.gs, r, m, gsr,
-                            -1.0, 1.0, m, c->syb_max_cols);
-    else
-      launch_spmm_b(st, gt, c->n, c->sy_rp.p, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
-                    c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, LowRankArgs(), c->sy_chunk);
+    static const bool fold = getenv("RICADI_NO_FOLD") == nullptr;
+    folded = fold && c->ady_ok && np > 0;
+    if (folded) {
+      // only the PRESSURE rows of r - (S Y) ec are formed (short CSR product over np rows); the
+      // velocity rows ride inside the first velocity sweep (block_apply2_kernel, below)
+      launch_spmm_b(st, gt, np, c->sy_rp.p + nv, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
+                    c->r2.p + (size_t)nv * m, m, bt.gs, r + (size_t)nv * m, m, gsr, -1.0, 1.0, m, LowRankArgs(),
+                    c->sy_chunk);
+    } else {
+      // Residual after the coarse correction, r2 = r - (S Y) ec, with the prolongated
+      // operator (short rows over the L2-resident coarse vector) -- not a full saddle SpMM
+      // through the prolongation map.  (Forming the velocity rows of r2 inside the first
+      // velocity sweep instead, like the J^T product below, was measured slower: 249 vs
+      // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
+      // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
+      static const bool sy_csr = getenv("RICADI_SY_CSR") != nullptr;
+      if (c->syb_ok && !sy_csr && ms_pays(c, gt.ng, c->snnz) &&
+          spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
+        launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
+                               c->syb_cols2.p, c->syb_lidx_ms.p, c->sybAJ.p, c->sybE.p, c->ec.p, m,
+                               bt.gsc, c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, c->syb_max_cols);
+      else if (c->syb_ok && !sy_csr &&
+          spmm_blocked_lds_bytes(m, c->syb_max_cols, 0) <= (size_t)40 * 1024)
+        launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
+                              c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, bt.gs, r, m, gsr,
+                              -1.0, 1.0, m, c->syb_max_cols);
+      else
+        launch_spmm_b(st, gt, c->n, c->sy_rp.p, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
+                      c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, LowRankArgs(), c->sy_chunk);
+    }
     rr = c->r2.p;
     gsrr = bt.gs;
   }
@@ -736,7 +774,27 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, in, m, gsi, z,
                            m, bt.gs, m, subtract, pa, cin);
   };
-  vel_apply(rr, gsrr, 0, np == 0);
+  if (folded) {
+    // z_v = Ahat^-1 r_v - (Ahat^-1 D) ec : first velocity sweep on the corrected residual without
+    // ever writing it
+    Seg2 s1, s2;
+    s1.kstride = c->bs;
+    s1.in = r;
+    s1.gs = gsr;
+    s2.iptr = c->cy_ptr.p;
+    s2.irows = c->cy_cols.p;
+    s2.kstride = c->ady_ks;
+    s2.in = c->ec.p;
+    s2.gs = bt.gsc;
+    if (c->precond32)
+      launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, s1, bt.adymf, s2, z, m,
+                            bt.gs, m, ProlongArgs());
+    else
+      launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, s1, bt.adym, s2, z, m,
+                            bt.gs, m, ProlongArgs());
+  } else {
+    vel_apply(rr, gsrr, 0, np == 0);
+  }
   if (np > 0) {
     // t = J z_v - r_p
     launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
@@ -2100,6 +2158,52 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->sy_A.upload(hs.sy_A, st);
   c->sy_E.upload(hs.sy_E, st);
   c->sy_J.upload(hs.sy_J, st);
+  {
+    // dense slices of S*Y per velocity block (first sweep with the coarse residual folded in)
+    c->ady_ok = false;
+    if (hs.kc > 0 && np > 0 && hs.nbv > 0 && !hs.sy_rp.empty()) {
+      std::vector<int> cptr(hs.nbv + 1, 0), ccols, tmp;
+      int kmax = 0;
+      for (int b = 0; b < hs.nbv; ++b) {
+        tmp.clear();
+        for (int q = hs.bv_ptr[b]; q < hs.bv_ptr[b + 1]; ++q) {
+          const int row = hs.bv_rows[q];
+          for (int kk = hs.sy_rp[row]; kk < hs.sy_rp[row + 1]; ++kk) tmp.push_back(hs.sy_ci[kk]);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        ccols.insert(ccols.end(), tmp.begin(), tmp.end());
+        cptr[b + 1] = (int)ccols.size();
+        kmax = std::max(kmax, (int)tmp.size());
+      }
+      const int ks = kmax <= 32 ? 32 : (kmax <= 64 ? 64 : 0);
+      if (ks > 0) {
+        const size_t tot = (size_t)hs.nbv * hs.bs * ks;
+        std::vector<double> dA(tot, 0.0), dE(tot, 0.0), dJ(tot, 0.0);
+        for (int b = 0; b < hs.nbv; ++b) {
+          const int* cb = ccols.data() + cptr[b];
+          const int nc = cptr[b + 1] - cptr[b];
+          for (int q = hs.bv_ptr[b]; q < hs.bv_ptr[b + 1]; ++q) {
+            const int row = hs.bv_rows[q], il = q - hs.bv_ptr[b];
+            for (int kk = hs.sy_rp[row]; kk < hs.sy_rp[row + 1]; ++kk) {
+              const int jl = (int)(std::lower_bound(cb, cb + nc, hs.sy_ci[kk]) - cb);
+              const size_t at = ((size_t)b * hs.bs + il) * ks + jl;
+              dA[at] += hs.sy_A[kk];
+              dE[at] += hs.sy_E[kk];
+              dJ[at] += hs.sy_J[kk];
+            }
+          }
+        }
+        c->cy_ptr.upload(cptr, st);
+        c->cy_cols.upload(ccols, st);
+        c->cy_dA.upload(dA, st);
+        c->cy_dE.upload(dE, st);
+        c->cy_dJ.upload(dJ, st);
+        c->ady_ks = ks;
+        c->ady_ok = true;
+      }
+    }
+  }
   c->syb_ok = hs.kc > 0 && hs.sb_nblk > 0 && hs.syb_max_cols > 0;
   c->syb_max_cols = hs.syb_max_cols;
   if (c->syb_ok) {
