@@ -92,7 +92,6 @@ struct GroupPtrsT {
 };
 typedef GroupPtrsT<double> GroupPtrs;
 typedef GroupPtrsT<float> GroupPtrsF;   // FP32-stored preconditioner operands
-typedef GroupPtrsT<_Float16> GroupPtrsH;   // FP16-stored (row-scaled) coarse inverse
 struct GroupInts {            // one small integer per group id (by value)
   int v[RICADI_MAX_GROUPS];
 };
@@ -261,10 +260,6 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
                           const ProlongArgs& pa = ProlongArgs(), const CsrInArgs& ci = CsrInArgs());
-// FP16-stored coarse inverse, tile-major, one scale per row (Einv[i][:] = rowscale[i] * stored[i][:])
-void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsH& Einv,
-                          const GroupPtrs& rowscale, const double* rc, double* ec);
-void launch_to_f16_tiled(hipStream_t st, int k, const double* src, double* rowscale, _Float16* dst);
 // rectangular block sweep  out[rows_b] (-)= mats[b] (bs x ks) * in[irows_b]  (+ fused prolongation)
 bool block_apply_rect_ok(int bs, int ks);
 void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
@@ -275,7 +270,9 @@ void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int k
                                const int* bptr, const int* rows, const int* iptr, const int* irows,
                                const GroupPtrsF& mats, const double* in, int ldi, size_t gsi, double* out,
                                int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa);
-// out[rows_b] = M1_b in1[list1_b] - M2_b in2[list2_b]  (+ fused prolongation / plain copy via pa)
+// out[rows_b] = M1_b in1[rows_b] - M2_b in2[list2_b]  (+ fused prolongation / plain copy via pa);
+// segment 1: the block's own rows, bs x bs matrices; segment 2: list + bs x kstride (32 | 64) matrices
+bool block_apply2_ok(int bs, int k2);
 void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                            const int* rows, const GroupPtrs& m1, const Seg2& s1, const GroupPtrs& m2,
                            const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa);

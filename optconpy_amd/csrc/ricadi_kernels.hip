@@ -1541,7 +1541,10 @@ void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int k
 // rows still go through a small CSR product).  A segment with list == NULL takes the block's
 // own rows.  One wave per block, FP64 MFMA 16x16x4 as in block_apply_kernel.
 // ---------------------------------------------------------------------------
-template <int BS, class T>
+// Segment 1 is always the block's own rows with a BS x BS matrix; segment 2 has a compile-time
+// padded width K2 (its list may be shorter).  All index loads are issued first, then all gathers,
+// then the MFMAs: the two segments' dependent-load chains overlap instead of following each other.
+template <int BS, int K2, class T>
 __global__ __launch_bounds__(256) void block_apply2_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
     GroupPtrsT<T> m1s, Seg2 s1, GroupPtrsT<T> m2s, Seg2 s2, double* __restrict__ out, int ldo, size_t gso,
@@ -1562,41 +1565,65 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
     return;
   }
   const int b0 = bptr[wave], nb = bptr[wave + 1] - b0;
-  constexpr int NT = BS / 16;
+  const int i0 = s2.iptr[wave], ni = s2.iptr[wave + 1] - i0;
+  constexpr int NT = BS / 16, N1 = BS / 16, N2 = K2 / 16;
+  const T* __restrict__ M1 = m1s.p[grp] + (size_t)wave * BS * BS;
+  const T* __restrict__ M2 = m2s.p[grp] + (size_t)wave * BS * K2;
+  const double* __restrict__ in1 = s1.in + (size_t)grp * s1.gs;
+  const double* __restrict__ in2 = s2.in + (size_t)grp * s2.gs;
+  // input row ids of this lane: 4 per 16-wide chunk
+  int r1[N1][4], r2[N2][4];
+#pragma unroll
+  for (int kc = 0; kc < N1; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kk = kc * 16 + 4 * q + s4;
+      r1[kc][s4] = kk < nb ? rows[b0 + kk] : -1;
+    }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int kk = kc * 16 + 4 * q + s4;
+      r2[kc][s4] = kk < ni ? s2.irows[i0 + kk] : -1;
+    }
   for (int c0 = 0; c0 < m; c0 += 16) {
     const int col = c0 + r;
-    d4 acc[2][NT];
+    const bool cok = col < m;
+    double x1[N1][4], x2[N2][4];
 #pragma unroll
-    for (int sg = 0; sg < 2; ++sg)
+    for (int kc = 0; kc < N1; ++kc)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[sg][t] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int s4 = 0; s4 < 4; ++s4)
+        x1[kc][s4] = (r1[kc][s4] >= 0 && cok) ? in1[(size_t)r1[kc][s4] * m + col] : 0.0;
 #pragma unroll
-    for (int sg = 0; sg < 2; ++sg) {
-      const Seg2& sd = sg == 0 ? s1 : s2;
-      const T* __restrict__ mat = (sg == 0 ? m1s : m2s).p[grp];
-      const double* __restrict__ in = sd.in + (size_t)grp * sd.gs;
-      const int* __restrict__ lst = sd.iptr ? sd.irows + sd.iptr[wave] : rows + b0;
-      const int ni = sd.iptr ? sd.iptr[wave + 1] - sd.iptr[wave] : nb;
-      const int ks = sd.kstride > 0 ? sd.kstride : ni;
-      const T* __restrict__ Mb = mat + (sd.moff ? (size_t)sd.moff[wave] : (size_t)wave * BS * ks);
-      for (int k0 = 0; k0 < ni; k0 += 16) {
-        double xb[4];
+    for (int kc = 0; kc < N2; ++kc)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const int kk = k0 + 4 * q + s4;
-          int irow = -1;
-          if (kk < ni && col < m) irow = lst[kk];
-          xb[s4] = irow >= 0 ? in[(size_t)irow * m + col] : 0.0;
-        }
+      for (int s4 = 0; s4 < 4; ++s4)
+        x2[kc][s4] = (r2[kc][s4] >= 0 && cok) ? in2[(size_t)r2[kc][s4] * m + col] : 0.0;
+    d4 acc1[NT], acc2[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          double a4[4];
-          load4(Mb + (size_t)(16 * t + r) * ks + k0 + 4 * q, a4);
-          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xb[0], acc[sg][t], 0, 0, 0);
-          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xb[1], acc[sg][t], 0, 0, 0);
-          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xb[2], acc[sg][t], 0, 0, 0);
-          acc[sg][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xb[3], acc[sg][t], 0, 0, 0);
-        }
+    for (int t = 0; t < NT; ++t) acc1[t] = acc2[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kc = 0; kc < N1; ++kc)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        double a4[4];
+        load4(M1 + (size_t)(16 * t + r) * BS + kc * 16 + 4 * q, a4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], x1[kc][s4], acc1[t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kc = 0; kc < N2; ++kc) {
+      if (kc * 16 >= ni) break;                 // wave-uniform
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        double a4[4];
+        load4(M2 + (size_t)(16 * t + r) * K2 + kc * 16 + 4 * q, a4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], x2[kc][s4], acc2[t], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -1604,9 +1631,9 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int il = 16 * t + q + 4 * e;
-        if (il < nb && col < m) {
+        if (il < nb && cok) {
           const int row = rows[b0 + il];
-          double v = acc[0][t][e] - acc[1][t][e];
+          double v = acc1[t][e] - acc2[t][e];
           if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];
           out[(size_t)row * ldo + col] = v;
@@ -1614,6 +1641,7 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
       }
   }
 }
+bool block_apply2_ok(int bs, int k2) { return (bs == 32 || bs == 16) && (k2 == 32 || k2 == 64); }
 template <class T>
 static void block_apply2_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                               const int* rows, const GroupPtrsT<T>& m1, const Seg2& s1,
@@ -1622,15 +1650,14 @@ static void block_apply2_impl(hipStream_t st, const GroupTab& gt, int bs, int nb
   if (nblocks <= 0 || gt.ng <= 0) return;
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
-  if (bs == 16)
-    hipLaunchKernelGGL((block_apply2_kernel<16, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
-                       out, ldo, gso, m, pa);
-  else if (bs == 32)
-    hipLaunchKernelGGL((block_apply2_kernel<32, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
-                       out, ldo, gso, m, pa);
-  else
-    hipLaunchKernelGGL((block_apply2_kernel<64, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, s2,
-                       out, ldo, gso, m, pa);
+#define RICADI_BA2(B, K)                                                                              \
+  hipLaunchKernelGGL((block_apply2_kernel<B, K, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, \
+                     s2, out, ldo, gso, m, pa)
+  if (bs == 32 && s2.kstride == 32) RICADI_BA2(32, 32);
+  else if (bs == 32) RICADI_BA2(32, 64);
+  else if (s2.kstride == 32) RICADI_BA2(16, 32);
+  else RICADI_BA2(16, 64);
+#undef RICADI_BA2
 }
 void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                            const int* rows, const GroupPtrs& m1, const Seg2& s1, const GroupPtrs& m2,
@@ -1947,20 +1974,13 @@ void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, cons
 // Low-precision-stored inverse in TILE-MAJOR layout: 16 x 16 tiles of 256 contiguous entries,
 // tile (it, jt) at (it * kp + jt) * 256, kp = ceil(k / 16), zero padded.  The A operand
 // of one MFMA chunk -- lane (r, q) needs Einv[16 it + r][16 jt + 4q .. 4q+3] -- is then
-// ONE fully coalesced read per wave (1 KB for FP32, 512 B for FP16; lane offset
-// (16 r + 4 q) entries) instead of sixteen row segments 4k bytes apart.
-// FP16 storage carries one scale per ROW (Einv[i][:] = rowscale[i] * stored[i][:], the row
-// maximum mapped to 6e4), applied to the finished row sums: same GMRES iteration counts as
-// FP32 / FP64 storage on the numpy mirror (tools/precond_lab.py), half the bytes of the
-// largest operand of the preconditioner.
+// ONE fully coalesced 1-KB read per wave (lane offset (16 r + 4 q) entries) instead of sixteen
+// row segments 4k bytes apart.  (An FP16-stored inverse with row / column scales was tried in
+// round 2: +2.4 % at cfg2 with row scales, but no usable preconditioner for the mass-dominated
+// DRE operator of cfg4 either way, and the column scales cost more loads than the bytes save.)
 __device__ __forceinline__ void load4t(const float* p, double (&a)[4]) {
   const float4 u = *reinterpret_cast<const float4*>(p);
   a[0] = (double)u.x; a[1] = (double)u.y; a[2] = (double)u.z; a[3] = (double)u.w;
-}
-__device__ __forceinline__ void load4t(const _Float16* p, double (&a)[4]) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  const h4 u = *reinterpret_cast<const h4*>(p);
-  a[0] = (double)(float)u.x; a[1] = (double)(float)u.y; a[2] = (double)(float)u.z; a[3] = (double)(float)u.w;
 }
 // Register blocking: a workgroup owns TI row tiles (16 TI output rows) x 16 columns; per
 // 16-column chunk of the inverse a lane loads its 4 values of rc ONCE and feeds them to the
@@ -1968,13 +1988,12 @@ __device__ __forceinline__ void load4t(const _Float16* p, double (&a)[4]) {
 // kernel's load instructions (the inverse itself is one vector load per chunk and tile).
 template <class T, int TI>
 __global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int k, int m,
-                                                                GroupPtrsT<T> Einvs, GroupPtrs rowscales,
+                                                                GroupPtrsT<T> Einvs,
                                                                 const double* __restrict__ rc,
                                                                 double* __restrict__ ec) {
   __shared__ double red[8][16 * TI][17];
   const int grp = gt.gid[blockIdx.z];
   const T* __restrict__ Einv = Einvs.p[grp];
-  const double* __restrict__ rsc = rowscales.p[grp];
   rc += (size_t)grp * k * m;
   ec += (size_t)grp * k * m;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2034,63 +2053,23 @@ __global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int
 #pragma unroll
     for (int t = 0; t < 8; ++t) sum += red[t][rr][cc];
     const int row = it0 * 16 + rr;
-    if (row < k && c0 + cc < m) ec[(size_t)row * m + c0 + cc] = rsc ? rsc[row] * sum : sum;
+    if (row < k && c0 + cc < m) ec[(size_t)row * m + c0 + cc] = sum;
   }
 }
 template <class T>
 static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, int m,
-                                     const GroupPtrsT<T>& Einv, const GroupPtrs& rowscale, const double* rc,
-                                     double* ec) {
+                                     const GroupPtrsT<T>& Einv, const double* rc, double* ec) {
   if (k <= 0 || gt.ng <= 0) return;
   const int kp = (k + 15) / 16;
   // one row tile per workgroup: four tiles per workgroup (rc values loaded once for four MFMA
   // groups) measured no faster -- 133 VGPRs, 3 waves per SIMD: 63 vs 57-63 us at cfg2, G = 16
   dim3 grid(kp, (m + 15) / 16, gt.ng);
-  hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rowscale, rc, ec);
+  hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
 }
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
                           int ldf, const double* rc, double* ec) {
   (void)ldf;   // tile-major storage (launch_to_f32_tiled)
-  dense_apply_tiled_launch(st, gt, k, m, Einv, same_ptr((const double*)nullptr), rc, ec);
-}
-void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsH& Einv,
-                          const GroupPtrs& rowscale, const double* rc, double* ec) {
-  dense_apply_tiled_launch(st, gt, k, m, Einv, rowscale, rc, ec);
-}
-// FP16 tile-major copy with one scale per row: rowscale[i] = max_j |src[i][j]| / 6e4
-__global__ __launch_bounds__(256) void rowscale_kernel(int k, const double* __restrict__ src,
-                                                       double* __restrict__ rowscale) {
-  __shared__ double red[256];
-  const int i = blockIdx.x;
-  double mx = 0.0;
-  for (int j = threadIdx.x; j < k; j += 256) mx = fmax(mx, fabs(src[(size_t)i * k + j]));
-  red[threadIdx.x] = mx;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + off]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) rowscale[i] = red[0] > 0.0 ? red[0] / 6e4 : 1.0;
-}
-__global__ void to_f16_tiled_kernel(int k, const double* __restrict__ src,
-                                    const double* __restrict__ rowscale, _Float16* __restrict__ dst) {
-  const int kp = (k + 15) / 16;
-  const size_t n = (size_t)kp * kp * 256;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t tile = i >> 8;
-    const int r = (int)((i >> 4) & 15), cc = (int)(i & 15);
-    const int row = (int)(tile / kp) * 16 + r, col = (int)(tile % kp) * 16 + cc;
-    dst[i] = (row < k && col < k) ? (_Float16)(float)(src[(size_t)row * k + col] / rowscale[row]) : (_Float16)0.f;
-  }
-}
-void launch_to_f16_tiled(hipStream_t st, int k, const double* src, double* rowscale, _Float16* dst) {
-  const int kp = (k + 15) / 16;
-  const size_t n = (size_t)kp * kp * 256;
-  if (!n) return;
-  hipLaunchKernelGGL(rowscale_kernel, dim3(k), dim3(256), 0, st, k, src, rowscale);
-  int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
-  hipLaunchKernelGGL(to_f16_tiled_kernel, dim3(grid), dim3(256), 0, st, k, src, rowscale, dst);
+  dense_apply_tiled_launch(st, gt, k, m, Einv, rc, ec);
 }
 // dst = FP32 copy of the k x k row-major src in 16 x 16 tile-major layout, zero padded
 __global__ void to_f32_tiled_kernel(int k, const double* __restrict__ src, float* __restrict__ dst) {

@@ -190,9 +190,6 @@ struct ShiftData {
   // Ahat_b^-1 D_b (D_b: dense slice of S*Y) of the first velocity sweep with the coarse residual folded in
   DArr<double> adym;
   DArr<float> adymf;
-  // FP16 copy of the coarse inverse with one scale per row (default; RICADI_COARSE16=0: FP32)
-  DArr<_Float16> einvh;
-  DArr<double> einvs;
   // Sherman-Morrison-Woodbury data for the current low-rank term (ctx->lr_epoch):
   // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
   DArr<double> smw_w;
@@ -295,7 +292,6 @@ struct ricadi_ctx {
   bool basis32 = true;
   bool basis16 = true;        // FP16-stored Krylov basis (default for n <= 2^21)
   bool precond32 = true;
-  bool coarse16 = false;      // RICADI_COARSE16=1: coarse inverse stored in FP16 with row scales (experimental)
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
   DArr<double*> eptrs;
@@ -551,14 +547,8 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       }
       if (k > 0) {
         const size_t kp = (size_t)(k + 15) / 16;
-        if (c->coarse16) {
-          if (sd->einvh.n != kp * kp * 256) sd->einvh.alloc(kp * kp * 256);
-          if (sd->einvs.n != (size_t)k) sd->einvs.alloc(k);
-          launch_to_f16_tiled(st, k, sd->einv.p, sd->einvs.p, sd->einvh.p);
-        } else {
-          if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
-          launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
-        }
+        if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
+        launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
       }
     }
     HIPCHK(hipStreamSynchronize(st));
@@ -583,8 +573,7 @@ struct Batch {
   double alpha[RICADI_MAX_GROUPS], beta[RICADI_MAX_GROUPS];   // shift of every group id
   GroupPtrs sval, svalb, syval, syvalb, bvinv, bpinv, einv;
   GroupPtrsF bvinvf, bpinvf, einvf;
-  GroupPtrsH einvh;
-  GroupPtrs einvs, gtm, adym;
+  GroupPtrs gtm, adym;
   GroupPtrsF gtmf, adymf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
 
@@ -609,8 +598,7 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.tab = GroupTab{};
   bt.sval = bt.svalb = bt.syval = bt.syvalb = bt.bvinv = bt.bpinv = bt.einv = same_ptr((const double*)nullptr);
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
-  bt.einvh = same_ptr((const _Float16*)nullptr);
-  bt.einvs = bt.gtm = bt.adym = same_ptr((const double*)nullptr);
+  bt.gtm = bt.adym = same_ptr((const double*)nullptr);
   bt.gtmf = bt.adymf = same_ptr((const float*)nullptr);
   for (int g = 0; g < RICADI_MAX_GROUPS; ++g) bt.alpha[g] = bt.beta[g] = 0.0;
   for (int g = 0; g < G; ++g) {
@@ -619,8 +607,6 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
     bt.bvinvf.p[g] = sds[g]->bvinvf.p;
     bt.bpinvf.p[g] = sds[g]->bpinvf.p;
     bt.einvf.p[g] = sds[g]->einvf.p;
-    bt.einvh.p[g] = sds[g]->einvh.p;
-    bt.einvs.p[g] = sds[g]->einvs.p;
     bt.gtm.p[g] = sds[g]->gtm.p;
     bt.gtmf.p[g] = sds[g]->gtmf.p;
     bt.adym.p[g] = sds[g]->adym.p;
@@ -715,9 +701,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
                   bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
-    if (c->precond32 && c->coarse16)
-      launch_dense_apply_b(st, gt, c->kc, m, bt.einvh, bt.einvs, c->rc.p, c->ec.p);
-    else if (c->precond32)
+    if (c->precond32)
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
@@ -2001,7 +1985,6 @@ int ricadi_create(int device_id, ricadi_ctx** out) {
   ricadi_default_opts(&c->opts);
   c->precond32 = getenv("RICADI_PRECOND64") == nullptr;
   c->timing = getenv("RICADI_TIMING") != nullptr;
-  if (const char* e = getenv("RICADI_COARSE16")) c->coarse16 = e[0] != '0';
   if (const char* e = getenv("RICADI_SMW")) c->smw = e[0] != '0';
   HIPCHK(hipStreamCreate(&c->st));
   RBCHK(rocblas_create_handle(&c->rb));
@@ -2177,7 +2160,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
         kmax = std::max(kmax, (int)tmp.size());
       }
       const int ks = kmax <= 32 ? 32 : (kmax <= 64 ? 64 : 0);
-      if (ks > 0) {
+      if (ks > 0 && block_apply2_ok(hs.bs, ks)) {
         const size_t tot = (size_t)hs.nbv * hs.bs * ks;
         std::vector<double> dA(tot, 0.0), dE(tot, 0.0), dJ(tot, 0.0);
         for (int b = 0; b < hs.nbv; ++b) {
@@ -2723,9 +2706,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         break;
       case 3:
         if (c->kc <= 0) throw HipError{"no coarse level"};
-        if (c->precond32 && c->coarse16)
-          launch_dense_apply_b(st, gt, c->kc, m, bt.einvh, bt.einvs, c->rc.p, c->ec.p);
-        else if (c->precond32)
+        if (c->precond32)
           launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
         else
           launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
