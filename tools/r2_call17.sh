@@ -2,7 +2,7 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-O=gpurun_out/r2c17
+O=gpurun_out/r2c19
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests16.log 2>&1
 echo "pytest(coarse16) rc=$?" >> $O/gputests16.log
@@ -16,5 +16,7 @@ d=json.load(open(sys.argv[1]))
 print("%-28s value %7.2f ms %7.1f solves/step %d its/solve %5.1f Kerr %.1e"%(sys.argv[2], d['value'], d['ms_per_step'], d['config']['shift_solves_per_step'], d['config']['gmres_iters_per_shift_solve'], d['config']['K_rel_diff_vs_oracle']))
 PY
 }
-run coarse32 A=1
-run coarse32b A=1
+run scalar RICADI_ARNOLDI_SCALAR=1
+run vec4 A=1
+run scalar2 RICADI_ARNOLDI_SCALAR=1
+run vec4b A=1
