@@ -122,6 +122,8 @@ struct ProlongArgs {
   int row0 = 0, nextra = 0;
   double* out2 = nullptr;   // if set: the sweep's result before the coarse part is added
   size_t gs2 = 0;
+  float* out32 = nullptr;   // if set: FP32 copy of what the sweep writes (flexible GMRES keeps Z_j = P^-1 v_j)
+  size_t gs32 = 0;
 };
 
 // Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for

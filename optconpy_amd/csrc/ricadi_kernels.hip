@@ -1310,8 +1310,11 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
     const int e0 = (wave - nblocks) * 32;
     for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
       const int row = pa.row0 + rr;
-      for (int col = r; col < m; col += 16)
-        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+      for (int col = r; col < m; col += 16) {
+        const double v = out[(size_t)row * ldo + col] + ec[(size_t)pa.aggof[row] * m + col];
+        out[(size_t)row * ldo + col] = v;
+        if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
+      }
     }
     return;
   }
@@ -1373,6 +1376,7 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
           if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
           *o = v;
+          if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
         }
       }
   }
@@ -1444,8 +1448,11 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
     const int e0 = (wave - nblocks) * 32;
     for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
       const int row = pa.row0 + rr;
-      for (int col = r; col < m; col += 16)
-        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+      for (int col = r; col < m; col += 16) {
+        const double v = out[(size_t)row * ldo + col] + ec[(size_t)pa.aggof[row] * m + col];
+        out[(size_t)row * ldo + col] = v;
+        if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
+      }
     }
     return;
   }
@@ -1488,6 +1495,7 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
           double v = subtract ? *o - acc[t][e] : acc[t][e];
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
           *o = v;
+          if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
         }
       }
   }
@@ -1559,8 +1567,11 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
     const int e0 = (wave - nblocks) * 32;
     for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
       const int row = pa.row0 + rr;
-      for (int col = r; col < m; col += 16)
-        out[(size_t)row * ldo + col] += ec[(size_t)pa.aggof[row] * m + col];
+      for (int col = r; col < m; col += 16) {
+        const double v = out[(size_t)row * ldo + col] + ec[(size_t)pa.aggof[row] * m + col];
+        out[(size_t)row * ldo + col] = v;
+        if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
+      }
     }
     return;
   }

@@ -288,7 +288,8 @@ struct ricadi_ctx {
   // workspaces
   int wcols = 0, wrestart = 0;   // total columns (width x groups) and restart length the workspace holds
   DArr<double> basis, vcur, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
-  DArr<float> basisf;
+  DArr<float> basisf, zbasisf;   // zbasisf: Z_j = P^-1 v_j of the flexible GMRES, FP32
+  bool flex = true;              // RICADI_FGMRES=0: plain right preconditioning (x += P^-1 (V y) per cycle)
   bool basis32 = true;
   bool basis16 = true;        // FP16-stored Krylov basis (default for n <= 2^21)
   bool precond32 = true;
@@ -362,6 +363,9 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
     c->basis.alloc((size_t)(restart + 1) * nm);
     c->basisf.release();
   }
+  c->flex = !(getenv("RICADI_FGMRES") && atoi(getenv("RICADI_FGMRES")) == 0);
+  if (c->flex) c->zbasisf.alloc((size_t)restart * nm);
+  else c->zbasisf.release();
   c->wv.alloc(nm);
   c->zv.alloc(nm);
   c->r2.alloc(nm);
@@ -689,8 +693,11 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
 // z = P^-1 r for every active group: multiplicative two-level, coarse correction
 // first, then one consistent SIMPLE block-Jacobi sweep on the updated residual.
 // r has group stride gsr; z lives in a workspace buffer (stride bt.gs).
-static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z) {
+// z32 (optional, group stride gs32): FP32 copy of z, written by the sweeps that write z last.
+static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z,
+                          float* z32 = nullptr, size_t gs32 = 0) {
   hipStream_t st = c->st;
+  bool mirrored = false;
   const int nv = c->nv, np = c->np, m = bt.m;
   const GroupTab& gt = bt.tab;
   const GroupPtrs ones = same_ptr(c->ones.p), jv = same_ptr(c->J.v.p), jtv = same_ptr(c->JT.v.p);
@@ -792,6 +799,10 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     if (fuse_jt) {
       ppro.out2 = c->tp.p;
       ppro.gs2 = bt.gsp;
+      if (z32) {
+        ppro.out32 = z32 + (size_t)nv * m;
+        ppro.gs32 = gs32;
+      }
       if (c->kc > 0) {
         ppro.aggof = c->aggof.p + nv;
         ppro.ec = c->ec.p;
@@ -811,6 +822,9 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     if (fuse_jt && rect && c->gt_ok) {
       // z_v -= G z_p with the per-shift blocks G_b = Ahat_b^-1 J^T[rows_b, pcols_b] formed at setup
       pro.nextra = 0;            // the pressure rows already carry their coarse part
+      pro.out32 = z32;
+      pro.gs32 = gs32;
+      mirrored = true;
       if (c->precond32)
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
                                   c->gt_cols.p, bt.gtmf, c->tp.p, m, bt.gsp, z, m, bt.gs, m, 1, pro);
@@ -833,6 +847,9 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       vel_apply(tmp, bt.gs, 1, true);
     }
   }
+  if (z32 && !mirrored)
+    for (int i = 0; i < gt.ng; ++i)
+      launch_to_f32(st, c->n, m, z + (size_t)gt.gid[i] * bt.gs, m, z32 + (size_t)gt.gid[i] * gs32, m);
 }
 
 static void op_apply(ricadi_ctx* c, ShiftData* sd, const double* x, double* y, int m, bool lowrank) {
@@ -881,6 +898,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   float* Vf = c->basisf.p;         // ... or the FP32-stored one
   const bool b16 = c->basis16;
   const bool b32 = c->basis32 && !b16;
+  const bool flex = c->flex;
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
@@ -978,7 +996,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     for (int j = 0; j < cyc && !live.empty(); ++j) {
       bt.set(live);
       const double* vj = (b32 || b16) ? c->vcur.p : V + (size_t)j * vs;
-      precond_apply(c, bt, vj, nm, c->zv.p);
+      // flexible form: Z_j = P^-1 v_j is kept (FP32), the cycle's correction is x += Z y -- no
+      // preconditioner application at the cycle end, and P may differ from step to step
+      precond_apply(c, bt, vj, nm, c->zv.p, flex ? c->zbasisf.p + (size_t)j * vs : nullptr, nm);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank);
       if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
@@ -1038,7 +1058,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       GroupInts ks = same_int(0);
       for (int g : act) ks.v[g] = kk[g];
       launch_gmres_backsolve_b(st, bt.tab, m, ks, restart, c->H.p, c->g.p, c->yv.p);
-      if (b16)
+      if (flex)
+        launch_cols_update_bk(st, bt.tab, n, m, ks, c->zbasisf.p, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
+      else if (b16)
         launch_cols_update_bk(st, bt.tab, n, m, ks, Vh, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
       else if (b32)
         launch_cols_update_bk(st, bt.tab, n, m, ks, Vf, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
@@ -1046,8 +1068,12 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
         launch_cols_update_bk(st, bt.tab, n, m, ks, V, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
     }
     bt.set(act);
-    precond_apply(c, bt, c->wv.p, nm, c->zv.p);
-    launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
+    if (flex) {
+      launch_axpby_b(st, bt.tab, nm, 1.0, c->wv.p, nm, 1.0, x, nm);
+    } else {
+      precond_apply(c, bt, c->wv.p, nm, c->zv.p);
+      launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
+    }
   }
   if (relres_host) {
     // true residuals
