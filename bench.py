@@ -363,7 +363,8 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
                steps=steps, warmup=warmup, n=int(n), m=int(w["m"]), shifts=len(ms), col_parts=parts,
                gmres_nonconverged=info["gmres_nonconverged"], gmres_worst_relres=info["gmres_worst_relres"],
                gmres_iters_per_shift_solve=round(ops.gmres_iters / max(ops.shift_solves, 1), 1),
-               final_residual_fro=info["res_fro"])
+               final_residual_fro=info["res_fro"],
+               preconditioner_levels=ctx.setup_info()["levels"], dense_coarse_dim=ctx.setup_info()["dense_coarse"])
     ctx.close()
     return res
 

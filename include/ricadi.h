@@ -59,6 +59,14 @@ typedef struct ricadi_opts {
   int agg_p;             /* pressure aggregate size of the coarse level     */
   int coarse_max;        /* cap on coarse dimension (default 4096)          */
   int use_coarse;        /* 0: one-level block-Jacobi only                  */
+  int max_levels;        /* 2: two-level method only.  3 (default): where the coarse problem of the
+                            aggregates exceeds coarse_max, it is handed to a child level (the same
+                            preconditioner on its Galerkin matrices, aggregates = pairs of velocity
+                            aggregates + single pressure aggregates, dense inverse <= coarse_max*9/8)
+                            instead of growing the aggregates until a dense inverse fits; the
+                            aggregates then only grow (x1.5 per step) until that gentle child fits:
+                            0.55 k_v + k_p <= coarse_max (n ~ 1e5 keeps agg_v / agg_p).  A harder-
+                            coarsened child makes GMRES stagnate              */
   int verbose;
   int compress_qr;       /* ricadi_compress: 0 = Gram matrix + eigendecomposition
                             (fast; resolves singular values down to sqrt(eps)*s_1),

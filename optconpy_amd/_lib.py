@@ -24,7 +24,7 @@ class RicadiOpts(C.Structure):
     _fields_ = [("gmres_tol", C.c_double), ("gmres_restart", C.c_int),
                 ("gmres_maxit", C.c_int), ("bj_block", C.c_int), ("agg_v", C.c_int),
                 ("agg_p", C.c_int), ("coarse_max", C.c_int), ("use_coarse", C.c_int),
-                ("verbose", C.c_int), ("compress_qr", C.c_int)]
+                ("max_levels", C.c_int), ("verbose", C.c_int), ("compress_qr", C.c_int)]
 
 
 class RicadiAdiParams(C.Structure):
@@ -502,9 +502,10 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 8)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 8))
-        return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols"), list(a)))
+        a = (C.c_int * 10)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 10))
+        return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
+                         "dense_coarse"), list(a)))
 
     def time_qr_dev(self, z_ptr, c, reps):
         ms = C.c_double(0.0)

@@ -107,8 +107,39 @@ static void lists_from_blocks(int n, const int* blk, int nb, std::vector<int>& p
   for (int i = 0; i < n; ++i) rows[pos[blk[i]]++] = i;
 }
 
+// Galerkin product R^T M C for aggregation maps: entry (i, j) of M goes to (rowmap[i], colmap[j]).
+// rows_ptr / rows_list: the fine rows of every coarse row.
+static HostCsr galerkin(const HostCsr& M, int nrow_c, const int* rows_ptr, const int* rows_list, int row_off,
+                        const int* colmap, int ncol_c) {
+  HostCsr out;
+  out.nrows = nrow_c;
+  out.ncols = ncol_c;
+  out.rp.assign(1, 0);
+  std::vector<int> where(ncol_c, -1);
+  for (int a = 0; a < nrow_c; ++a) {
+    const int r0 = (int)out.ci.size();
+    for (int q = rows_ptr[a]; q < rows_ptr[a + 1]; ++q) {
+      const int i = rows_list[q] - row_off;
+      for (int k = M.rp[i]; k < M.rp[i + 1]; ++k) {
+        const int cj = colmap[M.ci[k]];
+        int at = where[cj];
+        if (at < r0) {
+          at = (int)out.ci.size();
+          where[cj] = at;
+          out.ci.push_back(cj);
+          out.v.push_back(0.0);
+        }
+        out.v[at] += M.v[k];
+      }
+    }
+    out.rp.push_back((int)out.ci.size());
+  }
+  sort_rows(out);
+  return out;
+}
+
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
-                 HostSetup& hs) {
+                 HostSetup& hs, int max_levels) {
   const int nv = A.nrows, np = J.nrows, n = nv + np;
   hs.nv = nv;
   hs.np = np;
@@ -329,6 +360,22 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
     kv = aggregate(nv, g_rp, g_ci, av, va.data());
     kp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), ap, pa.data()) : 0;
     if (kv + kp <= std::max(16, o.coarse_max)) break;
+    // A third level, only where it can be GENTLE: the coarse problem of these aggregates goes to a
+    // child level whose own aggregates are pairs of velocity aggregates and single pressure aggregates
+    // (so that the child's two-level cycle is a near-exact solve).  Coarsening the child harder makes
+    // its cycle -- one multiplicative coarse correction + one SIMPLE sweep, not a contraction -- too
+    // poor a stand-in for the coarse solve: GMRES stagnates (measured at n = 5e5 with every tried
+    // pair of level-2 aggregate sizes).  Larger problems therefore still grow the
+    // aggregates of THIS level, but only until the gentle child fits (in steps of 1.5, not 2).
+    if (max_levels > 2 && np > 0 && 0.55 * kv + kp <= std::max(16, o.coarse_max)) {
+      hs.multilevel = true;
+      break;
+    }
+    if (max_levels > 2 && np > 0) {
+      av += av / 2;
+      ap += ap / 2;
+      continue;
+    }
     av *= 2;
     ap *= 2;
   }
@@ -339,6 +386,11 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   for (int i = 0; i < nv; ++i) hs.aggof[i] = va[i];
   for (int k = 0; k < np; ++k) hs.aggof[nv + k] = kv + pa[k];
   lists_from_blocks(n, hs.aggof.data(), kc, hs.agg_ptr, hs.agg_rows);
+  if (hs.multilevel) {
+    hs.l1A = galerkin(A, kv, hs.agg_ptr.data(), hs.agg_rows.data(), 0, va.data(), kv);
+    hs.l1E = galerkin(E, kv, hs.agg_ptr.data(), hs.agg_rows.data(), 0, va.data(), kv);
+    hs.l1J = galerkin(J, kp, hs.agg_ptr.data() + kv, hs.agg_rows.data(), nv, va.data(), kv);
+  } else {
   hs.E0.assign((size_t)kc * kc, 0.0);
   hs.EM.assign((size_t)kc * kc, 0.0);
   hs.EJ.assign((size_t)kc * kc, 0.0);
@@ -353,6 +405,7 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       hs.EJ[(size_t)cp * kc + cv] += J.v[q];
       hs.EJ[(size_t)cv * kc + cp] += J.v[q];
     }
+  }
   // ---- prolongated operator S*Y (n x kc, sparse) -----------------------------
   // Row i of the unified saddle pattern with its columns mapped to their aggregates and
   // duplicates merged (a row touches ~6 aggregates instead of ~28 columns).  The

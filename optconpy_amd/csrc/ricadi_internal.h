@@ -62,6 +62,10 @@ struct HostSetup {
   std::vector<int> agg_ptr, agg_rows;  // aggregates over all n dofs
   std::vector<int> aggof;              // n -> coarse index
   std::vector<double> E0, EM, EJ;      // kc x kc dense
+  // Multilevel: the coarse saddle problem is NOT inverted densely (kc > coarse_max with the base
+  // aggregate sizes); its Galerkin matrices Yv^T A Yv, Yv^T E Yv, Yp^T J Yv go to a child level.
+  bool multilevel = false;
+  HostCsr l1A, l1E, l1J;
   // S * Y: CSR over (row, aggregate) with the three value sources of the saddle pattern
   std::vector<int> sy_rp, sy_ci;
   std::vector<double> sy_A, sy_E, sy_J;
@@ -71,7 +75,7 @@ struct HostSetup {
   std::vector<uint16_t> syb_lidx;
 };
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
-                 HostSetup& hs);
+                 HostSetup& hs, int max_levels = 2);
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
 
 // ---- batches of panels ------------------------------------------------------------

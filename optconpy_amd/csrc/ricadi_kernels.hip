@@ -12,6 +12,7 @@
 //   * reductions over rows are two-stage (per-workgroup partials, then a small
 //     reduce kernel), so results are bitwise reproducible run to run.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ricadi_internal.h"
 
@@ -873,6 +874,233 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GroupTab gt, int n
 
 int dots_num_blocks(int nrows) { return (nrows + DOT_ROWS - 1) / DOT_ROWS; }
 
+// ---------------------------------------------------------------------------
+// K3, FP16-stored basis with 16-column panels (the hot case): the same three Arnoldi passes
+// with 16-byte (8 x FP16) basis loads.  The generic kernels above read 2 bytes per lane and
+// load, which is fine while the launches are latency bound (n ~ 3e4) and leaves them at
+// 0.34-0.46 of the HBM roofline at n = 5e5.
+//   dots: lane = (row slice s = lane & 15, column half, vector) -- the 16 lanes of a DPP row
+//   hold the 16 row slices of ONE (vector, half), each lane runs over rows s, s+16, s+32, s+48
+//   of the 64-row chunk with its 4 loads in flight, and the row sum is 4 DPP exchanges.
+// ---------------------------------------------------------------------------
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_xchg(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ double dpp_row_sum(double v) {
+  v += dpp_xchg<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_xchg<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_xchg<0x141>(v);   // row_half_mirror
+  v += dpp_xchg<0x140>(v);   // row_mirror
+  return v;
+}
+
+// dot products of the chunk held in wl (DOT_ROWS x 16 doubles, rows >= nr zeroed) against the
+// basis vectors [0, nvec) and, if want_self, against itself (output row nvec)
+__device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis, size_t vstride, int r0, int nr,
+                                             int nvec, int want_self, const double* wl,
+                                             double* __restrict__ pout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, half = (lane >> 4) & 1, vsub = lane >> 5;
+  const int ntot = nvec + (want_self ? 1 : 0);
+  for (int i0 = 0; i0 < ntot; i0 += 8) {
+    const int i = i0 + 2 * wave + vsub;
+    double acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.0;
+    if (i < nvec) {
+      const _Float16* v = basis + (size_t)i * vstride + (size_t)r0 * 16 + half * 8;
+      half8_t x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = s + 16 * k;
+        if (row < nr) x[k] = *reinterpret_cast<const half8_t*>(v + (size_t)row * 16);
+        else x[k] = (half8_t)(_Float16)0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double* wr = wl + (s + 16 * k) * 16 + half * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = fma((double)x[k][t], wr[t], acc[t]);
+      }
+    } else if (i == nvec && want_self) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double* wr = wl + (s + 16 * k) * 16 + half * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = fma(wr[t], wr[t], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = dpp_row_sum(acc[t]);
+    if (s == 0 && i < ntot) {
+      double2* o = reinterpret_cast<double2*>(pout + (size_t)i * 16 + half * 8);
+      o[0] = make_double2(acc[0], acc[1]);
+      o[1] = make_double2(acc[2], acc[3]);
+      o[2] = make_double2(acc[4], acc[5]);
+      o[3] = make_double2(acc[6], acc[7]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cols_dots16_kernel(
+    GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
+  __shared__ double wl[DOT_ROWS * 16];
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  {
+    const double2* src = reinterpret_cast<const double2*>(w + (size_t)r0 * 16);
+    double2* dst = reinterpret_cast<double2*>(wl);
+    for (int e = threadIdx.x; e < DOT_ROWS * 8; e += 256) dst[e] = e < nr * 8 ? src[e] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  const int nout = (nvec + (want_self ? 1 : 0)) * 16;
+  chunk_dots16(basis, vstride, r0, nr, nvec, want_self, wl, partial + (size_t)blockIdx.x * nout);
+}
+
+// w' = w - V h (written back), then the dots of w' against V and itself: thread = (row, quarter) with
+// 8-byte basis loads for the update, chunk_dots16 for the dots
+__global__ __launch_bounds__(256) void cols_update_dots16_kernel(
+    GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
+    double* __restrict__ partial, size_t gsp) {
+  extern __shared__ double sm16[];
+  double* wl = sm16;                       // DOT_ROWS x 16
+  double* hl = sm16 + DOT_ROWS * 16;       // nvec x 16
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
+  __syncthreads();
+  {
+    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (row < nr) {
+      const size_t e = ((size_t)(r0 + row)) * 16 + q * 4;
+      const _Float16* v = basis + e;
+      int i = 0;
+      for (; i + 3 < nvec; i += 4) {
+        half4_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const half4_t*>(v + (size_t)(i + u) * vstride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) a[t] = fma(hl[(i + u) * 16 + q * 4 + t], (double)x[u][t], a[t]);
+      }
+      for (; i < nvec; ++i) {
+        const half4_t x = *reinterpret_cast<const half4_t*>(v + (size_t)i * vstride);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = fma(hl[i * 16 + q * 4 + t], (double)x[t], a[t]);
+      }
+      double2* wp = reinterpret_cast<double2*>(w + e);
+      const double2 w0 = wp[0], w1 = wp[1];
+      a[0] = w0.x - a[0];
+      a[1] = w0.y - a[1];
+      a[2] = w1.x - a[2];
+      a[3] = w1.y - a[3];
+      wp[0] = make_double2(a[0], a[1]);
+      wp[1] = make_double2(a[2], a[3]);
+    }
+    double2* wd = reinterpret_cast<double2*>(wl + row * 16 + q * 4);
+    wd[0] = make_double2(a[0], a[1]);      // rows >= nr: zeros
+    wd[1] = make_double2(a[2], a[3]);
+  }
+  __syncthreads();
+  chunk_dots16(basis, vstride, r0, nr, nvec, 1, wl, partial + (size_t)blockIdx.x * (nvec + 1) * 16);
+}
+
+// out = scale * (w + sign * V h), stored in FP16 (outf) and, rounded identically, in FP64 (out):
+// thread = (row, column half), 16-byte basis loads, four vectors in flight
+__global__ __launch_bounds__(256) void cols_update16_kernel(
+    GroupTab gt, size_t nhalf, GroupInts nvecs, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ h, size_t gsh, double sign, const double* __restrict__ w, size_t gsw,
+    const double* __restrict__ scale, double* __restrict__ out, size_t gso, _Float16* __restrict__ outf,
+    size_t gsf) {
+  extern __shared__ double hl[];           // nvec x 16
+  const int grp = gt.gid[blockIdx.z];
+  const int nvec = nvecs.v[grp];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  if (w) w += (size_t)grp * gsw;
+  if (scale) scale += (size_t)grp * 16;
+  out += (size_t)grp * gso;
+  if (outf) outf += (size_t)grp * gsf;
+  for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
+  __syncthreads();
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nhalf; idx += (size_t)gridDim.x * 256) {
+    const size_t e = idx * 8;
+    const int c0 = (int)(idx & 1) * 8;
+    double a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = 0.0;
+    const _Float16* v = basis + e;
+    int i = 0;
+    for (; i + 3 < nvec; i += 4) {
+      half8_t x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const half8_t*>(v + (size_t)(i + u) * vstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = fma(hl[(i + u) * 16 + c0 + t], (double)x[u][t], a[t]);
+    }
+    for (; i < nvec; ++i) {
+      const half8_t x = *reinterpret_cast<const half8_t*>(v + (size_t)i * vstride);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] = fma(hl[i * 16 + c0 + t], (double)x[t], a[t]);
+    }
+    if (w) {
+      const double2* wp = reinterpret_cast<const double2*>(w + e);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 ww = wp[t];
+        a[2 * t] = ww.x + sign * a[2 * t];
+        a[2 * t + 1] = ww.y + sign * a[2 * t + 1];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] *= sign;
+    }
+    if (scale) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] *= scale[c0 + t];
+    }
+    if (outf) {
+      half8_t f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        f[t] = (_Float16)a[t];
+        a[t] = (double)f[t];
+      }
+      *reinterpret_cast<half8_t*>(outf + e) = f;
+    }
+    double2* op = reinterpret_cast<double2*>(out + e);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) op[t] = make_double2(a[2 * t], a[2 * t + 1]);
+  }
+}
+static bool arnoldi16() {
+  static const bool on = !(getenv("RICADI_ARNOLDI16") && atoi(getenv("RICADI_ARNOLDI16")) == 0);
+  return on;
+}
+
 template <class BT>
 static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                            const BT* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
@@ -880,6 +1108,15 @@ static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + (want_self ? 1 : 0)) * m;
   if (nout == 0 || gt.ng <= 0) return;
+  if constexpr (std::is_same<BT, _Float16>::value) {
+    if (m == 16 && arnoldi16()) {
+      hipLaunchKernelGGL(cols_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
+                         vstride, gsb, w, gsw, want_self, partial, gsp);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                         nblk, nout, partial, gsp, out, gso, 0);
+      return;
+    }
+  }
   hipLaunchKernelGGL(cols_dots_kernel<BT>, dim3(nblk, 1, gt.ng), dim3(256),
                      DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, w,
                      gsw, want_self, partial, gsp);
@@ -980,6 +1217,16 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
   if (gt.ng <= 0) return;
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + 1) * m;
+  if constexpr (std::is_same<BT, _Float16>::value) {
+    if (m == 16 && arnoldi16() && (size_t)(DOT_ROWS + nvec) * 16 * sizeof(double) <= 48 * 1024) {
+      hipLaunchKernelGGL(cols_update_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+                         (size_t)(DOT_ROWS + nvec) * 16 * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb,
+                         h, gsh, w, gsw, partial, gsp);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                         nblk, nout, partial, gsp, out, gso, 0);
+      return;
+    }
+  }
   hipLaunchKernelGGL(cols_update_dots_kernel<BT>, dim3(nblk, 1, gt.ng), dim3(256),
                      DOT_ROWS * m * sizeof(double), st, gt, nrows, m, nvec, basis, vstride, gsb, h,
                      gsh, w, gsw, partial, gsp);
@@ -1055,6 +1302,18 @@ static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int 
                              double* out, size_t gso, BT* outf, size_t gsf) {
   size_t nelem = (size_t)nrows * m;
   if (!nelem || gt.ng <= 0) return;
+  if constexpr (std::is_same<BT, _Float16>::value) {
+    int nmax = 0;
+    for (int i = 0; i < gt.ng; ++i) nmax = std::max(nmax, nvec.v[gt.gid[i]]);
+    if (m == 16 && arnoldi16() && (size_t)nmax * 16 * sizeof(double) <= 48 * 1024) {
+      const size_t nhalf = (size_t)nrows * 2;
+      const int grid16 = (int)std::min<size_t>((nhalf + 255) / 256, 8192);
+      hipLaunchKernelGGL(cols_update16_kernel, dim3(grid16, 1, gt.ng), dim3(256),
+                         (size_t)std::max(nmax, 1) * 16 * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb,
+                         h, gsh, sign, w, gsw, scale, out, gso, outf, gsf);
+      return;
+    }
+  }
   int grid = (int)std::min<size_t>((nelem + 255) / 256, 8192);
   hipLaunchKernelGGL(cols_update_kernel<BT>, dim3(grid, 1, gt.ng), dim3(256), 0, st, gt, nelem, m,
                      nvec, basis, vstride, gsb, h, gsh, sign, w, gsw, scale, out, gso, outf, gsf);

@@ -194,6 +194,7 @@ struct ShiftData {
   // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
   DArr<double> smw_w;
   long smw_epoch = -1;
+  ShiftData* sub = nullptr;   // the same shift on the child level (multilevel preconditioner)
 };
 
 struct DevCsr {
@@ -227,6 +228,13 @@ struct ricadi_ctx {
   int dev = 0;
   hipStream_t st = nullptr;
   rocblas_handle rb = nullptr;
+  // Multilevel preconditioner: when the coarse saddle problem of this level is too large for a
+  // dense inverse (kc > coarse_max at the base aggregate sizes) it becomes the operator of a child
+  // context (same stream and rocBLAS handle, borrowed), whose own preconditioner cycle -- sweep +
+  // coarse correction, again dense or through a grandchild -- replaces the dense coarse apply.
+  std::unique_ptr<ricadi_ctx> child;
+  bool borrowed = false;      // st / rb belong to the parent level
+  int levels = 2;             // levels this context may use (RICADI_LEVELS; 2 = two-level only)
   ricadi_opts opts;
   bool has_op = false;
   int nv = 0, np = 0, n = 0;
@@ -320,11 +328,12 @@ struct ricadi_ctx {
     if (h_resid) (void)hipHostFree(h_resid);
     for (int i = 0; i < 2; ++i)
       if (ev_res[i]) (void)hipEventDestroy(ev_res[i]);
-    if (rb) rocblas_destroy_handle(rb);
+    child.reset();
+    if (rb && !borrowed) rocblas_destroy_handle(rb);
     if (rb2) rocblas_destroy_handle(rb2);
     if (ev_z) (void)hipEventDestroy(ev_z);
     if (st2) (void)hipStreamDestroy(st2);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && !borrowed) (void)hipStreamDestroy(st);
   }
 };
 
@@ -339,6 +348,10 @@ namespace ricadi {
 static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   const int restart = c->opts.gmres_restart;
   if (extra < 0) extra = std::max(c->q, 0);
+  if (c->child) {
+    c->child->opts.gmres_restart = std::min(c->opts.gmres_restart, 4);   // its Krylov buffers are not used
+    ensure_work(c->child.get(), m, groups, extra);
+  }
   // every buffer scales with the total number of columns (m + extra) * groups
   const int want = (m + extra) * groups;
   if (want <= c->wcols && restart == c->wrestart) return;
@@ -428,6 +441,17 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
   HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
   const size_t bsz = (size_t)c->bs * c->bs;
   const int k = c->kc;
+  const int kd = c->child ? 0 : c->kc;   // size of the dense coarse inverse (none with a child level)
+  if (c->child) {
+    std::vector<double> al(todo.size()), be(todo.size());
+    std::vector<ShiftData*> subs(todo.size(), nullptr);
+    for (size_t i = 0; i < todo.size(); ++i) {
+      al[i] = todo[i]->alpha;
+      be[i] = todo[i]->beta;
+    }
+    get_shifts(c->child.get(), al.data(), be.data(), (int)todo.size(), subs.data());
+    for (size_t i = 0; i < todo.size(); ++i) todo[i]->sub = subs[i];
+  }
   for (ShiftData* sd : todo) {
     const double alpha = sd->alpha, beta = sd->beta;
     stable_alloc(sd->sval, c->snnz);
@@ -442,9 +466,11 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     if (c->nbp > 0) stable_alloc(sd->bpinv, (size_t)c->nbp * bsz);
     if (c->gt_ok) stable_alloc(sd->gtm, (size_t)c->nbv * c->bs * c->gt_ks);
     if (c->ady_ok && k > 0) stable_alloc(sd->adym, (size_t)c->nbv * c->bs * c->ady_ks);
-    if (k > 0) {
+    if (kd > 0) {
       stable_alloc(sd->einv, (size_t)k * k);
       launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, alpha, beta, sd->einv.p);
+    }
+    if (k > 0) {
       stable_alloc(sd->syval, c->synnz);
       launch_assemble_shift(st, (int)c->synnz, c->sy_A.p, c->sy_E.p, c->sy_J.p, alpha, beta,
                             sd->syval.p);
@@ -486,7 +512,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
   }
   const int nb = (int)todo.size();
   std::vector<int> info(nb, 0);
-  if (k > 0) {
+  if (kd > 0) {
     // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
     c->ipiv.ensure((size_t)k * nb);
     c->info.ensure(nb);
@@ -549,7 +575,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         if (sd->adymf.n != sd->adym.n) sd->adymf.alloc(sd->adym.n);
         launch_to_f32(st, c->nbv, gsz, sd->adym.p, gsz, sd->adymf.p, gsz);
       }
-      if (k > 0) {
+      if (kd > 0) {
         const size_t kp = (size_t)(k + 15) / 16;
         if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
         launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
@@ -580,6 +606,7 @@ struct Batch {
   GroupPtrs gtm, adym;
   GroupPtrsF gtmf, adymf;
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
+  std::shared_ptr<Batch> sub;                 // the same groups on the child level
 
   void all() {
     tab.ng = G;
@@ -628,6 +655,11 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.gsc = (size_t)c->kc * m;
   bt.gsq = (size_t)std::max(c->q, 1) * m;
   bt.all();
+  if (c->child) {
+    ShiftData* subs[RICADI_MAX_GROUPS];
+    for (int g = 0; g < G; ++g) subs[g] = sds[g]->sub;
+    bt.sub = std::make_shared<Batch>(make_batch(c->child.get(), subs, G, m));
+  }
   return bt;
 }
 static Batch make_batch(ricadi_ctx* c, ShiftData* sd, int m) { return make_batch(c, &sd, 1, m); }
@@ -708,7 +740,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
                   bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
-    if (c->precond32)
+    if (c->child) {
+      // coarse problem by one cycle of the child level's preconditioner (a fixed linear operator)
+      Batch cb = *bt.sub;
+      cb.tab = gt;
+      precond_apply(c->child.get(), cb, c->rc.p, bt.gsc, c->ec.p);
+    } else if (c->precond32)
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
@@ -1963,11 +2000,11 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 200; }
+int ricadi_version(void) { return 210; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
-const char* ricadi_struct_signature(void) { return "ricadi_opts:diiiiiiiii;ricadi_adi_params:ididdiiii"; }
+const char* ricadi_struct_signature(void) { return "ricadi_opts:diiiiiiiiii;ricadi_adi_params:ididdiiii"; }
 
 void ricadi_default_opts(ricadi_opts* o) {
   if (!o) return;
@@ -1979,6 +2016,7 @@ void ricadi_default_opts(ricadi_opts* o) {
   o->agg_p = 24;
   o->coarse_max = 4096;
   o->use_coarse = 1;
+  o->max_levels = 3;
   o->verbose = 0;
   o->compress_qr = 0;
 }
@@ -2036,6 +2074,7 @@ int ricadi_set_opts(ricadi_ctx* c, const ricadi_opts* o) {
   REQUIRE(o->gmres_tol > 0 && o->gmres_maxit > 0, RICADI_EINVAL, "bad gmres_tol / gmres_maxit");
   const bool structural = c->has_op && (o->bj_block != c->opts.bj_block || o->agg_v != c->opts.agg_v ||
                                         o->agg_p != c->opts.agg_p || o->coarse_max != c->opts.coarse_max ||
+                                        o->max_levels != c->opts.max_levels ||
                                         o->use_coarse != c->opts.use_coarse);
   REQUIRE(!structural, RICADI_ESTATE, "preconditioner options must be set before ricadi_set_operator");
   c->opts = *o;
@@ -2081,8 +2120,34 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   for (size_t k = 0; k < J.nnz(); ++k)
     if (J.ci[k] < 0 || J.ci[k] >= nv) throw ricadi::HipError{"J: column index out of range"};
   HostSetup hs;
-  build_setup(A, E, J, c->opts, hs);
+  if (!c->borrowed)
+    c->levels = getenv("RICADI_LEVELS") ? std::max(2, atoi(getenv("RICADI_LEVELS"))) : std::max(2, c->opts.max_levels);
+  build_setup(A, E, J, c->opts, hs, c->levels);
   c->cache.clear();
+  c->child.reset();
+  if (hs.multilevel) {
+    std::unique_ptr<ricadi_ctx> ch(new ricadi_ctx);
+    ch->dev = c->dev;
+    ch->st = c->st;
+    ch->rb = c->rb;
+    ch->borrowed = true;
+    ch->opts = c->opts;
+    // aggregates of the child level (in units of ITS dofs = this level's aggregates); they double
+    // until the last level's dense inverse fits coarse_max
+    ch->opts.agg_v = getenv("RICADI_L2_AV") ? std::max(1, atoi(getenv("RICADI_L2_AV"))) : 2;
+    ch->opts.agg_p = getenv("RICADI_L2_AP") ? std::max(1, atoi(getenv("RICADI_L2_AP"))) : 1;
+    ch->opts.coarse_max = c->opts.coarse_max + c->opts.coarse_max / 8;   // pairs do not always pair up
+    ch->levels = 2;
+    ch->precond32 = c->precond32;
+    ch->smw = c->smw;
+    ch->flag.alloc(4);
+    ch->info.alloc(4);
+    const int rc = ricadi_set_operator(ch.get(), hs.kcv, hs.kcp, hs.l1A.rp.data(), hs.l1A.ci.data(), hs.l1A.v.data(),
+                                       hs.l1E.rp.data(), hs.l1E.ci.data(), hs.l1E.v.data(), hs.l1J.rp.data(),
+                                       hs.l1J.ci.data(), hs.l1J.v.data());
+    if (rc != RICADI_OK) throw ricadi::HipError{std::string("child level: ") + ricadi_last_error()};
+    c->child = std::move(ch);
+  }
   c->nv = nv;
   c->np = np;
   c->n = nv + np;
@@ -2326,7 +2391,8 @@ int ricadi_clear_cache(ricadi_ctx* c) {
   REQUIRE(c, RICADI_EINVAL, "NULL ctx");
   API_BEGIN
   HIPCHK(hipStreamSynchronize(c->st));
-  for (auto& kv : c->cache) kv.second->valid = false;   // buffers (and iteration graphs) stay
+  for (ricadi_ctx* l = c; l; l = l->child.get())
+    for (auto& kv : l->cache) kv.second->valid = false;   // buffers (and iteration graphs) stay
   API_END
 }
 
@@ -2732,10 +2798,21 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         break;
       case 3:
         if (c->kc <= 0) throw HipError{"no coarse level"};
-        if (c->precond32)
-          launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
-        else
-          launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
+        {
+          // the dense inverse lives on the last level
+          ricadi_ctx* lc = c;
+          Batch lb = bt;
+          while (lc->child) {
+            Batch t = *lb.sub;
+            t.tab = gt;
+            lb = t;
+            lc = lc->child.get();
+          }
+          if (c->precond32)
+            launch_dense_apply_b(st, gt, lc->kc, m, lb.einvf, (lc->kc + 3) & ~3, lc->rc.p, lc->ec.p);
+          else
+            launch_dense_apply_b(st, gt, lc->kc, m, lb.einv, lc->rc.p, lc->ec.p);
+        }
         break;
       case 4:
         if (!c->syb_ok) throw HipError{"no tiled S*Y"};
@@ -2820,6 +2897,12 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   out[6] = c->sb_nblk;
   out[7] = c->sb_max_cols;
   for (int i = 8; i < nout; ++i) out[i] = 0;
+  // [8]: levels in use; [9]: size of the dense inverse on the last level
+  int lv = c->kc > 0 ? 2 : 1;
+  const ricadi_ctx* lc = c;
+  for (; lc->child; lc = lc->child.get()) ++lv;
+  if (nout > 8) out[8] = lv;
+  if (nout > 9) out[9] = lc->kc;
   return RICADI_OK;
 }
 

@@ -78,15 +78,19 @@ def test_cfg2_newton_adi_gain_vs_oracle_fixture():
 
 
 # --------------------------------------------------------------------- cfg3 / cfg4 / cfg5
-def _batched_properties(calA, calE, J, shifts, R, tol=1e-10, coarse_max=None):
+def _batched_properties(calA, calE, J, shifts, R, tol=1e-10, coarse_max=None, max_levels=None, info=None):
     """One batched solve of len(shifts) shifts against the shared panel R through the C-ABI;
     every property is recomputed on the host with scipy."""
     import torch
     nv, m = R.shape
     npr = J.shape[0]
     opts = {} if coarse_max is None else dict(coarse_max=coarse_max)
+    if max_levels is not None:
+        opts["max_levels"] = max_levels
     ctx = _lib.Context(0, **opts)
     ctx.set_operator(calA, calE, J)
+    if info is not None:
+        info.update(ctx.setup_info())
     dev = torch.device("cuda", 0)
     Rd = torch.as_tensor(R).to(dev)
     G = len(shifts)
@@ -141,8 +145,27 @@ def test_cfg4_dre_operator_wide_panel_properties():
     ft = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
     ms = pb.logshifts(0.5, 2e3, 64)[::4]
     R = np.random.default_rng(4).standard_normal((pr.NV, 66))
-    its, worst = _batched_properties(ft, MT, pr.J, ms, R)
+    info = {}
+    its, worst = _batched_properties(ft, MT, pr.J, ms, R, info=info)
+    assert info["levels"] == 3 and info["dense_coarse"] <= 4096 + 512     # the gentle third level serves this size
     print("cfg4: tau %.4f iterations per shift" % tau, its, "worst true residual %.2e" % worst)
+
+
+def test_third_level_forced_small_problem():
+    """The child-level path (coarse problem handed to a second context instead of a dense inverse) on a
+    problem small enough for the quick suite: N = 30 with coarse_max = 300 takes three levels, and the
+    same solve with max_levels = 2 (aggregates grown instead) must not need fewer iterations."""
+    pr = pb.ricc_problem(30, 0.05)
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    ms = [float(p) for p in pb.logshifts(1.0, 1e3, 8)]
+    R = np.random.default_rng(6).standard_normal((pr.NV, 16))
+    i3, i2 = {}, {}
+    its3, w3 = _batched_properties(calA, pr.M.T.tocsr(), pr.J, ms, R, coarse_max=300, info=i3)
+    its2, w2 = _batched_properties(calA, pr.M.T.tocsr(), pr.J, ms, R, coarse_max=300, max_levels=2, info=i2)
+    assert i3["levels"] == 3 and i2["levels"] == 2, (i3, i2)
+    assert i3["kc"] > 300 >= i2["kc"]
+    assert sum(its3) <= sum(its2), (its3, its2)
+    print("forced third level: iterations", its3, "two-level", its2)
 
 
 def test_cfg5_batched_shift_solves_properties():

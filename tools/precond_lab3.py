@@ -132,6 +132,32 @@ if __name__ == "__main__":
         "3-level K2 c4": dict(depth=1, inner=2, av_c=4, ap_c=6),
         "3-level K4 c4": dict(depth=1, inner=4, av_c=4, ap_c=6),
         "3-level c8": dict(depth=1, av_c=8, ap_c=12),
+        "3-level c16p1": dict(depth=1, av_c=16, ap_c=1),
+        "cm1000 3-level c2p2": dict(depth=1, av_c=2, ap_c=2, coarse_max=1000),
+        "cm1000 5-level c2p2": dict(depth=3, av_c=2, ap_c=2, coarse_max=1000),
+        "cm1000 5-level c2p1": dict(depth=3, av_c=2, ap_c=1, coarse_max=1000),
+        "cm1000 two-level": dict(depth=0, coarse_max=1000),
+        "cm1000 3-level K2": dict(depth=1, av_c=2, ap_c=2, coarse_max=1000, inner=2),
+        "cm1000 3-level K3": dict(depth=1, av_c=2, ap_c=2, coarse_max=1000, inner=3),
+        "cm1000 3-level K4": dict(depth=1, av_c=2, ap_c=2, coarse_max=1000, inner=4),
+        "cm1000 3-level K8": dict(depth=1, av_c=2, ap_c=2, coarse_max=1000, inner=8),
+        "cm1000 3-level K2 p3": dict(depth=1, av_c=2, ap_c=3, coarse_max=1000, inner=2),
+        "cm1000 3-level K4 p3": dict(depth=1, av_c=2, ap_c=3, coarse_max=1000, inner=4),
+        "cm1000 4-level c3p3": dict(depth=2, av_c=3, ap_c=3, coarse_max=1000),
+        "3-level c8p4": dict(depth=1, av_c=8, ap_c=4),
+        "3-level K2 c8p4": dict(depth=1, inner=2, av_c=8, ap_c=4),
+        "4-level c4p2": dict(depth=2, av_c=4, ap_c=2),
+        "4-level c4p3": dict(depth=2, av_c=4, ap_c=3),
+        "4-level K2 c4p2": dict(depth=2, av_c=4, ap_c=2, inner=2),
+        "two-level av64 ap6": dict(depth=0, av=64, ap=6),
+        "two-level av48 ap12": dict(depth=0, av=48, ap=12),
+        "two-level av256 ap24": dict(depth=0, av=256, ap=24),
+        "two-level av192 ap48": dict(depth=0, av=192, ap=48),
+        "3-level K2 c16p1": dict(depth=1, inner=2, av_c=16, ap_c=1),
+        "3-level K4 c16p1": dict(depth=1, inner=4, av_c=16, ap_c=1),
+        "3-level c2p1": dict(depth=1, av_c=2, ap_c=1),
+        "3-level K2 c2p1": dict(depth=1, inner=2, av_c=2, ap_c=1),
+        "3-level K4 c2p1": dict(depth=1, inner=4, av_c=2, ap_c=1),
         "3-level K2 c8": dict(depth=1, inner=2, av_c=8, ap_c=12),
         "3-level K3 c8": dict(depth=1, inner=3, av_c=8, ap_c=12),
         "3-level K4 c8": dict(depth=1, inner=4, av_c=8, ap_c=12),
