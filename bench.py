@@ -306,6 +306,15 @@ WORKLOADS = {
 }
 
 
+def _xopts():
+    """Developer hook for option sweeps: RICADI_OPTS="gmres_restart=40,agg_v=24"."""
+    xopts = {}
+    for kv in filter(None, os.environ.get("RICADI_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        xopts[k] = float(v) if "tol" in k else int(v)
+    return xopts
+
+
 def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_fn):
     """Times `steps` shift cycles of a WORKLOADS entry with the shift-parallel sweep driver (one
     process per GPU; at world size 1 the same code on one GPU).  Returns the result dict (rank 0)."""
@@ -322,7 +331,7 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
     else:
         calA = (-pr.A - pr.Nc).T.tocsr()
     ms = pb.logshifts(w["pmin"], w["pmax"], w["shifts"])
-    ctx = _lib.Context(local)
+    ctx = _lib.Context(local, **_xopts())
     ctx.set_operator(calA, MT, pr.J)
     ops = HipOps(ctx)
     # right-hand-side factor: seeded random panel, Leray-projected on the device
@@ -438,11 +447,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # developer hook for option sweeps: RICADI_OPTS="gmres_restart=40,agg_v=24"
-    xopts = {}
-    for kv in filter(None, os.environ.get("RICADI_OPTS", "").split(",")):
-        k, v = kv.split("=")
-        xopts[k] = float(v) if "tol" in k else int(v)
+    xopts = _xopts()
     if xopts:
         backend.configure(**xopts)
     t0 = time.time()

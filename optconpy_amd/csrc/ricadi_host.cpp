@@ -315,13 +315,25 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       std::sort(cols.begin(), cols.end());
       for (size_t j = 0; j < cols.size(); ++j) pos[cols[j]] = (int)j;
       const size_t nnz0 = hs.sb_perm.size();
+      // Entry order within a row: the kernel's 32-lane halves pair the local rows (2j, 2j+1), and
+      // their two ds_read_b64 of a step (16 columns = 128 B each) are conflict free iff the two tile
+      // rows have opposite parity (LDS bank = (byte / 4) mod 64).  Even local rows therefore list
+      // their even tile rows first, odd local rows their odd ones: the parities differ wherever both
+      // rows are in their first or both in their second part.
+      static const bool parity_order = !(getenv("RICADI_SB_PARITY") && atoi(getenv("RICADI_SB_PARITY")) == 0);
+      int ql = 0;
       for (int row : brows) {
-        for (int k = hs.s_rp[row]; k < hs.s_rp[row + 1]; ++k) {
-          hs.sb_perm.push_back(k);
-          hs.sb_lidx.push_back((uint16_t)pos[hs.s_ci[k]]);
-        }
+        for (int pass = 0; pass < 2; ++pass)
+          for (int k = hs.s_rp[row]; k < hs.s_rp[row + 1]; ++k) {
+            const int l = pos[hs.s_ci[k]];
+            const bool first = !parity_order || ((l & 1) == (ql & 1));
+            if (first != (pass == 0)) continue;
+            hs.sb_perm.push_back(k);
+            hs.sb_lidx.push_back((uint16_t)l);
+          }
         hs.sb_rows.push_back(row);
         hs.sb_rp.push_back((int)hs.sb_perm.size());
+        ++ql;
       }
       for (int c : cols) hs.sb_cols.push_back(c);
       hs.sb_cptr.push_back((int)hs.sb_cols.size());

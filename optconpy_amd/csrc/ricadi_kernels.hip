@@ -902,7 +902,10 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
   return v;
 }
 
-// dot products of the chunk held in wl (DOT_ROWS x 16 doubles, rows >= nr zeroed) against the
+// LDS row stride of the staged chunk: 18 doubles (144 B) -- with 16 the lanes of a DPP row (rows s, s+1, ...
+// 128 B apart) fall on two banks sets and every read is an 8-way conflict
+constexpr int WLS = 18;
+// dot products of the chunk held in wl (DOT_ROWS rows of 16 doubles, stride WLS; rows >= nr zeroed) against the
 // basis vectors [0, nvec) and, if want_self, against itself (output row nvec)
 __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis, size_t vstride, int r0, int nr,
                                              int nvec, int want_self, const double* wl,
@@ -926,14 +929,14 @@ __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis,
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const double* wr = wl + (s + 16 * k) * 16 + half * 8;
+        const double* wr = wl + (s + 16 * k) * WLS + half * 8;
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = fma((double)x[k][t], wr[t], acc[t]);
       }
     } else if (i == nvec && want_self) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const double* wr = wl + (s + 16 * k) * 16 + half * 8;
+        const double* wr = wl + (s + 16 * k) * WLS + half * 8;
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = fma(wr[t], wr[t], acc[t]);
       }
@@ -953,7 +956,7 @@ __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis,
 __global__ __launch_bounds__(256) void cols_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
-  __shared__ double wl[DOT_ROWS * 16];
+  __shared__ __attribute__((aligned(16))) double wl[DOT_ROWS * WLS];
   const int grp = gt.gid[blockIdx.z];
   basis += (size_t)grp * gsb;
   w += (size_t)grp * gsw;
@@ -962,23 +965,23 @@ __global__ __launch_bounds__(256) void cols_dots16_kernel(
   const int nr = min(DOT_ROWS, nrows - r0);
   {
     const double2* src = reinterpret_cast<const double2*>(w + (size_t)r0 * 16);
-    double2* dst = reinterpret_cast<double2*>(wl);
-    for (int e = threadIdx.x; e < DOT_ROWS * 8; e += 256) dst[e] = e < nr * 8 ? src[e] : make_double2(0.0, 0.0);
+    for (int e = threadIdx.x; e < DOT_ROWS * 8; e += 256)
+      *reinterpret_cast<double2*>(wl + (e >> 3) * WLS + (e & 7) * 2) = e < nr * 8 ? src[e] : make_double2(0.0, 0.0);
   }
   __syncthreads();
   const int nout = (nvec + (want_self ? 1 : 0)) * 16;
   chunk_dots16(basis, vstride, r0, nr, nvec, want_self, wl, partial + (size_t)blockIdx.x * nout);
 }
 
-// w' = w - V h (written back), then the dots of w' against V and itself: thread = (row, quarter) with
-// 8-byte basis loads for the update, chunk_dots16 for the dots
+// w' = w - V h (written back), then the dots of w' against V and itself (chunk_dots16; the basis chunk
+// is cache resident by then, so the LDS side decides: with unpadded rows this phase was 2x slower)
 __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
     double* __restrict__ partial, size_t gsp) {
-  extern __shared__ double sm16[];
-  double* wl = sm16;                       // DOT_ROWS x 16
-  double* hl = sm16 + DOT_ROWS * 16;       // nvec x 16
+  extern __shared__ __attribute__((aligned(16))) double sm16[];
+  double* wl = sm16;                       // DOT_ROWS rows, stride WLS
+  double* hl = sm16 + DOT_ROWS * WLS;      // nvec x 16
   const int grp = gt.gid[blockIdx.z];
   basis += (size_t)grp * gsb;
   h += (size_t)grp * gsh;
@@ -989,38 +992,25 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
   for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
   __syncthreads();
   {
-    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    if (row < nr) {
-      const size_t e = ((size_t)(r0 + row)) * 16 + q * 4;
-      const _Float16* v = basis + e;
-      int i = 0;
-      for (; i + 3 < nvec; i += 4) {
-        half4_t x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const half4_t*>(v + (size_t)(i + u) * vstride);
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) a[t] = fma(hl[(i + u) * 16 + q * 4 + t], (double)x[u][t], a[t]);
+    // update: one element per thread and pass (2-byte loads; the 16-byte form with the vectors split over
+    // lane pairs was slower at every basis size: 1.69 vs 1.02 ms at n = 5e5, 7 vectors)
+    const size_t base = (size_t)r0 * 16;
+    for (int e = threadIdx.x; e < DOT_ROWS * 16; e += 256) {
+      double v = 0.0;
+      if (e < nr * 16) {
+        const int c = e & 15;
+        double s0 = 0.0, s1 = 0.0;
+        int i = 0;
+        for (; i + 1 < nvec; i += 2) {
+          s0 = fma(hl[i * 16 + c], (double)basis[(size_t)i * vstride + base + e], s0);
+          s1 = fma(hl[(i + 1) * 16 + c], (double)basis[(size_t)(i + 1) * vstride + base + e], s1);
+        }
+        if (i < nvec) s0 = fma(hl[i * 16 + c], (double)basis[(size_t)i * vstride + base + e], s0);
+        v = w[base + e] - (s0 + s1);
+        w[base + e] = v;
       }
-      for (; i < nvec; ++i) {
-        const half4_t x = *reinterpret_cast<const half4_t*>(v + (size_t)i * vstride);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = fma(hl[i * 16 + q * 4 + t], (double)x[t], a[t]);
-      }
-      double2* wp = reinterpret_cast<double2*>(w + e);
-      const double2 w0 = wp[0], w1 = wp[1];
-      a[0] = w0.x - a[0];
-      a[1] = w0.y - a[1];
-      a[2] = w1.x - a[2];
-      a[3] = w1.y - a[3];
-      wp[0] = make_double2(a[0], a[1]);
-      wp[1] = make_double2(a[2], a[3]);
+      wl[(e >> 4) * WLS + (e & 15)] = v;
     }
-    double2* wd = reinterpret_cast<double2*>(wl + row * 16 + q * 4);
-    wd[0] = make_double2(a[0], a[1]);      // rows >= nr: zeros
-    wd[1] = make_double2(a[2], a[3]);
   }
   __syncthreads();
   chunk_dots16(basis, vstride, r0, nr, nvec, 1, wl, partial + (size_t)blockIdx.x * (nvec + 1) * 16);
@@ -1096,9 +1086,10 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
     for (int t = 0; t < 4; ++t) op[t] = make_double2(a[2 * t], a[2 * t + 1]);
   }
 }
-static bool arnoldi16() {
-  static const bool on = !(getenv("RICADI_ARNOLDI16") && atoi(getenv("RICADI_ARNOLDI16")) == 0);
-  return on;
+// RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update)
+static bool arnoldi16(int which) {
+  static const int mask = getenv("RICADI_ARNOLDI16") ? atoi(getenv("RICADI_ARNOLDI16")) : 7;
+  return (mask & which) != 0;
 }
 
 template <class BT>
@@ -1109,7 +1100,7 @@ static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
   const int nout = (nvec + (want_self ? 1 : 0)) * m;
   if (nout == 0 || gt.ng <= 0) return;
   if constexpr (std::is_same<BT, _Float16>::value) {
-    if (m == 16 && arnoldi16()) {
+    if (m == 16 && arnoldi16(1)) {
       hipLaunchKernelGGL(cols_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
                          vstride, gsb, w, gsw, want_self, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
@@ -1218,10 +1209,10 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + 1) * m;
   if constexpr (std::is_same<BT, _Float16>::value) {
-    if (m == 16 && arnoldi16() && (size_t)(DOT_ROWS + nvec) * 16 * sizeof(double) <= 48 * 1024) {
+    if (m == 16 && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double) <= 48 * 1024) {
       hipLaunchKernelGGL(cols_update_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256),
-                         (size_t)(DOT_ROWS + nvec) * 16 * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb,
-                         h, gsh, w, gsw, partial, gsp);
+                         (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
+                         gsb, h, gsh, w, gsw, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                          nblk, nout, partial, gsp, out, gso, 0);
       return;
@@ -1305,7 +1296,7 @@ static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int 
   if constexpr (std::is_same<BT, _Float16>::value) {
     int nmax = 0;
     for (int i = 0; i < gt.ng; ++i) nmax = std::max(nmax, nvec.v[gt.gid[i]]);
-    if (m == 16 && arnoldi16() && (size_t)nmax * 16 * sizeof(double) <= 48 * 1024) {
+    if (m == 16 && arnoldi16(4) && (size_t)nmax * 16 * sizeof(double) <= 48 * 1024) {
       const size_t nhalf = (size_t)nrows * 2;
       const int grid16 = (int)std::min<size_t>((nhalf + 255) / 256, 8192);
       hipLaunchKernelGGL(cols_update16_kernel, dim3(grid16, 1, gt.ng), dim3(256),
