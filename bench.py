@@ -150,7 +150,7 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     al, be = [float(p) for p in shifts], [1.0] * G
     n, nv = ctx.n, ctx.nv
     info = ctx.setup_info()
-    nb, kc = info["nbv"], info["kc"]
+    nb, kc = info["nbv"], info.get("dense_coarse", info["kc"])   # the dense inverse of the LAST preconditioner level
     b = 8 if os.environ.get("RICADI_BASIS64") else (4 if os.environ.get("RICADI_BASIS32") else 2)
     pb_ = 8 if os.environ.get("RICADI_PRECOND64") else 4
     kp = 16 * ((kc + 15) // 16)

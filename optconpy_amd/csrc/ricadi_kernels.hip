@@ -2323,7 +2323,8 @@ static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, 
   if (k <= 0 || gt.ng <= 0) return;
   const int kp = (k + 15) / 16;
   // one row tile per workgroup: four tiles per workgroup (rc values loaded once for four MFMA
-  // groups) measured no faster -- 133 VGPRs, 3 waves per SIMD: 63 vs 57-63 us at cfg2, G = 16
+  // groups) measured no faster -- 133 VGPRs, 3 waves per SIMD: 63 vs 57-63 us at cfg2, G = 16; two tiles
+  // (81 VGPRs): 54.9 vs 52.8 us at cfg2, 168 vs 174 us on the 3.2k child matrix of cfg5
   dim3 grid(kp, (m + 15) / 16, gt.ng);
   hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
 }
