@@ -275,6 +275,7 @@ class Context:
     # -- operator ---------------------------------------------------------
     def set_operator(self, calA, calE, J=None):
         """``calA``, ``calE`` NV x NV, ``J`` NP x NV (or None), any scipy format."""
+        self._zdev = None
         arp, aci, av, ash = as_csr(calA)
         erp, eci, ev, esh = as_csr(calE)
         nv = ash[0]
@@ -300,6 +301,7 @@ class Context:
 
     def set_dims(self, nv):
         """Dimension-only context: enough for compress() and gain(MT=...)."""
+        self._zdev = None
         _chk(self._lib.ricadi_set_dims(self._h, int(nv)))
         self.nv, self.np_, self.n = int(nv), 0, int(nv)
 
@@ -366,6 +368,7 @@ class Context:
         Z = np.empty((self.nv, cap)) if fetch else None
         cc = C.c_int(0)
         stats = np.zeros(8)
+        self._zdev = None
         _chk(self._lib.ricadi_lyap_adi(self._h, _d(sh), sh.size, _d(W), m, C.byref(prm),
                                        None if Z is None else _d(Z), C.byref(cc), _d(stats)))
         c = cc.value
@@ -388,6 +391,7 @@ class Context:
         Z = np.empty((self.nv, cap)) if fetch else None
         cc = C.c_int(0)
         stats = np.zeros(12)
+        self._zdev = None
         _chk(self._lib.ricadi_ric_newtonadi(
             self._h, _d(sh), sh.size, _d(B), nb, _d(W), mw,
             None if Z0 is None else _d(Z0), 0 if Z0 is None else Z0.shape[1],
@@ -396,6 +400,11 @@ class Context:
         c = cc.value
         if fetch:
             Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
+            # The factor also stays on the device.  The returned array is made read-only, so that a later
+            # gain(B, Z=<this very array>) may use the device copy instead of uploading it again
+            # (get_mTzzTtb right after the Newton iteration: optcont_main.py:488-506).
+            Z.flags.writeable = False
+            self._zdev = Z
         info = dict(nwtn_steps=int(stats[0]), upd_abs=stats[1], upd_rel=stats[2],
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
                     shift_solves=int(stats[5]), cols=c,
@@ -406,6 +415,7 @@ class Context:
 
     def compress(self, Z=None, thresh=None, k=None):
         """``Z=None`` compresses the factor left on the device."""
+        self._zdev = None
         if Z is not None:
             Z = as_panel(Z, self.nv)
             c = Z.shape[1]
@@ -426,6 +436,8 @@ class Context:
         """``MT (Z (Z^T B))`` with ``MT`` = calE of the context when None."""
         B = as_panel(B, self.nv)
         K = np.empty_like(B)
+        if Z is not None and Z is getattr(self, "_zdev", None) and not Z.flags.writeable:
+            Z = None          # the device-resident factor IS this array (read-only since it was returned)
         if Z is not None:
             Z = as_panel(Z, self.nv)
         c = 0 if Z is None else Z.shape[1]

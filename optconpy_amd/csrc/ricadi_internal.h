@@ -341,6 +341,12 @@ void launch_cholqr_small(hipStream_t st, int w, const double* G, const double* R
                          double* R, int* flag);
 void launch_select_evecs(hipStream_t st, int c, int k, const double* evec, double* sel);
 void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
+// batched block Gauss-Jordan inverse of the coarse matrices (ricadi_kernels.hip); nb <= RICADI_MAX_GROUPS matrices
+int gj_block();
+void launch_gj_prep(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, double* Cb, double* Rp,
+                    double* D);
+void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag);
+void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);
 

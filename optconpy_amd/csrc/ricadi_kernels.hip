@@ -2353,6 +2353,123 @@ void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst) {
   hipLaunchKernelGGL(to_f32_tiled_kernel, dim3(grid), dim3(256), 0, st, k, src, dst);
 }
 
+
+// ---------------------------------------------------------------------------
+// Batched in-place inverse of the dense coarse matrices by BLOCK Gauss-Jordan elimination without
+// pivoting (row-major k x k, one pointer per matrix).  Per diagonal block I (GJ_NB rows):
+//   gj_prep:    Cb = A[:, I] with the rows I zeroed;  Rp = A[I, :] with the block A[I, I] replaced by the
+//               identity;  D = A[I, I];  A[:, I] = 0
+//   gj_diag:    D <- D^-1 (one workgroup per matrix, Gauss-Jordan in LDS)
+//   two batched rocBLAS GEMMs (ricadi_solver.hip):  Rb = D^-1 Rp,   A -= Cb Rb
+//   gj_rows:    A[I, :] = Rb
+// after the last block A holds its inverse.  All of the 2 k^3 flops are in the rank-GJ_NB updates on the
+// matrix cores (rocSOLVER's getrf + getri spend a third of their time in one poorly parallel kernel).
+// ---------------------------------------------------------------------------
+constexpr int GJ_NB = 128;
+struct GjPtrs {
+  double* a[RICADI_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256) void gj_prep_kernel(GjPtrs A, int k, int k0, int nbe, double* __restrict__ Cb,
+                                                      double* __restrict__ Rp, double* __restrict__ D) {
+  double* __restrict__ a = A.a[blockIdx.z];
+  (void)Cb;
+  double* rp = Rp + (size_t)blockIdx.z * k * GJ_NB;
+  double* d = D + (size_t)blockIdx.z * GJ_NB * GJ_NB;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  // row panel (nbe x k) first: it reads the diagonal block before the column pass zeroes it
+  for (size_t e = tid; e < (size_t)nbe * k; e += nth) {
+    const int i = (int)(e / k), j = (int)(e - (size_t)i * k);
+    const double v = a[(size_t)(k0 + i) * k + j];
+    const bool inb = j >= k0 && j < k0 + nbe;
+    rp[(size_t)i * k + j] = inb ? (j - k0 == i ? 1.0 : 0.0) : v;
+    if (inb) d[(size_t)i * GJ_NB + (j - k0)] = v;
+  }
+}
+__global__ __launch_bounds__(256) void gj_cols_kernel(GjPtrs A, int k, int k0, int nbe, double* __restrict__ Cb) {
+  double* __restrict__ a = A.a[blockIdx.z];
+  double* cb = Cb + (size_t)blockIdx.z * k * GJ_NB;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = tid; e < (size_t)k * nbe; e += nth) {
+    const int i = (int)(e / nbe), j = (int)(e - (size_t)i * nbe);
+    const size_t at = (size_t)i * k + k0 + j;
+    const bool inrow = i >= k0 && i < k0 + nbe;
+    cb[(size_t)i * GJ_NB + j] = inrow ? 0.0 : a[at];
+    a[at] = 0.0;
+  }
+}
+// D (GJ_NB x GJ_NB, row-major, leading nbe x nbe block used) <- its inverse; flag set on a vanishing pivot
+__global__ __launch_bounds__(1024) void gj_diag_kernel(double* __restrict__ D, int nbe, int* __restrict__ flag) {
+  extern __shared__ double gjm[];          // GJ_NB x (GJ_NB + 1) matrix, then row and column buffers
+  constexpr int LD = GJ_NB + 1;
+  double* rowb = gjm + GJ_NB * LD;
+  double* colb = rowb + GJ_NB;
+  double* d = D + (size_t)blockIdx.x * GJ_NB * GJ_NB;
+  for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 1024) {
+    const int i = e / GJ_NB, j = e - i * GJ_NB;
+    gjm[i * LD + j] = (i < nbe && j < nbe) ? d[e] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 16;   // 128 rows x 8 column segments of 16
+  for (int p = 0; p < nbe; ++p) {
+    const double piv = gjm[p * LD + p];
+    if (!(fabs(piv) > 1e-300)) {           // uniform: every thread reads the same pivot
+      if (threadIdx.x == 0) atomicExch(flag, 1);
+      break;
+    }
+    const double inv = 1.0 / piv;
+    if (threadIdx.x < GJ_NB) {
+      rowb[threadIdx.x] = threadIdx.x == p ? inv : gjm[p * LD + threadIdx.x] * inv;
+      colb[threadIdx.x] = gjm[threadIdx.x * LD + p];
+    }
+    __syncthreads();
+    const double f = colb[i];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int j = j0 + t;
+      double v;
+      if (i == p) v = rowb[j];
+      else v = (j == p ? 0.0 : gjm[i * LD + j]) - f * rowb[j];
+      gjm[i * LD + j] = v;
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 1024) {
+    const int ii = e / GJ_NB, jj = e - ii * GJ_NB;
+    d[e] = gjm[ii * LD + jj];
+  }
+}
+__global__ __launch_bounds__(256) void gj_rows_kernel(GjPtrs A, int k, int k0, int nbe, const double* __restrict__ Rb) {
+  double* __restrict__ a = A.a[blockIdx.z];
+  const double* rb = Rb + (size_t)blockIdx.z * k * GJ_NB;
+  const size_t tid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = tid; e < (size_t)nbe * k; e += nth) a[(size_t)k0 * k + e] = rb[e];
+}
+int gj_block() { return GJ_NB; }
+void launch_gj_prep(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, double* Cb, double* Rp,
+                    double* D) {
+  GjPtrs P;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
+  const int grid = (int)std::min<size_t>(((size_t)nbe * k + 255) / 256, 1024);
+  hipLaunchKernelGGL(gj_prep_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Cb, Rp, D);
+  hipLaunchKernelGGL(gj_cols_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Cb);
+}
+void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag) {
+  const size_t lds = (size_t)(GJ_NB * (GJ_NB + 1) + 2 * GJ_NB) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gj_diag_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gj_diag_kernel, dim3(nb), dim3(1024), lds, st, D, nbe, flag);
+}
+void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb) {
+  GjPtrs P;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
+  const int grid = (int)std::min<size_t>(((size_t)nbe * k + 255) / 256, 1024);
+  hipLaunchKernelGGL(gj_rows_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Rb);
+}
+
 // dst (FP32, leading dimension ldd) = src (FP64, leading dimension lds_)
 __global__ void to_f32_kernel(int nrows, int ncols, const double* __restrict__ src, int lds_,
                               float* __restrict__ dst, int ldd) {

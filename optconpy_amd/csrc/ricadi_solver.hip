@@ -304,6 +304,8 @@ struct ricadi_ctx {
   DArr<double> partial, h1, h2, H, cs, sn, g, scale, resid, yv, bnorm2, nrm2;
   DArr<int> flag, ipiv, info;
   DArr<double*> eptrs;
+  DArr<double> gj_cb, gj_rp, gj_rb, gj_d;   // block Gauss-Jordan inverse of the coarse matrices
+  DArr<double*> gj_ptrs;
   double* h_resid = nullptr;  // pinned, 4 slots of MAX_GROUPS*MAX_M: norms, rhs norms, two residual slots
   hipEvent_t ev_res[2] = {nullptr, nullptr};
   // factor
@@ -415,6 +417,54 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
 template <class T>
 static void stable_alloc(DArr<T>& a, size_t n) {
   if (a.n != n) a.alloc(n);
+}
+
+// In-place inverses of nb (<= RICADI_MAX_GROUPS) dense k x k matrices (row-major, device pointers in hmats) by
+// block Gauss-Jordan elimination without pivoting: per 128-row block three small kernels and two batched
+// rocBLAS GEMMs (ricadi_kernels.hip).  Returns false if a diagonal block had a vanishing pivot (the matrices
+// are garbage then; the caller assembles them again and takes the pivoted rocSOLVER route).
+static bool gj_invert_batched(ricadi_ctx* c, double* const* hmats, int nb, int k) {
+  hipStream_t st = c->st;
+  const int NB = gj_block();
+  const size_t pan = (size_t)k * NB;
+  c->gj_cb.ensure(pan * nb);
+  c->gj_rp.ensure(pan * nb);
+  c->gj_rb.ensure(pan * nb);
+  c->gj_d.ensure((size_t)NB * NB * nb);
+  std::vector<double*> hp((size_t)5 * nb);
+  for (int i = 0; i < nb; ++i) {
+    hp[i] = hmats[i];
+    hp[nb + i] = c->gj_cb.p + pan * i;
+    hp[2 * nb + i] = c->gj_rp.p + pan * i;
+    hp[3 * nb + i] = c->gj_rb.p + pan * i;
+    hp[4 * nb + i] = c->gj_d.p + (size_t)NB * NB * i;
+  }
+  c->gj_ptrs.ensure((size_t)5 * nb);
+  HIPCHK(hipMemcpyAsync(c->gj_ptrs.p, hp.data(), sizeof(double*) * hp.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(c->flag.p + 2, 0, sizeof(int), st));
+  HIPCHK(hipStreamSynchronize(st));   // hp is a stack object
+  double* const* dA = c->gj_ptrs.p;
+  double* const* dCb = dA + nb;
+  double* const* dRp = dA + 2 * nb;
+  double* const* dRb = dA + 3 * nb;
+  double* const* dD = dA + 4 * nb;
+  const double one = 1.0, zero = 0.0, mone = -1.0;
+  for (int k0 = 0; k0 < k; k0 += NB) {
+    const int nbe = std::min(NB, k - k0);
+    launch_gj_prep(st, nb, hmats, k, k0, nbe, c->gj_cb.p, c->gj_rp.p, c->gj_d.p);
+    launch_gj_diag(st, nb, c->gj_d.p, nbe, c->flag.p + 2);
+    // row-major Rb = D^-1 Rp  ==  column-major Rb^T = Rp^T (D^-1)^T
+    RBCHK(rocblas_dgemm_batched(c->rb, rocblas_operation_none, rocblas_operation_none, k, nbe, nbe, &one,
+                                (const double* const*)dRp, k, (const double* const*)dD, NB, &zero, dRb, k, nb));
+    // row-major A -= Cb Rb  ==  column-major A^T -= Rb^T Cb^T
+    RBCHK(rocblas_dgemm_batched(c->rb, rocblas_operation_none, rocblas_operation_none, k, k, nbe, &mone,
+                                (const double* const*)dRb, k, (const double* const*)dCb, NB, &one, dA, k, nb));
+    launch_gj_rows(st, nb, hmats, k, k0, nbe, c->gj_rb.p);
+  }
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->flag.p + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return flag == 0;
 }
 
 // Per-shift data for the given (alpha, beta) pairs; whatever is missing is built for
@@ -529,8 +579,19 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     // factorisation.  A zero pivot (info != 0) sends all matrices of the call through
     // the pivoted routines.
     static const bool npvt = getenv("RICADI_COARSE_PIVOT") == nullptr;
-    bool done = false;
-    if (npvt) {
+    // default: block Gauss-Jordan on batched GEMMs (RICADI_COARSE_GJ=0: rocSOLVER getrf + getri)
+    static const bool gj = !(getenv("RICADI_COARSE_GJ") && atoi(getenv("RICADI_COARSE_GJ")) == 0);
+    bool done = false, done_gj = false;
+    if (gj && npvt) {
+      done = true;
+      for (int i0 = 0; i0 < nb && done; i0 += RICADI_MAX_GROUPS)
+        done = gj_invert_batched(c, hp.data() + i0, std::min(RICADI_MAX_GROUPS, nb - i0), k);
+      done_gj = done;
+      if (!done)
+        for (ShiftData* sd : todo)   // a vanishing pivot: assemble again for the rocSOLVER routes
+          launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, sd->alpha, sd->beta, sd->einv.p);
+    }
+    if (!done && npvt) {
       RBCHK(rocsolver_dgetrf_npvt_batched(c->rb, k, k, c->eptrs.p, k, c->info.p, nb));
       HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -547,7 +608,8 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       RBCHK(rocsolver_dgetrf_batched(c->rb, k, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
       RBCHK(rocsolver_dgetri_batched(c->rb, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
     }
-    HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    if (!(gj && npvt && done_gj))
+      HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
   }
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -278,6 +278,31 @@ def test_get_mtzzttb_sparse_and_dense(cfg1):
     backend.reset()
 
 
+def test_gain_from_the_device_resident_factor(cfg1):
+    """get_mTzzTtb right after the Newton iteration (optcont_main.py:488-506) uses the factor the iteration
+    left on the device when it is handed the very array the iteration returned (made read-only for that);
+    a copy of it goes through the upload path -- same K."""
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    out = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
+    Z = out["zfac"]
+    assert not Z.flags.writeable
+    ctx = backend.context()
+    assert ctx._zdev is Z
+    K_dev = pru.get_mTzzTtb(pr.M.T, Z, tb)
+    K_up = pru.get_mTzzTtb(pr.M.T, Z.copy(), tb)
+    assert rel(K_dev, K_up) < 1e-13
+    assert rel(K_dev, opru.get_mTzzTtb(pr.M.T, Z, tb)) < 1e-12
+    # any call that changes the device factor drops the shortcut
+    pru.compress_Zsvd(Z, thresh=1e-9)
+    assert ctx._zdev is None
+    assert rel(pru.get_mTzzTtb(pr.M.T, Z, tb), K_up) < 1e-13
+    backend.reset()
+
+
 def test_lau_mirror(cfg1, golden):
     import sadptprj_riclyap_adi.lin_alg_utils as lau
     backend.reset()
