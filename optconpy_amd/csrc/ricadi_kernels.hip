@@ -2409,7 +2409,9 @@ __global__ __launch_bounds__(1024) void gj_diag_kernel(double* __restrict__ D, i
     gjm[i * LD + j] = (i < nbe && j < nbe) ? d[e] : (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 16;   // 128 rows x 8 column segments of 16
+  // 128 rows x 8 column segments of 16; consecutive lanes = consecutive rows (row stride 129 doubles: the 32
+  // lanes of an LDS access group fall on distinct banks)
+  const int i = threadIdx.x & 127, j0 = (threadIdx.x >> 7) * 16;
   for (int p = 0; p < nbe; ++p) {
     const double piv = gjm[p * LD + p];
     if (!(fabs(piv) > 1e-300)) {           // uniform: every thread reads the same pivot
