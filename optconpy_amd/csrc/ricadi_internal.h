@@ -128,6 +128,7 @@ struct ProlongArgs {
   size_t gs2 = 0;
   float* out32 = nullptr;   // if set: FP32 copy of what the sweep writes (flexible GMRES keeps Z_j = P^-1 v_j)
   size_t gs32 = 0;
+  int only32 = 0;           // with out32: the FP64 result is not stored (the operator reads the FP32 copy)
 };
 
 // Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for
@@ -187,6 +188,13 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 // all active groups; lidx carries the velocity-velocity flag in bit 15; alphas / betas:
 // RICADI_MAX_GROUPS coefficients indexed by group id
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows);
+void launch_spmm_blocked_x32(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2, const int* rp2,
+                             const int* cols2, const uint16_t* lidx, const GroupPtrs& vals, const float* x, int ldx,
+                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols);
+void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
+                                int nblk, const int* rows2, const int* rp2, const int* cols2, const uint16_t* lidx,
+                                const double* vAJ, const double* vE, const float* x, int ldx, size_t gsx, double* y,
+                                int ldy, size_t gsy, double alpha, int m, int max_cols);
 void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
                             int nblk, const int* rows2, const int* rp2, const int* cols2,
                             const uint16_t* lidx, const double* vAJ, const double* vE,

@@ -289,11 +289,11 @@ void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
 // loads, and this removes one full round trip (block pointers -> row/column lists).
 // HAS_R / HAS_LR: compile the residual term / the low-rank epilogue in (the plain
 // operator launch of the GMRES iteration has neither).
-template <bool HAS_R, bool HAS_LR>
+template <bool HAS_R, bool HAS_LR, class XT = double>
 __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
-    const double* __restrict__ x, int ldx, size_t gsx,
+    const XT* __restrict__ x, int ldx, size_t gsx,
     double* __restrict__ y, int ldy, size_t gsy, const double* __restrict__ r, int ldr,
     size_t gsr, double alpha, double beta_r, int m, int max_cols, LowRankArgs lr) {
   extern __shared__ double xs[];                             // max_cols x m
@@ -344,18 +344,18 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   for (int cc = g; cc < m; cc += 16) {
     for (int jb = 0; jb < max_cols; jb += 16 * XJ) {
       int cidx[XJ];
-      double xv[XJ];
+      XT xv[XJ];             // raw loads; an FP32 x is converted at the LDS store, not between the loads
 #pragma unroll
       for (int t = 0; t < XJ; ++t) {
         const int j = jb + gq + 16 * t;
         cidx[t] = (j < max_cols) ? bcols[j] : -1;
       }
 #pragma unroll
-      for (int t = 0; t < XJ; ++t) xv[t] = (cidx[t] >= 0) ? x[(size_t)cidx[t] * ldx + cc] : 0.0;
+      for (int t = 0; t < XJ; ++t) xv[t] = (cidx[t] >= 0) ? x[(size_t)cidx[t] * ldx + cc] : (XT)0;
 #pragma unroll
       for (int t = 0; t < XJ; ++t) {
         const int j = jb + gq + 16 * t;
-        if (cidx[t] >= 0) xs[j * m + cc] = xv[t];
+        if (cidx[t] >= 0) xs[j * m + cc] = (double)xv[t];
       }
     }
   }
@@ -459,6 +459,19 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 #undef RICADI_TILE_LAUNCH
 }
 
+// plain operator product with an FP32-stored x (the flexible GMRES applies S to the stored Z_j): the x tile
+// is converted while it is staged, the inner loop is the same
+void launch_spmm_blocked_x32(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2, const int* rp2,
+                             const int* cols2, const uint16_t* lidx, const GroupPtrs& vals, const float* x, int ldx,
+                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols) {
+  if (nblk <= 0 || gt.ng <= 0) return;
+  const dim3 grid(nblk, 1, gt.ng), block(256);
+  const size_t lds = spmm_blocked_lds_bytes(m, max_cols, 0);
+  hipLaunchKernelGGL((spmm_blocked_kernel<false, false, float>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
+                     vals, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0, (size_t)0, alpha, 0.0, m, max_cols,
+                     LowRankArgs());
+}
+
 // ---------------------------------------------------------------------------
 // K1, multi-shift form of the LDS-tiled kernel (the "batched shifted" kernel of SURVEY.md
 // App. C.4 / section 8d): the shifted matrices of a sweep differ by two scalars only,
@@ -483,12 +496,12 @@ struct GroupCoefs {
 //     value = alpha_g * vE + (entry in the velocity-velocity block ? beta_g : 1) * vAJ,
 // the block membership riding in bit 15 of the 16-bit local column index (tiles have at
 // most 160 columns).
-template <bool HAS_R>
+template <bool HAS_R, class XT = double>
 __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
     const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupCoefs cf,
     const double* __restrict__ vAJ, const double* __restrict__ vE,
-    const double* __restrict__ x, int ldx, size_t gsx, double* __restrict__ y, int ldy, size_t gsy,
+    const XT* __restrict__ x, int ldx, size_t gsx, double* __restrict__ y, int ldy, size_t gsy,
     const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r, int m,
     int max_cols) {
   extern __shared__ double xs[];                             // 2 tiles of max_cols x 16
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
     for (int t = 0; t < XJ; ++t) {
       const int j = pp * 16 * XJ + gq + 16 * t;
       const int ci = (j < max_cols) ? bcols[j] : -1;
-      xoff[pp][t] = ci >= 0 ? (ci * ldx + gc) * 8 : -1;
+      xoff[pp][t] = ci >= 0 ? (ci * ldx + gc) * (int)sizeof(XT) : -1;
     }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr)
@@ -533,14 +546,14 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
   const int ystep = gridDim.y;
   int gi = blockIdx.y;
   if (gi >= gt.ng) return;
-  double xv[XP][XJ];
+  XT xv[XP][XJ];             // raw loads (converted when they go to the LDS tile)
   auto fetch = [&](int grp) {
     const char* __restrict__ xg = reinterpret_cast<const char*>(x + (size_t)grp * gsx);
 #pragma unroll
     for (int pp = 0; pp < XP; ++pp)
 #pragma unroll
       for (int t = 0; t < XJ; ++t)
-        xv[pp][t] = (xoff[pp][t] >= 0) ? *reinterpret_cast<const double*>(xg + (unsigned)xoff[pp][t]) : 0.0;
+        xv[pp][t] = (xoff[pp][t] >= 0) ? *reinterpret_cast<const XT*>(xg + (unsigned)xoff[pp][t]) : (XT)0;
   };
   auto stash = [&](int buf) {
     double* __restrict__ tile = xs + (size_t)buf * max_cols * 16;
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
 #pragma unroll
       for (int t = 0; t < XJ; ++t) {
         const int j = pp * 16 * XJ + gq + 16 * t;
-        if (j < max_cols) tile[j * 16 + g] = xv[pp][t];
+        if (j < max_cols) tile[j * 16 + g] = (double)xv[pp][t];
       }
   };
   fetch(gt.gid[gi]);
@@ -641,6 +654,24 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
 #undef RICADI_MS_STEP
 }
 size_t spmm_blocked_ms_lds_bytes(int max_cols) { return (size_t)2 * max_cols * 16 * sizeof(double) + 16; }
+void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
+                                int nblk, const int* rows2, const int* rp2, const int* cols2, const uint16_t* lidx,
+                                const double* vAJ, const double* vE, const float* x, int ldx, size_t gsx, double* y,
+                                int ldy, size_t gsy, double alpha, int m, int max_cols) {
+  if (nblk <= 0 || gt.ng <= 0) return;
+  GroupCoefs cf;
+  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) {
+    cf.alpha[i] = alphas[i];
+    cf.beta[i] = betas[i];
+  }
+  int ysplit = 1;
+  while (ysplit < gt.ng && (long)nblk * ysplit < 900 && ysplit < 8) ysplit *= 2;
+  ysplit = std::min(ysplit, gt.ng);
+  const dim3 grid(nblk, ysplit, 1), block(256);
+  hipLaunchKernelGGL((spmm_blocked_ms_kernel<false, float>), grid, block, spmm_blocked_ms_lds_bytes(max_cols), st,
+                     rows2, rp2, cols2, lidx, gt, cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0,
+                     (size_t)0, alpha, 0.0, m, max_cols);
+}
 // max_cols <= 160 (tile slots per thread: 16 x XP x XJ), m <= 16, panel offsets in 31 bits
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows) {
   return m <= 16 && max_cols <= 160 && panel_rows * (size_t)m * 8 < ((size_t)1 << 31);
@@ -1625,7 +1656,7 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
           // optional second copy WITHOUT the coarse part (group stride pa.gs2)
           if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
-          *o = v;
+          if (!(pa.out32 && pa.only32)) *o = v;
           if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
         }
       }
@@ -1744,7 +1775,7 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
           double* o = &out[(size_t)row * ldo + col];
           double v = subtract ? *o - acc[t][e] : acc[t][e];
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
-          *o = v;
+          if (!(pa.out32 && pa.only32)) *o = v;
           if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
         }
       }

@@ -741,15 +741,31 @@ static bool ms_pays(const ricadi_ctx* c, int ng, size_t nnz) {
 // y = beta_r * r + alpha * S x on the saddle operator (optionally through the
 // prolongation map): LDS-tiled kernel when the block tiles fit, else the CSR one.
 // gsx / gsy / gsr: group strides of x, y, r.
+// The LDS-tiled kernels serve panels of width m (else the CSR kernel runs)
+static bool saddle_tiled(const ricadi_ctx* c, int m) {
+  static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
+  return c->sb_ok && !force_csr &&
+         spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
+}
+// x32 (optional): FP32 copy of x with the same leading dimension and group stride; the tiled kernels read it
+// instead of x (plain products only: no residual term, no low-rank epilogue, no prolongation map)
 static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx,
                         const int* xmap, double* y, size_t gsy, const double* r, size_t gsr,
-                        double alpha, double beta_r, const LowRankArgs& lr = LowRankArgs()) {
-  static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
+                        double alpha, double beta_r, const LowRankArgs& lr = LowRankArgs(),
+                        const float* x32 = nullptr) {
   const int m = bt.m;
-  const bool fits =
-      c->sb_ok && !force_csr &&
-      spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
+  const bool fits = saddle_tiled(c, m);
   const bool has_lr = lr.q > 0 && lr.nrows > 0;
+  if (x32 && fits && !r && !xmap && !has_lr) {
+    if (ms_pays(c, bt.tab.ng, c->snnz) && spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n))
+      launch_spmm_blocked_ms_x32(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
+                                 c->sb_cols2.p, c->sb_lidx_ms.p, c->sbAJ.p, c->sbE.p, x32, m, gsx, y, m, gsy, alpha,
+                                 m, c->sb_max_cols);
+    else
+      launch_spmm_blocked_x32(c->st, bt.tab, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p, c->sb_cols2.p, c->sb_lidx.p,
+                              bt.svalb, x32, m, gsx, y, m, gsy, alpha, m, c->sb_max_cols);
+    return;
+  }
   if (fits && ms_pays(c, bt.tab.ng, c->snnz) && !xmap && !has_lr &&
       spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n))
     launch_spmm_blocked_ms(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
@@ -764,10 +780,17 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
                   m, gsr, alpha, beta_r, m, lr);
 }
 
+// Does the GMRES iteration apply the operator to the FP32-stored Z_j (RICADI_X32=0: to the FP64 z)?
+static bool operator_reads_x32(const ricadi_ctx* c, int m) {
+  static const bool x32_on = !(getenv("RICADI_X32") && atoi(getenv("RICADI_X32")) == 0);
+  const bool flex = !(getenv("RICADI_FGMRES") && atoi(getenv("RICADI_FGMRES")) == 0);
+  return flex && x32_on && saddle_tiled(c, m);
+}
+
 // y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
 // bt.gs); optional low-rank  - U V^T x_v  (U, V shared by the groups)
 static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx, double* y,
-                     bool lowrank) {
+                     bool lowrank, const float* x32 = nullptr) {
   hipStream_t st = c->st;
   const int m = bt.m;
   LowRankArgs lr;
@@ -781,15 +804,16 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
     lr.q = c->q;
     lr.nrows = c->nv;
   }
-  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0, lr);
+  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0, lr, x32);
 }
 
 // z = P^-1 r for every active group: multiplicative two-level, coarse correction
 // first, then one consistent SIMPLE block-Jacobi sweep on the updated residual.
 // r has group stride gsr; z lives in a workspace buffer (stride bt.gs).
 // z32 (optional, group stride gs32): FP32 copy of z, written by the sweeps that write z last.
+// only32: z itself need not be stored where the sweeps write the copy (the operator will read z32).
 static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z,
-                          float* z32 = nullptr, size_t gs32 = 0) {
+                          float* z32 = nullptr, size_t gs32 = 0, bool only32 = false) {
   hipStream_t st = c->st;
   bool mirrored = false;
   const int nv = c->nv, np = c->np, m = bt.m;
@@ -891,6 +915,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
                   rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
     static const bool fuse_jt = getenv("RICADI_NOFUSE_JT") == nullptr;
+    static const bool rect = getenv("RICADI_NO_RECT") == nullptr;
     // Fused variant: the pressure sweep writes z_p already WITH its coarse part and keeps
     // the plain z_p (the operand of the J^T product below) in tp -- in place: a wave
     // reads its block's rows of tp before it writes them, blocks are disjoint.
@@ -901,6 +926,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       if (z32) {
         ppro.out32 = z32 + (size_t)nv * m;
         ppro.gs32 = gs32;
+        ppro.only32 = only32 && rect && c->gt_ok;   // the rectangle sweep below completes the FP32 copy
       }
       if (c->kc > 0) {
         ppro.aggof = c->aggof.p + nv;
@@ -917,12 +943,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks; the
     // J^T product is formed inside the sweep, row by row as the blocks gather them
     // (z_p is small and L2 resident), instead of through an intermediate panel
-    static const bool rect = getenv("RICADI_NO_RECT") == nullptr;
     if (fuse_jt && rect && c->gt_ok) {
       // z_v -= G z_p with the per-shift blocks G_b = Ahat_b^-1 J^T[rows_b, pcols_b] formed at setup
       pro.nextra = 0;            // the pressure rows already carry their coarse part
       pro.out32 = z32;
       pro.gs32 = gs32;
+      pro.only32 = only32;
       mirrored = true;
       if (c->precond32)
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
@@ -998,6 +1024,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   const bool b16 = c->basis16;
   const bool b32 = c->basis32 && !b16;
   const bool flex = c->flex;
+  // (only where the launches are bandwidth bound -- the multi-shift SpMM regime: cfg5 K1 1252 -> 1150 us per
+  // launch, cycle +2 %; at cfg2 the FP32 gathers are no faster and the step was 1.4 % slower)
+  const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
@@ -1097,8 +1126,11 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       const double* vj = (b32 || b16) ? c->vcur.p : V + (size_t)j * vs;
       // flexible form: Z_j = P^-1 v_j is kept (FP32), the cycle's correction is x += Z y -- no
       // preconditioner application at the cycle end, and P may differ from step to step
-      precond_apply(c, bt, vj, nm, c->zv.p, flex ? c->zbasisf.p + (size_t)j * vs : nullptr, nm);
-      op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank);
+      // ... and the operator reads that stored FP32 copy (half the bytes of the x gathers; S Z_j = V H then
+      // holds for exactly the vectors the correction uses), so the sweeps need not store the FP64 z at all
+      float* zj = flex ? c->zbasisf.p + (size_t)j * vs : nullptr;
+      precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32);
+      op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr);
       if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
                            c->h1.p, gsh);
@@ -2776,10 +2808,18 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* c, int ng, const double* alphas, cons
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  // the saddle SpMM exactly as the batched GMRES launches it (no low-rank term)
-  saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
+  // the saddle SpMM exactly as the batched GMRES launches it (no low-rank term; on the FP32-stored vector
+  // when the iteration does so)
+  DArr<float> x32;
+  if (operator_reads_x32(c, m) && ms_pays(c, ng, c->snnz)) {
+    x32.alloc(bt.gs * ng);
+    for (int g = 0; g < ng; ++g)
+      launch_to_f32(c->st, c->n, m, dX + (size_t)g * bt.gs, m, x32.p + (size_t)g * bt.gs, m);
+  }
+  saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p);
   HIPCHK(hipEventRecord(e0, c->st));
-  for (int i = 0; i < reps; ++i) saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0);
+  for (int i = 0; i < reps; ++i)
+    saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p);
   HIPCHK(hipEventRecord(e1, c->st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -2814,6 +2854,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
   // finite fill: byte 0x3C -> 1.5e-18 (FP64), 1.06 (FP16), 0.0115 (FP32)
   HIPCHK(hipMemsetAsync(c->wv.p, 0x3C, sizeof(double) * vs, st));
   HIPCHK(hipMemsetAsync(c->zv.p, 0x3C, sizeof(double) * vs, st));
+  if (c->zbasisf.p) HIPCHK(hipMemsetAsync(c->zbasisf.p, 0x3C, sizeof(float) * vs, st));
   HIPCHK(hipMemsetAsync(c->r2.p, 0x3C, sizeof(double) * vs, st));
   HIPCHK(hipMemsetAsync(c->h1.p, 0x3C, sizeof(double) * gsh * ng, st));
   HIPCHK(hipMemsetAsync(c->h2.p, 0x3C, sizeof(double) * gsh * ng, st));
@@ -2839,7 +2880,8 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
   auto launch = [&]() {
     switch (which) {
       case 0:
-        saddle_spmm(c, bt, c->zv.p, nm, nullptr, c->wv.p, nm, nullptr, 0, 1.0, 0.0);
+        saddle_spmm(c, bt, c->zv.p, nm, nullptr, c->wv.p, nm, nullptr, 0, 1.0, 0.0, LowRankArgs(),
+                    operator_reads_x32(c, m) && ms_pays(c, ng, c->snnz) && c->zbasisf.p ? c->zbasisf.p : nullptr);
         break;
       case 1:
         if (c->precond32)
