@@ -168,11 +168,15 @@ struct Seg2 {
   int kstride = 0;
   const double* in = nullptr;
   size_t gs = 0;
+  const _Float16* in16 = nullptr;   // segment 1 only: read the input rows from an FP16 panel instead of `in`
 };
 
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
 // The *_b launchers are the batched forms (GroupTab + group strides `gs*`, in
 // doubles); the plain ones run a single panel.
+void launch_spmm_h(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                   const GroupPtrs& vals, const double* x, const _Float16* x16, int ldx, size_t gsx, double* y, int ldy,
+                   size_t gsy, const _Float16* r16, int ldr, size_t gsr, double alpha, double beta_r, int m, int chunk);
 void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
                    const GroupPtrs& vals, const double* x, int ldx, size_t gsx, const int* xmap,
                    double* y, int ldy, size_t gsy, const double* r, int ldr, size_t gsr,

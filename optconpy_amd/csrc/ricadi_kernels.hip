@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void spmm_kernel(
 // x rows of a band matrix inside that XCD's L2.
 // CHK = entries per chunk (16, or 8 for matrices with short rows such as S*Y: half the
 // broadcast steps are saved when a row has <= 8 entries).
-template <int CPL, int CHK>
+template <int CPL, int CHK, class XT = double, class RT = double>
 __global__ __launch_bounds__(256) void spmm_kernel_v2(
     GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci,
-    GroupPtrs vals, const double* __restrict__ x, int ldx, size_t gsx,
+    GroupPtrs vals, const XT* __restrict__ x, int ldx, size_t gsx,
     const int* __restrict__ xmap, double* __restrict__ y, int ldy, size_t gsy,
-    const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
+    const RT* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r,
     const double* __restrict__ rowscale, int m, LowRankArgs lr) {
   const int grp = gt.gid[blockIdx.z];
   const double* __restrict__ val = vals.p[grp];
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
   {                                                                   \
     const int c0 = bc16i<T>(myc);                                     \
     const double v0 = bc16d<T>(myv);                                  \
-    const double* x0 = x + (size_t)c0 * ldx;                          \
+    const XT* x0 = x + (size_t)c0 * ldx;                              \
     _Pragma("unroll") for (int c = 0; c < CPL; ++c)                   \
-        acc[c] = fma(v0, x0[colx[c]], acc[c]);                        \
+        acc[c] = fma(v0, (double)x0[colx[c]], acc[c]);                \
   }
     if (CHK == 16) {
       RICADI_FOR16(RICADI_V2_STEP)
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
     const int col = g + 16 * c;
     if (col < m) {
       double out = sc * acc[c];
-      if (r) out += beta_r * r[(size_t)row * ldr + col];
+      if (r) out += beta_r * (double)r[(size_t)row * ldr + col];
       if (row < lr.nrows) out -= lowrank_term(lr, lrc, row, col, m);
       y[(size_t)row * ldy + col] = out;
     }
@@ -262,6 +262,29 @@ void launch_spmm_b(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
                    double alpha, double beta_r, int m, const LowRankArgs& lr, int chunk) {
   spmm_dispatch(st, gt, nrows, rp, ci, vals, x, ldx, gsx, xmap, y, ldy, gsy, r, ldr, gsr, alpha,
                 beta_r, nullptr, m, lr, chunk);
+}
+
+// Forms with an operand taken from the FP16-stored Krylov vector (panels of <= 16 columns): x16 replaces x
+// (restriction of the current vector), r16 replaces r (its pressure rows as the additive term)
+void launch_spmm_h(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                   const GroupPtrs& vals, const double* x, const _Float16* x16, int ldx, size_t gsx, double* y, int ldy,
+                   size_t gsy, const _Float16* r16, int ldr, size_t gsr, double alpha, double beta_r, int m, int chunk) {
+  if (nrows <= 0 || m <= 0 || m > 16 || gt.ng <= 0) return;
+  dim3 grid((nrows + 15) / 16, 1, gt.ng), block(256);
+  const int* nomap = nullptr;
+  const double* norow = nullptr;
+  if (x16 && chunk == 8)
+    hipLaunchKernelGGL((spmm_kernel_v2<1, 8, _Float16, _Float16>), grid, block, 0, st, gt, nrows, rp, ci, vals, x16,
+                       ldx, gsx, nomap, y, ldy, gsy, r16, ldr, gsr, alpha, beta_r, norow, m, LowRankArgs());
+  else if (x16)
+    hipLaunchKernelGGL((spmm_kernel_v2<1, 16, _Float16, _Float16>), grid, block, 0, st, gt, nrows, rp, ci, vals, x16,
+                       ldx, gsx, nomap, y, ldy, gsy, r16, ldr, gsr, alpha, beta_r, norow, m, LowRankArgs());
+  else if (chunk == 8)
+    hipLaunchKernelGGL((spmm_kernel_v2<1, 8, double, _Float16>), grid, block, 0, st, gt, nrows, rp, ci, vals, x, ldx,
+                       gsx, nomap, y, ldy, gsy, r16, ldr, gsr, alpha, beta_r, norow, m, LowRankArgs());
+  else
+    hipLaunchKernelGGL((spmm_kernel_v2<1, 16, double, _Float16>), grid, block, 0, st, gt, nrows, rp, ci, vals, x, ldx,
+                       gsx, nomap, y, ldy, gsy, r16, ldr, gsr, alpha, beta_r, norow, m, LowRankArgs());
 }
 
 // ---------------------------------------------------------------------------
@@ -1061,7 +1084,7 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
   h += (size_t)grp * gsh;
   if (w) w += (size_t)grp * gsw;
   if (scale) scale += (size_t)grp * 16;
-  out += (size_t)grp * gso;
+  if (out) out += (size_t)grp * gso;
   if (outf) outf += (size_t)grp * gsf;
   for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
   __syncthreads();
@@ -1112,9 +1135,11 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
       }
       *reinterpret_cast<half8_t*>(outf + e) = f;
     }
-    double2* op = reinterpret_cast<double2*>(out + e);
+    if (out) {
+      double2* op = reinterpret_cast<double2*>(out + e);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) op[t] = make_double2(a[2 * t], a[2 * t + 1]);
+      for (int t = 0; t < 4; ++t) op[t] = make_double2(a[2 * t], a[2 * t + 1]);
+    }
   }
 }
 // RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update)
@@ -1294,7 +1319,7 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
   h += (size_t)grp * gsh;
   if (w) w += (size_t)grp * gsw;
   if (scale) scale += (size_t)grp * m;
-  out += (size_t)grp * gso;
+  if (out) out += (size_t)grp * gso;
   if (outf) outf += (size_t)grp * gsf;
   for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nelem;
        e += (size_t)gridDim.x * blockDim.x) {
@@ -1313,7 +1338,7 @@ __global__ __launch_bounds__(256) void cols_update_kernel(
       outf[e] = f;
       v = (double)f;
     }
-    out[e] = v;
+    if (out) out[e] = v;
   }
 }
 template <class BT>
@@ -1861,7 +1886,8 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
   constexpr int NT = BS / 16, N1 = BS / 16, N2 = K2 / 16;
   const T* __restrict__ M1 = m1s.p[grp] + (size_t)wave * BS * BS;
   const T* __restrict__ M2 = m2s.p[grp] + (size_t)wave * BS * K2;
-  const double* __restrict__ in1 = s1.in + (size_t)grp * s1.gs;
+  const double* __restrict__ in1 = s1.in ? s1.in + (size_t)grp * s1.gs : nullptr;
+  const _Float16* __restrict__ in1h = s1.in16 ? s1.in16 + (size_t)grp * s1.gs : nullptr;
   const double* __restrict__ in2 = s2.in + (size_t)grp * s2.gs;
   // input row ids of this lane: 4 per 16-wide chunk
   int r1[N1][4], r2[N2][4];
@@ -1887,7 +1913,9 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
     for (int kc = 0; kc < N1; ++kc)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
-        x1[kc][s4] = (r1[kc][s4] >= 0 && cok) ? in1[(size_t)r1[kc][s4] * m + col] : 0.0;
+        x1[kc][s4] = (r1[kc][s4] >= 0 && cok)
+                         ? (in1h ? (double)in1h[(size_t)r1[kc][s4] * m + col] : in1[(size_t)r1[kc][s4] * m + col])
+                         : 0.0;
 #pragma unroll
     for (int kc = 0; kc < N2; ++kc)
 #pragma unroll

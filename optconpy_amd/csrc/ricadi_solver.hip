@@ -812,8 +812,15 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
 // r has group stride gsr; z lives in a workspace buffer (stride bt.gs).
 // z32 (optional, group stride gs32): FP32 copy of z, written by the sweeps that write z last.
 // only32: z itself need not be stored where the sweeps write the copy (the operator will read z32).
+// r16: the same residual panel as stored in FP16 (the current Krylov vector; group stride gsr); where the folded
+// path runs, its three readers of r take the 2-byte copy (exactly the same values) and r itself is not touched.
+static bool precond_folds(const ricadi_ctx* c) {
+  static const bool fold = getenv("RICADI_NO_FOLD") == nullptr;
+  return fold && c->kc > 0 && c->ady_ok && c->np > 0;
+}
 static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z,
-                          float* z32 = nullptr, size_t gs32 = 0, bool only32 = false) {
+                          float* z32 = nullptr, size_t gs32 = 0, bool only32 = false,
+                          const _Float16* r16 = nullptr) {
   hipStream_t st = c->st;
   bool mirrored = false;
   const int nv = c->nv, np = c->np, m = bt.m;
@@ -824,8 +831,14 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   bool folded = false;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
-    launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
-                  bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
+    folded = precond_folds(c);
+    if (!folded || m > 16) r16 = nullptr;
+    if (r16)
+      launch_spmm_h(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, nullptr, r16, m, gsr, c->rc.p, m, bt.gsc,
+                    nullptr, 0, 0, 1.0, 0.0, m, 16);
+    else
+      launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
+                    bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
     if (c->child) {
       // coarse problem by one cycle of the child level's preconditioner (a fixed linear operator)
       Batch cb = *bt.sub;
@@ -835,14 +848,16 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
-    static const bool fold = getenv("RICADI_NO_FOLD") == nullptr;
-    folded = fold && c->ady_ok && np > 0;
     if (folded) {
       // only the PRESSURE rows of r - (S Y) ec are formed (short CSR product over np rows); the
       // velocity rows ride inside the first velocity sweep (block_apply2_kernel, below)
-      launch_spmm_b(st, gt, np, c->sy_rp.p + nv, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
-                    c->r2.p + (size_t)nv * m, m, bt.gs, r + (size_t)nv * m, m, gsr, -1.0, 1.0, m, LowRankArgs(),
-                    c->sy_chunk);
+      if (r16)
+        launch_spmm_h(st, gt, np, c->sy_rp.p + nv, c->sy_ci.p, bt.syval, c->ec.p, nullptr, m, bt.gsc,
+                      c->r2.p + (size_t)nv * m, m, bt.gs, r16 + (size_t)nv * m, m, gsr, -1.0, 1.0, m, c->sy_chunk);
+      else
+        launch_spmm_b(st, gt, np, c->sy_rp.p + nv, c->sy_ci.p, bt.syval, c->ec.p, m, bt.gsc, nullptr,
+                      c->r2.p + (size_t)nv * m, m, bt.gs, r + (size_t)nv * m, m, gsr, -1.0, 1.0, m, LowRankArgs(),
+                      c->sy_chunk);
     } else {
       // Residual after the coarse correction, r2 = r - (S Y) ec, with the prolongated
       // operator (short rows over the L2-resident coarse vector) -- not a full saddle SpMM
@@ -893,7 +908,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // ever writing it
     Seg2 s1, s2;
     s1.kstride = c->bs;
-    s1.in = r;
+    s1.in = r16 ? nullptr : r;
+    s1.in16 = r16;
     s1.gs = gsr;
     s2.iptr = c->cy_ptr.p;
     s2.irows = c->cy_cols.p;
@@ -1026,6 +1042,9 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   const bool flex = c->flex;
   // (only where the launches are bandwidth bound -- the multi-shift SpMM regime: cfg5 K1 1252 -> 1150 us per
   // launch, cycle +2 %; at cfg2 the FP32 gathers are no faster and the step was 1.4 % slower)
+  // the preconditioner reads the current vector from the FP16 basis itself; its FP64 copy is then not written
+  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
+  const bool h16 = h16_on && c->basis16 && m <= 16 && precond_folds(c);
   const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
@@ -1129,7 +1148,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       // ... and the operator reads that stored FP32 copy (half the bytes of the x gathers; S Z_j = V H then
       // holds for exactly the vectors the correction uses), so the sweeps need not store the FP64 z at all
       float* zj = flex ? c->zbasisf.p + (size_t)j * vs : nullptr;
-      precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32);
+      precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32, h16 ? Vh + (size_t)j * vs : nullptr);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr);
       if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
@@ -1155,7 +1174,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
                           c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur);
       if (b16)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
-                             c->scale.p, c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
+                             c->scale.p, h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
       else if (b32)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, c->vcur.p, nm, Vf + (size_t)(j + 1) * vs, nm);

@@ -4,7 +4,7 @@ set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2final2
+O=$R/gpurun_out/r2final3
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1
 echo "pytest rc=$?" >> $O/gputests.log
@@ -13,7 +13,7 @@ python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1
 ( time timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench.time
 echo "bench rc=$?"; tail -3 $O/bench.time; cut -c1-240 $O/bench.json; echo
 for w in cfg3 cfg4 cfg5; do
-  st=2; wu=1; [ $w = cfg5 ] && st=1 && wu=0; [ $w = cfg4 ] && st=1
+  st=2; wu=1; [ $w = cfg5 ] && st=1; [ $w = cfg4 ] && st=1
   timeout -k 10 900 python bench.py --workload $w --steps $st --warmup $wu > $O/$w.json 2> $O/$w.err; cut -c1-160 $O/$w.json; echo
 done
 cd /tmp
