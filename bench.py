@@ -161,7 +161,8 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
                    G * (pb_ * float(kp) * kp + 16.0 * kc * m)),
         "dots": ("ricadi::cols_dots_kernel (+reduce_partials)", G * ((nvec * b + 8.0) * n * m)),
         "update_dots": ("ricadi::cols_update_dots_kernel (+reduce_partials)", G * ((nvec * b + 16.0) * n * m)),
-        "update": ("ricadi::cols_update_kernel", G * ((nvec * b + 16.0 + b) * n * m)),
+        # ... + w read + the new vector in storage precision (+ its FP64 copy unless the preconditioner reads the FP16 one)
+        "update": ("ricadi::cols_update_kernel", G * ((nvec * b + 8.0 + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
     }
     out = {}
     for key, (kname, nbytes) in models.items():

@@ -325,7 +325,10 @@ int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_
 
 /* Structure of the preconditioner the context built for its operator:
  * out = [NV, NP, velocity blocks, Schur blocks, block size, coarse dimension,
- *        SpMM row blocks, max distinct columns per row block]; nout >= 8.           */
+ *        SpMM row blocks, max distinct columns per row block,
+ *        preconditioner levels in use, dimension of the dense inverse on the last level,
+ *        1 if the GMRES iteration hands the preconditioner the FP16-stored vector];
+ * nout >= 8; entries beyond nout are not written.                                   */
 int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
 
 /* Average duration (ms) of the thin QR of a device-resident NV x c factor (the device

@@ -514,10 +514,10 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 10)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 10))
+        a = (C.c_int * 11)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 11))
         return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
-                         "dense_coarse"), list(a)))
+                         "dense_coarse", "fp16_vector_input"), list(a)))
 
     def time_qr_dev(self, z_ptr, c, reps):
         ms = C.c_double(0.0)

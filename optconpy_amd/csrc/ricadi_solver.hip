@@ -818,6 +818,15 @@ static bool precond_folds(const ricadi_ctx* c) {
   static const bool fold = getenv("RICADI_NO_FOLD") == nullptr;
   return fold && c->kc > 0 && c->ady_ok && c->np > 0;
 }
+static bool precond_reads_h16_static(const ricadi_ctx* c) {
+  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
+  return h16_on && precond_folds(c);
+}
+// Does the GMRES iteration hand the preconditioner the FP16-stored vector (RICADI_H16=0: the FP64 copy)?
+static bool precond_reads_h16(const ricadi_ctx* c, int m) {
+  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
+  return h16_on && c->basis16 && m <= 16 && precond_folds(c);
+}
 static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z,
                           float* z32 = nullptr, size_t gs32 = 0, bool only32 = false,
                           const _Float16* r16 = nullptr) {
@@ -1043,8 +1052,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   // (only where the launches are bandwidth bound -- the multi-shift SpMM regime: cfg5 K1 1252 -> 1150 us per
   // launch, cycle +2 %; at cfg2 the FP32 gathers are no faster and the step was 1.4 % slower)
   // the preconditioner reads the current vector from the FP16 basis itself; its FP64 copy is then not written
-  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
-  const bool h16 = h16_on && c->basis16 && m <= 16 && precond_folds(c);
+  const bool h16 = precond_reads_h16(c, m);
   const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
@@ -2959,12 +2967,15 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         break;
       case 7:
-        if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
+        if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
         else if (b32) launch_cols_update_b(st, gt, n, m, nvec, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vf + (size_t)nvec * vs, nm);
         else launch_cols_update_b(st, gt, n, m, nvec, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, V + (size_t)nvec * vs, nm);
         break;
       case 8:
-        precond_apply(c, bt, c->wv.p, nm, c->zv.p);
+        if (b16 && precond_reads_h16(c, m))
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, false, Vh);
+        else
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm);
         break;
       case 9:
         if (c->kc <= 0) throw HipError{"no coarse level"};
@@ -3026,6 +3037,9 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   for (; lc->child; lc = lc->child.get()) ++lv;
   if (nout > 8) out[8] = lv;
   if (nout > 9) out[9] = lc->kc;
+  // [10]: 1 if the iteration reads the current vector from the FP16 basis (no FP64 copy written), 16-column panels
+  if (nout > 10) out[10] = (c->has_op && (getenv("RICADI_BASIS64") == nullptr) && (getenv("RICADI_BASIS32") == nullptr) &&
+                            c->n <= (1 << 21) && precond_reads_h16_static(c)) ? 1 : 0;
   return RICADI_OK;
 }
 

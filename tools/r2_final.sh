@@ -26,4 +26,9 @@ stats classes58 tools/kernel_classes.py 58 16 100
 stats spmm58 tools/spmm_batch_pmc.py 58 16 200
 stats spmm236 tools/spmm_batch_pmc.py 236 16 50
 grep "us per launch" $O/spmm58.log $O/spmm236.log | cut -c1-200
+# attribution at cfg5 (warm): one feature off at a time
+for t in "RICADI_FGMRES=0" "RICADI_ARNOLDI16=0" "RICADI_LEVELS=2" "RICADI_X32=0" "RICADI_H16=0" "RICADI_COARSE_GJ=0"; do
+  env $t timeout -k 10 900 python bench.py --workload cfg5 --steps 1 --warmup 1 > $O/cfg5_off.json 2> $O/cfg5_off.err
+  echo "cfg5 with $t: $(cut -c1-110 $O/cfg5_off.json)"
+done
 exit 0
