@@ -715,6 +715,8 @@ void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* al
   // blocks alone do not fill the chip
   int ysplit = 1;
   while (ysplit < gt.ng && (long)nblk * ysplit < 900 && ysplit < 8) ysplit *= 2;
+  static const int ys_env = getenv("RICADI_MS_YSPLIT") ? atoi(getenv("RICADI_MS_YSPLIT")) : 0;
+  if (ys_env > 0) ysplit = ys_env;
   ysplit = std::min(ysplit, gt.ng);
   const dim3 grid(nblk, ysplit, 1), block(256);
   const size_t lds = spmm_blocked_ms_lds_bytes(max_cols);
