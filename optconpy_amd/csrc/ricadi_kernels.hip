@@ -2458,48 +2458,68 @@ __global__ __launch_bounds__(256) void gj_cols_kernel(GjPtrs A, int k, int k0, i
     a[at] = 0.0;
   }
 }
-// D (GJ_NB x GJ_NB, row-major, leading nbe x nbe block used) <- its inverse; flag set on a vanishing pivot
+// D (GJ_NB x GJ_NB, row-major, leading nbe x nbe block used) <- its inverse; flag set on a vanishing pivot.
+// One workgroup of 1024 threads per matrix; the matrix lives in REGISTERS (thread (bi, bj) owns the 4 x 4
+// sub-block at rows 4 bi, columns 4 bj), a Gauss-Jordan step only passes the pivot row and column through LDS
+// (double buffered: one barrier per step).  The first version kept the matrix in LDS and rewrote all of it
+// per step: bound by the LDS store rate, 260 us per call instead of ~25.
 __global__ __launch_bounds__(1024) void gj_diag_kernel(double* __restrict__ D, int nbe, int* __restrict__ flag) {
-  extern __shared__ double gjm[];          // GJ_NB x (GJ_NB + 1) matrix, then row and column buffers
-  constexpr int LD = GJ_NB + 1;
-  double* rowb = gjm + GJ_NB * LD;
-  double* colb = rowb + GJ_NB;
+  __shared__ double rowb[2][GJ_NB], colb[2][GJ_NB];
   double* d = D + (size_t)blockIdx.x * GJ_NB * GJ_NB;
-  for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 1024) {
-    const int i = e / GJ_NB, j = e - i * GJ_NB;
-    gjm[i * LD + j] = (i < nbe && j < nbe) ? d[e] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  // 128 rows x 8 column segments of 16; consecutive lanes = consecutive rows (row stride 129 doubles: the 32
-  // lanes of an LDS access group fall on distinct banks)
-  const int i = threadIdx.x & 127, j0 = (threadIdx.x >> 7) * 16;
+  const int bi = threadIdx.x & 31, bj = threadIdx.x >> 5;
+  const int i0 = 4 * bi, j0 = 4 * bj;
+  double a[4][4];
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) {
+      const int i = i0 + ti, j = j0 + tj;
+      a[ti][tj] = (i < nbe && j < nbe) ? d[(size_t)i * GJ_NB + j] : (i == j ? 1.0 : 0.0);
+    }
+  bool bad = false;
   for (int p = 0; p < nbe; ++p) {
-    const double piv = gjm[p * LD + p];
-    if (!(fabs(piv) > 1e-300)) {           // uniform: every thread reads the same pivot
-      if (threadIdx.x == 0) atomicExch(flag, 1);
+    const int buf = p & 1;
+    if ((p >> 2) == bi) {          // owners of the pivot row
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+        if (i0 + ti == p) {
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj) rowb[buf][j0 + tj] = a[ti][tj];
+        }
+    }
+    if ((p >> 2) == bj) {          // owners of the pivot column
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+        if (j0 + tj == p) {
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) colb[buf][i0 + ti] = a[ti][tj];
+        }
+    }
+    __syncthreads();
+    const double piv = rowb[buf][p];
+    if (!(fabs(piv) > 1e-300)) {   // uniform: every thread reads the same pivot
+      bad = true;
       break;
     }
     const double inv = 1.0 / piv;
-    if (threadIdx.x < GJ_NB) {
-      rowb[threadIdx.x] = threadIdx.x == p ? inv : gjm[p * LD + threadIdx.x] * inv;
-      colb[threadIdx.x] = gjm[threadIdx.x * LD + p];
-    }
-    __syncthreads();
-    const double f = colb[i];
+    double rj[4], ci[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int j = j0 + t;
-      double v;
-      if (i == p) v = rowb[j];
-      else v = (j == p ? 0.0 : gjm[i * LD + j]) - f * rowb[j];
-      gjm[i * LD + j] = v;
-    }
-    __syncthreads();
+    for (int tj = 0; tj < 4; ++tj) rj[tj] = (j0 + tj == p) ? inv : rowb[buf][j0 + tj] * inv;
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) ci[ti] = colb[buf][i0 + ti];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        if (i0 + ti == p) a[ti][tj] = rj[tj];
+        else a[ti][tj] = ((j0 + tj == p) ? 0.0 : a[ti][tj]) - ci[ti] * rj[tj];
+      }
   }
-  for (int e = threadIdx.x; e < GJ_NB * GJ_NB; e += 1024) {
-    const int ii = e / GJ_NB, jj = e - ii * GJ_NB;
-    d[e] = gjm[ii * LD + jj];
-  }
+  if (bad && threadIdx.x == 0) atomicExch(flag, 1);
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) d[(size_t)(i0 + ti) * GJ_NB + j0 + tj] = a[ti][tj];
 }
 __global__ __launch_bounds__(256) void gj_rows_kernel(GjPtrs A, int k, int k0, int nbe, const double* __restrict__ Rb) {
   double* __restrict__ a = A.a[blockIdx.z];
@@ -2517,14 +2537,7 @@ void launch_gj_prep(hipStream_t st, int nb, double* const* mats, int k, int k0, 
   hipLaunchKernelGGL(gj_cols_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Cb);
 }
 void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag) {
-  const size_t lds = (size_t)(GJ_NB * (GJ_NB + 1) + 2 * GJ_NB) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gj_diag_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gj_diag_kernel, dim3(nb), dim3(1024), lds, st, D, nbe, flag);
+  hipLaunchKernelGGL(gj_diag_kernel, dim3(nb), dim3(1024), 0, st, D, nbe, flag);
 }
 void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb) {
   GjPtrs P;
