@@ -405,6 +405,8 @@ def main():
                     help="N>1: after the cfg2 headline also time one shift cycle of the BASELINE configuration "
                          "quoted for this GPU count (cfg3 @ 4, cfg4 @ 8) and add it as `baseline_config_for_n`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 on a one-GPU box: all ranks on device 0 with gloo (checks the code path only)")
     ap.add_argument("--cpu-full", action="store_true",
                     help="cpu_baseline: run the whole single-core step (all LUs, all panel solves, ~100 s)")
     ap.add_argument("--no-large-roofline", action="store_true")
@@ -420,7 +422,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 and args.rehearse_one_gpu:
+        # developer rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo collectives
+        # (RCCL refuses two ranks on one device); the figure it prints is not a measurement
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        os.environ["LOCAL_RANK"] = "0"      # the drop-in backend picks its device from it
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
