@@ -1048,24 +1048,53 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
   for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
   __syncthreads();
   {
-    // update: one element per thread and pass (2-byte loads; the 16-byte form with the vectors split over
-    // lane pairs was slower at every basis size: 1.69 vs 1.02 ms at n = 5e5, 7 vectors)
+    // update: a thread owns the elements tid, tid + 256, ... of the chunk (one column c = tid & 15, four rows);
+    // per pair of basis vectors its 8 two-byte loads are issued together and the two coefficients come from
+    // LDS once.  (The 16-byte form with the vectors split over lane pairs was slower at every basis size:
+    // 1.69 vs 1.02 ms at n = 5e5, 7 vectors.)
     const size_t base = (size_t)r0 * 16;
-    for (int e = threadIdx.x; e < DOT_ROWS * 16; e += 256) {
-      double v = 0.0;
-      if (e < nr * 16) {
-        const int c = e & 15;
-        double s0 = 0.0, s1 = 0.0;
-        int i = 0;
-        for (; i + 1 < nvec; i += 2) {
-          s0 = fma(hl[i * 16 + c], (double)basis[(size_t)i * vstride + base + e], s0);
-          s1 = fma(hl[(i + 1) * 16 + c], (double)basis[(size_t)(i + 1) * vstride + base + e], s1);
-        }
-        if (i < nvec) s0 = fma(hl[i * 16 + c], (double)basis[(size_t)i * vstride + base + e], s0);
-        v = w[base + e] - (s0 + s1);
-        w[base + e] = v;
+    const int c = threadIdx.x & 15;
+    constexpr int NE = DOT_ROWS * 16 / 256;          // 4
+    int e[NE];
+    bool ok[NE];
+    double sacc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      e[k] = threadIdx.x + 256 * k;
+      ok[k] = e[k] < nr * 16;
+      sacc[k] = 0.0;
+    }
+    int i = 0;
+    for (; i + 1 < nvec; i += 2) {
+      _Float16 b0[NE], b1[NE];
+      const _Float16* v0 = basis + (size_t)i * vstride + base;
+      const _Float16* v1 = v0 + vstride;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        b0[k] = v0[ok[k] ? e[k] : 0];               // unconditional loads (row 0 of the chunk is always valid)
+        b1[k] = v1[ok[k] ? e[k] : 0];
       }
-      wl[(e >> 4) * WLS + (e & 15)] = v;
+      const double h0 = hl[i * 16 + c], h1 = hl[(i + 1) * 16 + c];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) sacc[k] = fma(h1, (double)b1[k], fma(h0, (double)b0[k], sacc[k]));
+    }
+    if (i < nvec) {
+      _Float16 b0[NE];
+      const _Float16* v0 = basis + (size_t)i * vstride + base;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) b0[k] = v0[ok[k] ? e[k] : 0];
+      const double h0 = hl[i * 16 + c];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) sacc[k] = fma(h0, (double)b0[k], sacc[k]);
+    }
+    double wv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) wv[k] = w[base + (ok[k] ? e[k] : 0)];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double v = ok[k] ? wv[k] - sacc[k] : 0.0;
+      if (ok[k]) w[base + e[k]] = v;
+      wl[(e[k] >> 4) * WLS + c] = v;
     }
   }
   __syncthreads();
@@ -1860,7 +1889,7 @@ void launch_block_apply_rect_b(hipStream_t st, const GroupTab& gt, int bs, int k
 // Segment 1 is always the block's own rows with a BS x BS matrix; segment 2 has a compile-time
 // padded width K2 (its list may be shorter).  All index loads are issued first, then all gathers,
 // then the MFMAs: the two segments' dependent-load chains overlap instead of following each other.
-template <int BS, int K2, class T>
+template <int BS, int K2, class T, bool H1 = false>
 __global__ __launch_bounds__(256) void block_apply2_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
     GroupPtrsT<T> m1s, Seg2 s1, GroupPtrsT<T> m2s, Seg2 s2, double* __restrict__ out, int ldo, size_t gso,
@@ -1911,18 +1940,36 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
     const int col = c0 + r;
     const bool cok = col < m;
     double x1[N1][4], x2[N2][4];
+    if (H1) {
+      // raw FP16 loads first, conversion afterwards: a conversion between the loads makes the compiler wait
+      // for each of them in turn (the sweep was 37.8 instead of 32.1 us with the FP16 input)
+      _Float16 h1[N1][4];
+#pragma unroll
+      for (int kc = 0; kc < N1; ++kc)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          h1[kc][s4] = in1h[(r1[kc][s4] >= 0 && cok) ? (size_t)r1[kc][s4] * m + col : (size_t)0];   // unconditional load
+#pragma unroll
+      for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          x2[kc][s4] = (r2[kc][s4] >= 0 && cok) ? in2[(size_t)r2[kc][s4] * m + col] : 0.0;
+#pragma unroll
+      for (int kc = 0; kc < N1; ++kc)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x1[kc][s4] = (r1[kc][s4] >= 0 && cok) ? (double)h1[kc][s4] : 0.0;
+    } else {
 #pragma unroll
     for (int kc = 0; kc < N1; ++kc)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
-        x1[kc][s4] = (r1[kc][s4] >= 0 && cok)
-                         ? (in1h ? (double)in1h[(size_t)r1[kc][s4] * m + col] : in1[(size_t)r1[kc][s4] * m + col])
-                         : 0.0;
+        x1[kc][s4] = (r1[kc][s4] >= 0 && cok) ? in1[(size_t)r1[kc][s4] * m + col] : 0.0;
 #pragma unroll
     for (int kc = 0; kc < N2; ++kc)
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
         x2[kc][s4] = (r2[kc][s4] >= 0 && cok) ? in2[(size_t)r2[kc][s4] * m + col] : 0.0;
+    }
     d4 acc1[NT], acc2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc1[t] = acc2[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -1972,13 +2019,22 @@ static void block_apply2_impl(hipStream_t st, const GroupTab& gt, int bs, int nb
   if (nblocks <= 0 || gt.ng <= 0) return;
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
-#define RICADI_BA2(B, K)                                                                              \
-  hipLaunchKernelGGL((block_apply2_kernel<B, K, T>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, \
+  // H = first-segment rows read from an FP16 panel (s1.in16): its own instantiation -- both paths in one
+  // kernel cost 148 instead of 128 VGPRs, i.e. one wave per SIMD less
+#define RICADI_BA2(B, K, H)                                                                              \
+  hipLaunchKernelGGL((block_apply2_kernel<B, K, T, H>), grid, block, 0, st, gt, nblocks, bptr, rows, m1, s1, m2, \
                      s2, out, ldo, gso, m, pa)
-  if (bs == 32 && s2.kstride == 32) RICADI_BA2(32, 32);
-  else if (bs == 32) RICADI_BA2(32, 64);
-  else if (s2.kstride == 32) RICADI_BA2(16, 32);
-  else RICADI_BA2(16, 64);
+  if (s1.in16) {
+    if (bs == 32 && s2.kstride == 32) RICADI_BA2(32, 32, true);
+    else if (bs == 32) RICADI_BA2(32, 64, true);
+    else if (s2.kstride == 32) RICADI_BA2(16, 32, true);
+    else RICADI_BA2(16, 64, true);
+  } else {
+    if (bs == 32 && s2.kstride == 32) RICADI_BA2(32, 32, false);
+    else if (bs == 32) RICADI_BA2(32, 64, false);
+    else if (s2.kstride == 32) RICADI_BA2(16, 32, false);
+    else RICADI_BA2(16, 64, false);
+  }
 #undef RICADI_BA2
 }
 void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
