@@ -911,7 +911,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(GroupTab gt, int n
   const int o = blockIdx.x * 16 + oo;
   double s0 = 0.0, s1 = 0.0;
   if (o < nout) {
+    // eight loads in flight per thread (two left the kernel waiting on ~15 dependent round trips: 6.6 us)
     int b = bsl;
+    double t[8];
+    for (; b + 112 < nblk; b += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(b + 16 * u) * nout + o];
+      s0 += (t[0] + t[2]) + (t[4] + t[6]);
+      s1 += (t[1] + t[3]) + (t[5] + t[7]);
+    }
     for (; b + 16 < nblk; b += 32) {
       s0 += partial[(size_t)b * nout + o];
       s1 += partial[(size_t)(b + 16) * nout + o];
@@ -1619,6 +1627,31 @@ __device__ __forceinline__ void load4(const float* p, double (&a)[4]) {
   a[0] = (double)u.x; a[1] = (double)u.y; a[2] = (double)u.z; a[3] = (double)u.w;
 }
 
+// four consecutive stored entries as ONE raw load; converted to FP64 only when used (a conversion between
+// loads makes the compiler wait for each load in turn)
+template <class T>
+struct Raw4;
+template <>
+struct Raw4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ float4 load(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void unpack(const float4& u, double (&a)[4]) {
+    a[0] = (double)u.x; a[1] = (double)u.y; a[2] = (double)u.z; a[3] = (double)u.w;
+  }
+};
+template <>
+struct Raw4<double> {
+  struct type { double2 lo, hi; };
+  static __device__ __forceinline__ type load(const double* p) {
+    type t;
+    t.lo = reinterpret_cast<const double2*>(p)[0];
+    t.hi = reinterpret_cast<const double2*>(p)[1];
+    return t;
+  }
+  static __device__ __forceinline__ void unpack(const type& u, double (&a)[4]) {
+    a[0] = u.lo.x; a[1] = u.lo.y; a[2] = u.hi.x; a[3] = u.hi.y;
+  }
+};
 template <int BS, class T>
 __global__ __launch_bounds__(256) void block_apply_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
@@ -1797,42 +1830,83 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
   const int i0 = iptr[wave], ni = iptr[wave + 1] - i0;
   const T* Gi = mat + (size_t)wave * BS * KS;
   constexpr int NT = BS / 16, NK = KS / 16;
+  // Every index this wave needs is loaded up front and WITHOUT conditions (clamped to a valid entry, masked
+  // at use): an index load inside the condition of its gather made the compiler wait for every pair in turn
+  // -- the kernel was a chain of ~20 dependent round trips.
+  int xrow[NK][4], orow[NT][4], oagg[NT][4];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int kk = kc * 16 + 4 * q + s2;
+      xrow[kc][s2] = ni > 0 ? irows[i0 + min(kk, ni - 1)] : 0;
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) orow[t][e] = rows[b0 + min(16 * t + q + 4 * e, nb - 1)];
+  const int* __restrict__ aggp = ec ? pa.aggof : rows;        // a readable dummy when there is no coarse part
+  const double* __restrict__ ecp = ec ? ec : out;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) oagg[t][e] = aggp[orow[t][e]];
   for (int c0 = 0; c0 < m; c0 += 16) {
     const int col = c0 + r;
+    const bool cok = col < m;
+    const int colx = cok ? col : 0;
+    // all gathers, all tile loads, then (old output, coarse part) -- each group issued together
+    double xb[NK][4];
+    typename Raw4<T>::type graw[NT][NK];
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) xb[kc][s2] = in[(size_t)xrow[kc][s2] * ldi + colx];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) graw[t][kc] = Raw4<T>::load(Gi + (size_t)(16 * t + r) * KS + kc * 16 + 4 * q);
+    __builtin_amdgcn_sched_barrier(0);
     d4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kc = 0; kc < NK; ++kc) {
       if (kc * 16 >= ni) break;                 // wave-uniform: chunks beyond the block's inputs
-      double xb[4];
+      double xm[4];
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const int kk = kc * 16 + 4 * q + s2;
-        xb[s2] = (kk < ni && col < m) ? in[(size_t)irows[i0 + kk] * ldi + col] : 0.0;
-      }
+      for (int s2 = 0; s2 < 4; ++s2) xm[s2] = (kc * 16 + 4 * q + s2 < ni && cok) ? xb[kc][s2] : 0.0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         double a4[4];
-        load4(Gi + (size_t)(16 * t + r) * KS + kc * 16 + 4 * q, a4);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xb[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xb[1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xb[2], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xb[3], acc[t], 0, 0, 0);
+        Raw4<T>::unpack(graw[t][kc], a4);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xm[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xm[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xm[2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xm[3], acc[t], 0, 0, 0);
       }
     }
+    // old output and coarse part: again all loads together, without conditions
+    double oldv[NT][4], ecv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        oldv[t][e] = out[(size_t)orow[t][e] * ldo + colx];
+        ecv[t][e] = ecp[(size_t)oagg[t][e] * m + colx];
+      }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int il = 16 * t + q + 4 * e;
-        if (il < nb && col < m) {
-          const int row = rows[b0 + il];
-          double* o = &out[(size_t)row * ldo + col];
-          double v = subtract ? *o - acc[t][e] : acc[t][e];
-          if (ec) v += ec[(size_t)pa.aggof[row] * m + col];   // fused coarse-level prolongation
-          if (!(pa.out32 && pa.only32)) *o = v;
-          if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
+        if (il < nb && cok) {
+          const size_t at = (size_t)orow[t][e] * ldo + col;
+          double v = subtract ? oldv[t][e] - acc[t][e] : acc[t][e];
+          if (ec) v += ecv[t][e];
+          if (!(pa.out32 && pa.only32)) out[at] = v;
+          if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + at] = (float)v;
         }
       }
   }
@@ -2441,7 +2515,9 @@ static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, 
   const int kp = (k + 15) / 16;
   // one row tile per workgroup: four tiles per workgroup (rc values loaded once for four MFMA
   // groups) measured no faster -- 133 VGPRs, 3 waves per SIMD: 63 vs 57-63 us at cfg2, G = 16; two tiles
-  // (81 VGPRs): 54.9 vs 52.8 us at cfg2, 168 vs 174 us on the 3.2k child matrix of cfg5
+  // (81 VGPRs): 54.9 vs 52.8 us at cfg2, 168 vs 174 us on the 3.2k child matrix of cfg5; four chunks per pass
+  // with all 20 loads issued together (70 VGPRs): 55.4 vs 50-52 us at cfg2, 178 vs 165 us at cfg5 -- the launch
+  // wants waves, not loads per wave
   dim3 grid(kp, (m + 15) / 16, gt.ng);
   hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
 }
