@@ -1752,11 +1752,25 @@ __global__ __launch_bounds__(256) void block_apply_kernel(
   }
 }
 template <class T>
+static void block_apply_rect_impl(hipStream_t st, const GroupTab& gt, int bs, int ks, int nblocks,
+                                  const int* bptr, const int* rows, const int* iptr, const int* irows,
+                                  const GroupPtrsT<T>& mats, const double* in, int ldi, size_t gsi, double* out,
+                                  int ldo, size_t gso, int m, int subtract, const ProlongArgs& pa);
+template <class T>
 static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                              const int* rows, const GroupPtrsT<T>& inv, const double* in, int ldi,
                              size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,
                              const ProlongArgs& pa, const CsrInArgs& ci) {
   if (nblocks <= 0 || gt.ng <= 0) return;
+  // plain panel input, 32 x 32 blocks: the rectangle kernel with the block's own rows as its input list (its loads
+  // are issued in groups; this kernel's index -> gather pairs are a chain of dependent round trips).
+  // RICADI_BA_PLAIN=1 keeps this kernel.
+  static const bool via_rect = !(getenv("RICADI_BA_PLAIN") && atoi(getenv("RICADI_BA_PLAIN")) != 0);
+  if (via_rect && !ci.rp && bs == 32) {
+    block_apply_rect_impl(st, gt, 32, 32, nblocks, bptr, rows, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m,
+                          subtract, pa);
+    return;
+  }
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
   switch (bs) {
@@ -1904,6 +1918,7 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
         if (il < nb && cok) {
           const size_t at = (size_t)orow[t][e] * ldo + col;
           double v = subtract ? oldv[t][e] - acc[t][e] : acc[t][e];
+          if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + at] = v;        // the result before the coarse part
           if (ec) v += ecv[t][e];
           if (!(pa.out32 && pa.only32)) out[at] = v;
           if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + at] = (float)v;
