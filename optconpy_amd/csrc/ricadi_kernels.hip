@@ -1765,8 +1765,11 @@ static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nbl
   // plain panel input, 32 x 32 blocks: the rectangle kernel with the block's own rows as its input list (its loads
   // are issued in groups; this kernel's index -> gather pairs are a chain of dependent round trips).
   // RICADI_BA_PLAIN=1 keeps this kernel.
+  // Only where the launch is latency bound (few waves: the Schur sweep of cfg2 has 110 blocks x 16 groups): with many
+  // waves the rectangle kernel's 152 VGPRs cost more than its grouped loads gain (velocity-sized sweep at cfg2:
+  // 43 vs 33 us).
   static const bool via_rect = !(getenv("RICADI_BA_PLAIN") && atoi(getenv("RICADI_BA_PLAIN")) != 0);
-  if (via_rect && !ci.rp && bs == 32) {
+  if (via_rect && !ci.rp && bs == 32 && (long)nblocks * gt.ng <= 8192) {
     block_apply_rect_impl(st, gt, 32, 32, nblocks, bptr, rows, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m,
                           subtract, pa);
     return;
