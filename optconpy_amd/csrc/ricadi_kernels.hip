@@ -1109,27 +1109,155 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
   chunk_dots16(basis, vstride, r0, nr, nvec, 1, wl, partial + (size_t)blockIdx.x * (nvec + 1) * 16);
 }
 
+// ---- the same two dot kernels for panels of 8 * NOCT columns (NOCT = 1, 3, 4: the projection solve, the
+// augmented Sherman-Morrison-Woodbury sweep [b, U] of the Newton step and wider panels): a DPP row holds the 16 row
+// slices of one (vector, column octet) pair.
+template <int NOCT>
+__device__ __forceinline__ void chunk_dots8x(const _Float16* __restrict__ basis, size_t vstride, int r0, int nr,
+                                             int nvec, int want_self, const double* wl, double* __restrict__ pout) {
+  constexpr int M = 8 * NOCT, WS = M + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 15, pr = lane >> 4;
+  const int ntot = nvec + (want_self ? 1 : 0);
+  const int npairs = ntot * NOCT;
+  for (int pq0 = 0; pq0 < npairs; pq0 += 16) {
+    const int pq = pq0 + 4 * wave + pr;
+    const int i = pq / NOCT, o = pq - i * NOCT;
+    double acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.0;
+    if (i < nvec) {
+      const _Float16* v = basis + (size_t)i * vstride + (size_t)r0 * M + o * 8;
+      half8_t x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = s + 16 * k;
+        if (row < nr) x[k] = *reinterpret_cast<const half8_t*>(v + (size_t)row * M);
+        else x[k] = (half8_t)(_Float16)0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double* wr = wl + (s + 16 * k) * WS + o * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = fma((double)x[k][t], wr[t], acc[t]);
+      }
+    } else if (i == nvec && want_self) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double* wr = wl + (s + 16 * k) * WS + o * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = fma(wr[t], wr[t], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = dpp_row_sum(acc[t]);
+    if (s == 0 && i < ntot) {
+      double2* op = reinterpret_cast<double2*>(pout + (size_t)i * M + o * 8);
+      op[0] = make_double2(acc[0], acc[1]);
+      op[1] = make_double2(acc[2], acc[3]);
+      op[2] = make_double2(acc[4], acc[5]);
+      op[3] = make_double2(acc[6], acc[7]);
+    }
+  }
+}
+template <int NOCT>
+__global__ __launch_bounds__(256) void cols_dots8x_kernel(
+    GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
+  constexpr int M = 8 * NOCT, WS = M + 2;
+  __shared__ __attribute__((aligned(16))) double wl[DOT_ROWS * WS];
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  {
+    const double2* src = reinterpret_cast<const double2*>(w + (size_t)r0 * M);
+    for (int e = threadIdx.x; e < DOT_ROWS * (M / 2); e += 256) {
+      const int row = e / (M / 2), c2 = e - row * (M / 2);
+      *reinterpret_cast<double2*>(wl + row * WS + 2 * c2) = row < nr ? src[e] : make_double2(0.0, 0.0);
+    }
+  }
+  __syncthreads();
+  const int nout = (nvec + (want_self ? 1 : 0)) * M;
+  chunk_dots8x<NOCT>(basis, vstride, r0, nr, nvec, want_self, wl, partial + (size_t)blockIdx.x * nout);
+}
+template <int NOCT>
+__global__ __launch_bounds__(256) void cols_update_dots8x_kernel(
+    GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
+    double* __restrict__ partial, size_t gsp) {
+  constexpr int M = 8 * NOCT, WS = M + 2;
+  extern __shared__ __attribute__((aligned(16))) double sm8x[];
+  double* wl = sm8x;                       // DOT_ROWS rows, stride WS
+  double* hl = sm8x + DOT_ROWS * WS;       // nvec x M
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  w += (size_t)grp * gsw;
+  partial += (size_t)grp * gsp;
+  const int r0 = blockIdx.x * DOT_ROWS;
+  const int nr = min(DOT_ROWS, nrows - r0);
+  for (int e = threadIdx.x; e < nvec * M; e += 256) hl[e] = h[e];
+  __syncthreads();
+  {
+    const size_t base = (size_t)r0 * M;
+    constexpr int NE = DOT_ROWS * M / 256;           // 2 * NOCT
+    int e[NE], c[NE];
+    bool ok[NE];
+    double sacc[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      e[k] = threadIdx.x + 256 * k;
+      c[k] = e[k] % M;
+      ok[k] = e[k] < nr * M;
+      sacc[k] = 0.0;
+    }
+    for (int i = 0; i < nvec; ++i) {
+      _Float16 b0[NE];
+      const _Float16* v0 = basis + (size_t)i * vstride + base;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) b0[k] = v0[ok[k] ? e[k] : 0];
+#pragma unroll
+      for (int k = 0; k < NE; ++k) sacc[k] = fma(hl[i * M + c[k]], (double)b0[k], sacc[k]);
+    }
+    double wv[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) wv[k] = w[base + (ok[k] ? e[k] : 0)];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const double v = ok[k] ? wv[k] - sacc[k] : 0.0;
+      if (ok[k]) w[base + e[k]] = v;
+      wl[(e[k] / M) * WS + c[k]] = v;
+    }
+  }
+  __syncthreads();
+  chunk_dots8x<NOCT>(basis, vstride, r0, nr, nvec, 1, wl, partial + (size_t)blockIdx.x * (nvec + 1) * M);
+}
+
 // out = scale * (w + sign * V h), stored in FP16 (outf) and, rounded identically, in FP64 (out):
 // thread = (row, column half), 16-byte basis loads, four vectors in flight
 __global__ __launch_bounds__(256) void cols_update16_kernel(
     GroupTab gt, size_t nhalf, GroupInts nvecs, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ h, size_t gsh, double sign, const double* __restrict__ w, size_t gsw,
     const double* __restrict__ scale, double* __restrict__ out, size_t gso, _Float16* __restrict__ outf,
-    size_t gsf) {
-  extern __shared__ double hl[];           // nvec x 16
+    size_t gsf, int m) {
+  extern __shared__ double hl[];           // nvec x m  (m = 8, 16, 24 or 32 columns)
+  const int noct = m >> 3;
   const int grp = gt.gid[blockIdx.z];
   const int nvec = nvecs.v[grp];
   basis += (size_t)grp * gsb;
   h += (size_t)grp * gsh;
   if (w) w += (size_t)grp * gsw;
-  if (scale) scale += (size_t)grp * 16;
+  if (scale) scale += (size_t)grp * m;
   if (out) out += (size_t)grp * gso;
   if (outf) outf += (size_t)grp * gsf;
-  for (int e = threadIdx.x; e < nvec * 16; e += 256) hl[e] = h[e];
+  for (int e = threadIdx.x; e < nvec * m; e += 256) hl[e] = h[e];
   __syncthreads();
   for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nhalf; idx += (size_t)gridDim.x * 256) {
     const size_t e = idx * 8;
-    const int c0 = (int)(idx & 1) * 8;
+    const int c0 = (int)(idx % (size_t)noct) * 8;
     double a[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) a[t] = 0.0;
@@ -1142,12 +1270,12 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) a[t] = fma(hl[(i + u) * 16 + c0 + t], (double)x[u][t], a[t]);
+        for (int t = 0; t < 8; ++t) a[t] = fma(hl[(i + u) * m + c0 + t], (double)x[u][t], a[t]);
     }
     for (; i < nvec; ++i) {
       const half8_t x = *reinterpret_cast<const half8_t*>(v + (size_t)i * vstride);
 #pragma unroll
-      for (int t = 0; t < 8; ++t) a[t] = fma(hl[i * 16 + c0 + t], (double)x[t], a[t]);
+      for (int t = 0; t < 8; ++t) a[t] = fma(hl[i * m + c0 + t], (double)x[t], a[t]);
     }
     if (w) {
       const double2* wp = reinterpret_cast<const double2*>(w + e);
@@ -1181,9 +1309,10 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
     }
   }
 }
-// RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update)
+// RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update;
+// 8: also for panels of 8, 24 and 32 columns)
 static bool arnoldi16(int which) {
-  static const int mask = getenv("RICADI_ARNOLDI16") ? atoi(getenv("RICADI_ARNOLDI16")) : 7;
+  static const int mask = getenv("RICADI_ARNOLDI16") ? atoi(getenv("RICADI_ARNOLDI16")) : 15;
   return (mask & which) != 0;
 }
 
@@ -1195,6 +1324,21 @@ static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
   const int nout = (nvec + (want_self ? 1 : 0)) * m;
   if (nout == 0 || gt.ng <= 0) return;
   if constexpr (std::is_same<BT, _Float16>::value) {
+    if ((m == 8 || m == 24 || m == 32) && arnoldi16(1) && arnoldi16(8)) {
+      const dim3 grid(nblk, 1, gt.ng);
+      if (m == 8)
+        hipLaunchKernelGGL((cols_dots8x_kernel<1>), grid, dim3(256), 0, st, gt, nrows, nvec, basis, vstride, gsb, w, gsw,
+                           want_self, partial, gsp);
+      else if (m == 24)
+        hipLaunchKernelGGL((cols_dots8x_kernel<3>), grid, dim3(256), 0, st, gt, nrows, nvec, basis, vstride, gsb, w, gsw,
+                           want_self, partial, gsp);
+      else
+        hipLaunchKernelGGL((cols_dots8x_kernel<4>), grid, dim3(256), 0, st, gt, nrows, nvec, basis, vstride, gsb, w, gsw,
+                           want_self, partial, gsp);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                         nblk, nout, partial, gsp, out, gso, 0);
+      return;
+    }
     if (m == 16 && arnoldi16(1)) {
       hipLaunchKernelGGL(cols_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
                          vstride, gsb, w, gsw, want_self, partial, gsp);
@@ -1304,6 +1448,23 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
   const int nblk = dots_num_blocks(nrows);
   const int nout = (nvec + 1) * m;
   if constexpr (std::is_same<BT, _Float16>::value) {
+    if ((m == 8 || m == 24 || m == 32) && arnoldi16(2) && arnoldi16(8) &&
+        (size_t)(DOT_ROWS * (m + 2) + nvec * m) * sizeof(double) <= 48 * 1024) {
+      const dim3 grid(nblk, 1, gt.ng);
+      const size_t lds = (size_t)(DOT_ROWS * (m + 2) + nvec * m) * sizeof(double);
+      if (m == 8)
+        hipLaunchKernelGGL((cols_update_dots8x_kernel<1>), grid, dim3(256), lds, st, gt, nrows, nvec, basis, vstride,
+                           gsb, h, gsh, w, gsw, partial, gsp);
+      else if (m == 24)
+        hipLaunchKernelGGL((cols_update_dots8x_kernel<3>), grid, dim3(256), lds, st, gt, nrows, nvec, basis, vstride,
+                           gsb, h, gsh, w, gsw, partial, gsp);
+      else
+        hipLaunchKernelGGL((cols_update_dots8x_kernel<4>), grid, dim3(256), lds, st, gt, nrows, nvec, basis, vstride,
+                           gsb, h, gsh, w, gsw, partial, gsp);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
+                         nblk, nout, partial, gsp, out, gso, 0);
+      return;
+    }
     if (m == 16 && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double) <= 48 * 1024) {
       hipLaunchKernelGGL(cols_update_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256),
                          (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
@@ -1391,12 +1552,13 @@ static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int 
   if constexpr (std::is_same<BT, _Float16>::value) {
     int nmax = 0;
     for (int i = 0; i < gt.ng; ++i) nmax = std::max(nmax, nvec.v[gt.gid[i]]);
-    if (m == 16 && arnoldi16(4) && (size_t)nmax * 16 * sizeof(double) <= 48 * 1024) {
-      const size_t nhalf = (size_t)nrows * 2;
+    if ((m == 16 || ((m & 7) == 0 && m <= 32 && arnoldi16(8))) && arnoldi16(4) &&
+        (size_t)nmax * m * sizeof(double) <= 48 * 1024) {
+      const size_t nhalf = (size_t)nrows * (m / 8);       // 8-column pieces
       const int grid16 = (int)std::min<size_t>((nhalf + 255) / 256, 8192);
       hipLaunchKernelGGL(cols_update16_kernel, dim3(grid16, 1, gt.ng), dim3(256),
-                         (size_t)std::max(nmax, 1) * 16 * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb,
-                         h, gsh, sign, w, gsw, scale, out, gso, outf, gsf);
+                         (size_t)std::max(nmax, 1) * m * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb,
+                         h, gsh, sign, w, gsw, scale, out, gso, outf, gsf, m);
       return;
     }
   }
