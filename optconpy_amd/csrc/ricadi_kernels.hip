@@ -1309,6 +1309,69 @@ __global__ __launch_bounds__(256) void cols_update16_kernel(
     }
   }
 }
+// Same update for an FP32-stored basis (the Z_j of the flexible GMRES: the correction x += Z y at the end of a
+// restart cycle): thread = 4 consecutive elements, 16-byte loads, four vectors in flight.  No stored copy.
+__global__ __launch_bounds__(256) void cols_update_f4_kernel(
+    GroupTab gt, size_t nquad, GroupInts nvecs, const float* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ h, size_t gsh, double sign, const double* __restrict__ w, size_t gsw,
+    const double* __restrict__ scale, double* __restrict__ out, size_t gso, int m) {
+  extern __shared__ double hl[];           // nvec x m
+  const int grp = gt.gid[blockIdx.z];
+  const int nvec = nvecs.v[grp];
+  basis += (size_t)grp * gsb;
+  h += (size_t)grp * gsh;
+  if (w) w += (size_t)grp * gsw;
+  if (scale) scale += (size_t)grp * m;
+  out += (size_t)grp * gso;
+  for (int e = threadIdx.x; e < nvec * m; e += 256) hl[e] = h[e];
+  __syncthreads();
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nquad; idx += (size_t)gridDim.x * 256) {
+    const size_t e = idx * 4;
+    const int c0 = (int)(e % (size_t)m);
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* v = basis + e;
+    int i = 0;
+    for (; i + 3 < nvec; i += 4) {
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const float4*>(v + (size_t)(i + u) * vstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* hh = hl + (i + u) * m + c0;
+        a[0] = fma(hh[0], (double)x[u].x, a[0]);
+        a[1] = fma(hh[1], (double)x[u].y, a[1]);
+        a[2] = fma(hh[2], (double)x[u].z, a[2]);
+        a[3] = fma(hh[3], (double)x[u].w, a[3]);
+      }
+    }
+    for (; i < nvec; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(v + (size_t)i * vstride);
+      const double* hh = hl + i * m + c0;
+      a[0] = fma(hh[0], (double)x.x, a[0]);
+      a[1] = fma(hh[1], (double)x.y, a[1]);
+      a[2] = fma(hh[2], (double)x.z, a[2]);
+      a[3] = fma(hh[3], (double)x.w, a[3]);
+    }
+    if (w) {
+      const double2* wp = reinterpret_cast<const double2*>(w + e);
+      const double2 w0 = wp[0], w1 = wp[1];
+      a[0] = w0.x + sign * a[0];
+      a[1] = w0.y + sign * a[1];
+      a[2] = w1.x + sign * a[2];
+      a[3] = w1.y + sign * a[3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] *= sign;
+    }
+    if (scale) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] *= scale[c0 + t];
+    }
+    double2* op = reinterpret_cast<double2*>(out + e);
+    op[0] = make_double2(a[0], a[1]);
+    op[1] = make_double2(a[2], a[3]);
+  }
+}
 // RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update;
 // 8: also for panels of 8, 24 and 32 columns)
 static bool arnoldi16(int which) {
@@ -1559,6 +1622,18 @@ static void cols_update_impl(hipStream_t st, const GroupTab& gt, int nrows, int 
       hipLaunchKernelGGL(cols_update16_kernel, dim3(grid16, 1, gt.ng), dim3(256),
                          (size_t)std::max(nmax, 1) * m * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb,
                          h, gsh, sign, w, gsw, scale, out, gso, outf, gsf, m);
+      return;
+    }
+  }
+  if constexpr (std::is_same<BT, float>::value) {
+    int nmax = 0;
+    for (int i = 0; i < gt.ng; ++i) nmax = std::max(nmax, nvec.v[gt.gid[i]]);
+    if ((m & 3) == 0 && !outf && out && arnoldi16(4) && (size_t)nmax * m * sizeof(double) <= 48 * 1024) {
+      const size_t nquad = nelem / 4;
+      const int gridq = (int)std::min<size_t>((nquad + 255) / 256, 8192);
+      hipLaunchKernelGGL(cols_update_f4_kernel, dim3(gridq, 1, gt.ng), dim3(256),
+                         (size_t)std::max(nmax, 1) * m * sizeof(double), st, gt, nquad, nvec, basis, vstride, gsb, h,
+                         gsh, sign, w, gsw, scale, out, gso, m);
       return;
     }
   }
