@@ -4,7 +4,7 @@ set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2final8
+O=$R/gpurun_out/r2final9
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1
 echo "pytest rc=$?" >> $O/gputests.log
