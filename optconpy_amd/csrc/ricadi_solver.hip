@@ -734,7 +734,9 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* sd, int m) { return make_batch
 static bool ms_pays(const ricadi_ctx* c, int ng, size_t nnz) {
   if (!c->ms_spmm) return false;
   if (c->ms_force) return true;
-  return ng >= 4 && (double)nnz * 10.0 * ng > 256e6;      // beyond the 256 MB infinity cache
+  // per-shift value arrays of the active groups near or beyond the 256 MB infinity cache (measured with the FP32
+  // operator input that follows this switch: cfg3, 227 MB: 197 -> 205 shift-solves/s; cfg2, 136 MB: 1.4 % slower)
+  return ng >= 4 && (double)nnz * 10.0 * ng > 200e6;
 }
 
 // ---- operator and preconditioner on device panels ---------------------------------
