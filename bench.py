@@ -22,9 +22,14 @@ One *unit* = one shift-solve: one saddle-point solve S(p) [V;L] = [R;0] with an
 NV x 16 panel to relative residual 1e-10.  Per-shift setup (the counterpart of the
 reference's sparse LUs) is part of every step: the cache is cleared first.
 
-N > 1 (one process per GPU, torch.distributed over RCCL): the shift-parallel sweeps
-of optconpy_amd/shift_parallel.py on the same problem -- work items = (shift, column
-half) pairs dealt to the ranks, one all-gather per sweep -> "scaling": "strong".
+N > 1 (one process per GPU, torch.distributed over RCCL): THE SAME STEP through the same
+boundary calls -- under torch.distributed the drop-in shards the ADI sweeps by shift over
+the ranks inside the library (ricadi_set_exchange: fixed owner per shift, every rank sets up
+and solves only its own shifts, one all-gather of the solution panels per sweep;
+projection, recombination, recompression, update norm and gain replicated) -> "scaling":
+"strong".  `python bench.py --gpus N` without WORLD_SIZE starts its own N ranks
+(`python -m torch.distributed.run ... bench.py` as a CHILD process, before anything touches
+the GPU) and relays rank 0's JSON line.
 
 The JSON line also carries: the same step through the Python sweep driver
 (`value_python_sweep_driver`), with FP64-stored Krylov basis / preconditioner
@@ -121,11 +126,19 @@ def spmm_roofline(ctx, nnz_k, nnz_j, n, m, shifts, reps=200):
     b_batch = nnz_k * 20.0 + 2.0 * nnz_j * 12.0 + 4.0 * (n + 1) + 16.0 * n * m * G
     gbs = nbytes / (med * 1e-3) / 1e9
     traffic, tsrc = traffic_entry("%dx%dx%d" % (G, n, m))
-    return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
-                kernel="ricadi::spmm_blocked_kernel", us_per_launch=round(med * 1e3, 2),
+    # which kernel served the launch (ricadi_solver.hip: ms_pays): the multi-shift kernel reads ONE value set
+    # for all groups -- its honest byte model is the batched form, and `frac` follows the kernel that ran
+    ms = G >= 4 and nnz_s * 10.0 * G > 200e6 and not os.environ.get("RICADI_MS_SPMM") == "0"
+    model = b_batch if ms else nbytes
+    gbs_model = model / (med * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(gbs_model, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(gbs_model / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
+                byte_model="batched form (one value set for all groups)" if ms else "per panel (G x B_spmm)",
+                frac_per_panel_model=round(gbs / HBM_PEAK_GBS, 4),
+                kernel="ricadi::spmm_blocked_ms_kernel" if ms else "ricadi::spmm_blocked_kernel",
+                us_per_launch=round(med * 1e3, 2),
                 us_per_launch_best=round(best * 1e3, 2),
-                frac_best=round(nbytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                frac_best=round(model / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 units_per_launch=G, algorithmic_bytes=int(nbytes),
                 algorithmic_bytes_per_unit=int(unit),
                 algorithmic_bytes_batched_form=int(b_batch),
@@ -155,8 +168,10 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     pb_ = 8 if os.environ.get("RICADI_PRECOND64") else 4
     kp = 16 * ((kc + 15) // 16)
     models = {
-        "block_v": ("ricadi::block_apply_kernel<32,%s>" % ("double" if pb_ == 8 else "float"),
-                    G * (pb_ * nb * 1024.0 + 16.0 * nv * m)),
+        # a plain velocity-sized sweep: not launched by the folded cycle (see pc_two_term / pc_rect below); kept as the
+        # reference point of the block-Jacobi apply itself
+        "block_v": ("ricadi::block_apply_kernel<32,%s> (plain sweep; not on the folded hot path)"
+                    % ("double" if pb_ == 8 else "float"), G * (pb_ * nb * 1024.0 + 16.0 * nv * m)),
         "coarse": ("ricadi::dense_apply_tiled_kernel" if pb_ == 4 else "ricadi::dense_apply_kernel<double>",
                    G * (pb_ * float(kp) * kp + 16.0 * kc * m)),
         "dots": ("ricadi::cols_dots_kernel (+reduce_partials)", G * ((nvec * b + 8.0) * n * m)),
@@ -173,6 +188,47 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
                         frac=round(gbs / HBM_PEAK_GBS, 4), us_per_launch=round(med * 1e3, 2),
                         us_per_launch_best=round(best * 1e3, 2), algorithmic_bytes=int(nbytes),
                         units_per_launch=G, nvec=nvec if key in ("dots", "update_dots", "update") else None)
+    # The stages of ONE preconditioner application, each issued alone by the solver's own code path
+    # (ricadi_time_kernel_dev 10 + k), so kernel and template instance are the ones the iteration launches
+    # at this size.  Byte models per launch; the FP32-stored operands are pb_ bytes.
+    kc0, npn = info["kc"], info["np"]
+    rk, tk = info.get("rect_ks", 0), info.get("two_term_ks", 0)
+    h16 = bool(info.get("fp16_vector_input")) and b == 2 and m <= 16
+    vin = 2.0 if h16 else 8.0
+    fl = "float" if pb_ == 4 else "double"
+    few = nb * G <= 8192
+    stages = {
+        "pc_restrict": ("ricadi::spmm_kernel_v2 (unit values, aggregate lists)", G * (vin * n * m + 8.0 * kc0 * m) + 4.0 * n),
+        "pc_coarse": (models["coarse"][0] if info["levels"] <= 2 else "child level: one full cycle of its own stages",
+                      models["coarse"][1] if info["levels"] <= 2 else None),
+        "pc_sy_prows": ("ricadi::spmm_kernel_v2 (pressure rows of S*Y)", None),
+        "pc_two_term": ("ricadi::block_apply2_kernel<32,%d,%s,%s>" % (tk, fl, "true" if h16 else "false") if tk else
+                        "ricadi::block_apply_kernel<32,%s>" % fl,
+                        G * (pb_ * nb * 32.0 * (32 + tk) + (vin + 8.0) * nv * m + 8.0 * kc0 * m)),
+        "pc_jprod": ("ricadi::spmm_kernel_v2 (J)", 12.0 * info.get("nnz_j", 0) + G * (8.0 * nv * m + 16.0 * npn * m)),
+        "pc_schur": (("ricadi::block_apply_rect_kernel<32,32,%s> (block's own rows as input list)" % fl)
+                     if info["nbp"] * G <= 8192 else "ricadi::block_apply_kernel<32,%s>" % fl,
+                     G * (pb_ * info["nbp"] * 1024.0 + (8.0 + 8.0 + 8.0 + 4.0) * npn * m)),
+        "pc_rect": ("ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl) if rk else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
+                    G * (pb_ * nb * 32.0 * max(rk, 32) + (8.0 + 8.0) * nv * m + 4.0 * n * m + 8.0 * npn * m + 8.0 * kc0 * m)),
+    }
+    tot = 0.0
+    for key, (kname, nbytes) in stages.items():
+        try:
+            ctx.time_kernel_dev(key, al, be, m, nvec=nvec, reps=10)
+            med, best = trials(lambda: ctx.time_kernel_dev(key, al, be, m, nvec=nvec, reps=reps), 3)
+        except Exception as e:
+            out[key] = {"error": str(e)}
+            continue
+        tot += med
+        o = dict(kernel=kname, us_per_launch=round(med * 1e3, 2), us_per_launch_best=round(best * 1e3, 2),
+                 units_per_launch=G)
+        if nbytes:
+            gbs = nbytes / (med * 1e-3) / 1e9
+            o.update(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(gbs / HBM_PEAK_GBS, 4), algorithmic_bytes=int(nbytes))
+        out[key] = o
+    out["precond_stages_sum_us"] = round(tot * 1e3, 1)
     # anatomy of one lockstep iteration at G groups (sum over its launches)
     ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=5)
     med, _ = trials(lambda: ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=50), 3)
@@ -290,6 +346,14 @@ def cpu_baseline(pr, ms, m, adi_steps, full=False):
                                step_seconds=round(wall, 2))
     except Exception as e:                                   # never lose the headline line
         out["parallel"] = {"error": str(e)}
+    if "value" in out.get("parallel", {}):
+        # the MEASURED figure is the headline of the object: the full step, nothing extrapolated, on the cores
+        # actually used; the bounded single-core sample (priced up) stays beside it
+        single = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "lu_seconds", "solve_seconds",
+                                      "step_seconds")}
+        par = out["parallel"]
+        out = dict(value=par["value"], unit=par["unit"], cores=par["cores"], kind="port", sample=par["sample"],
+                   step_seconds=par["step_seconds"], single_core=single)
     return out
 
 
@@ -414,6 +478,24 @@ def main():
                     help="headline only (no second figures, no kernel rooflines)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the N ranks ourselves: a CHILD torchrun (never an exec), decided before torch or the HIP
+        # library have been imported; rank 0's JSON line and the exit code are relayed
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "2")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        sys.exit(r.returncode)
+
     import torch
     import torch.distributed as dist
     from optconpy_amd import _lib, backend, problems as pb
@@ -536,7 +618,7 @@ def main():
         Kt = ops.gain(-1.0, Z, sp["tbd"])                    # gain on the replicated factor
         return info["adi_steps"], ops.gmres_iters, Kt.cpu().numpy(), ops.shift_solves
 
-    use_sp = world > 1 or args.python_driver
+    use_sp = args.python_driver        # N > 1 runs the SAME boundary step as N = 1 (the library shards the sweeps)
     if use_sp:
         sp_prepare()
     one_step = sp_step if use_sp else dropin_step
@@ -575,14 +657,19 @@ def main():
         basis = "FP64" if os.environ.get("RICADI_BASIS64") else "FP32" if os.environ.get("RICADI_BASIS32") else "FP16"
         prec = "FP64" if os.environ.get("RICADI_PRECOND64") else "FP32"
         if use_sp:
-            par = ("shift-parallel ADI on %d GPU(s) (Python sweep driver): %d shifts/sweep x %d column part(s) "
-                   "= %d work items dealt to the ranks, one batched lockstep solve per rank and sweep, "
-                   "1 all-gather/sweep" % (world, sp["G"], sp["parts"], sp["G"] * sp["parts"]))
+            par = ("shift-parallel ADI on %d GPU(s) (Python sweep driver, Lyapunov sweeps + gain only): %d shifts/sweep x "
+                   "%d column part(s) = %d work items dealt to the ranks, one batched lockstep solve per rank and "
+                   "sweep, 1 all-gather/sweep" % (world, sp["G"], sp["parts"], sp["G"] * sp["parts"]))
         else:
             par = ("drop-in boundary (sadptprj_riclyap_adi.proj_ric_utils.proj_alg_ric_newtonadi + get_mTzzTtb), "
-                   "C++ Newton-ADI, %s, 1 GPU"
+                   "C++ Newton-ADI, %s, %s"
                    % ("ADI steps one at a time" if args.stepwise
-                      else "sweeps of %d shifts in one batched lockstep solve" % args.sweep_width))
+                      else "sweeps of %d shifts in one batched lockstep solve" % args.sweep_width,
+                      "1 GPU" if world == 1 else
+                      "%d GPUs: the same full step on every rank count -- sweeps sharded by shift inside the library "
+                      "(owners %s), one all-gather of the solution panels per sweep over %s, everything else replicated"
+                      % (world, list(map(int, _lib.host_deal(ms, world))),
+                         "gloo (one-GPU rehearsal)" if args.rehearse_one_gpu else "RCCL")))
         out = {
             "metric": "ADI shift-solves/sec (wall-clock to feedback K in ms_per_step)",
             "value": round(units / elapsed, 3),
@@ -683,11 +770,9 @@ def main():
         G = max(1, min(args.sweep_width, 16, len(ms)))
         out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m, [float(p) for p in ms[:G]])
     elif rank == 0:
-        # N > 1: the launch a rank issues holds its share of the sweep's work items
-        G = max(1, min(args.sweep_width, 16, len(ms)))
-        items = G * sp["parts"]
-        g_loc = max(1, -(-items // world))
-        out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m // sp["parts"], [float(p) for p in ms[:min(g_loc, G)]])
+        # N > 1: the launch a rank issues holds its own shifts of the sweep
+        own = [float(p) for p, o in zip(ms, _lib.host_deal(ms, world)) if o == 0][:16]
+        out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m, own or [float(ms[0])])
     if world > 1 and args.also_baseline_config:
         cfg_for_n = {4: "cfg3", 8: "cfg4"}.get(world)
         if cfg_for_n:

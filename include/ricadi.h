@@ -312,6 +312,12 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* ctx, int ng, const double* alphas,
 #define RICADI_TK_UPDATE 7        /* cols_update (writes the new Krylov vector)           */
 #define RICADI_TK_PRECOND 8       /* the whole preconditioner application (all launches)  */
 #define RICADI_TK_RESTRICT 9      /* restriction Y^T r (CSR SpMM with unit values)        */
+/* 10 + k: stage k of the preconditioner application ALONE, issued by the solver's own code path (so the
+ * kernel and its template instance are the ones the iteration launches at this size):
+ * 0 restriction, 1 coarse apply (dense inverse or child cycle), 2 pressure rows of r - (S Y) e,
+ * 3 first velocity sweep (two-term block sweep with the coarse residual folded in), 4 J product,
+ * 5 Schur-complement sweep, 6 last velocity sweep (rectangle sweep with prolongation)             */
+#define RICADI_TK_PC_STAGE0 10
 int ricadi_time_kernel_dev(ricadi_ctx* ctx, int which, int ng, const double* alphas,
                            const double* betas, int m, int nvec, int reps,
                            double* ms_per_launch);
@@ -327,7 +333,9 @@ int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_
  * out = [NV, NP, velocity blocks, Schur blocks, block size, coarse dimension,
  *        SpMM row blocks, max distinct columns per row block,
  *        preconditioner levels in use, dimension of the dense inverse on the last level,
- *        1 if the GMRES iteration hands the preconditioner the FP16-stored vector];
+ *        1 if the GMRES iteration hands the preconditioner the FP16-stored vector,
+ *        padded width of the dense rectangles of the last velocity sweep (0: not in that form),
+ *        the same for the first (two-term) velocity sweep, NP, nnz(J), nnz(S*Y)];
  * nout >= 8; entries beyond nout are not written.                                   */
 int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
 
@@ -342,7 +350,48 @@ int ricadi_time_qr_dev(ricadi_ctx* ctx, const double* dZ, int c, int reps, doubl
 int ricadi_time_gram_dev(ricadi_ctx* ctx, const double* dZ, int c, double* dG, int reps,
                          double* ms_per_launch);
 
+/* ---- recycling of solved right-hand sides -------------------------------
+ * depth > 0: every batched solve whose groups share ONE right-hand side panel (the sweeps
+ * of the ADI) starts from the least-squares combination of the last `depth` panels it has
+ * already solved for the same shifts -- x0_g = sum_e Y_{g,e} C_e with C = argmin ||b - B C||_F
+ * over the stored right-hand sides B -- instead of from zero, and stores its own (b, y_g)
+ * afterwards.  The residual factors of consecutive ADI sweeps span nearly the same space
+ * (cfg2: ||b - B C|| / ||b|| = 5e-2 ... 7e-4 per column from the fourth sweep on), which
+ * saves that many digits of every later solve; the tolerance stays relative to ||b||.
+ * The ADI / Newton drivers switch it on for their own sweeps (depth 3; RICADI_RECYCLE=d
+ * overrides, 0 = off); this call sets the depth for direct ricadi_shift_solve*_dev calls
+ * (default 0, so that repeated identical solves measure what they seem to measure).
+ * ricadi_clear_cache() drops the stored panels.  No reference counterpart (SuperLU is direct). */
+int ricadi_set_recycle(ricadi_ctx* ctx, int depth);
+
+/* ---- shift-parallel sweeps across processes (one process per GPU) -------
+ * The ADI sweeps of ricadi_lyap_adi / ricadi_ric_newtonadi (sweep_width > 1) shard by shift:
+ * every rank owns a fixed subset of the shift list (ricadi_host_deal), sets up and solves only
+ * its own shifts of a sweep in one batched solve, and the solution panels are exchanged by ONE
+ * all-gather per sweep; recombination, recompression, update norm and gain are replicated, the
+ * stopping decisions are rank 0's (a second, tiny all-gather per sweep).  The library does not
+ * link a communication library: the host supplies the collective as a callback on two device
+ * buffers it owns (torch.distributed.all_gather_into_tensor over RCCL in the Python binding):
+ *   fn(user, send_dev, recv_dev, bytes_per_rank) must place rank r's first bytes_per_rank bytes
+ *   of send_dev at recv_dev + r * bytes_per_rank on EVERY rank and return 0 once the data are
+ *   visible to work enqueued afterwards on any stream (the library has synchronised its own
+ *   stream before the call).
+ * send_dev holds send_capacity bytes, recv_dev world * send_capacity.  world = 1 (or fn NULL)
+ * removes the exchange.  All ranks must make the same sequence of solver calls with the same
+ * arguments.  SURVEY.md section 8e; the reference has nothing distributed
+ * (/root/reference/solve_dae_ric.py:122 and optcont_main.py:577 are sequential loops).      */
+typedef int (*ricadi_allgather_fn)(void* user, const void* send_dev, void* recv_dev,
+                                   int64_t bytes_per_rank);
+int ricadi_set_exchange(ricadi_ctx* ctx, int rank, int world, ricadi_allgather_fn fn, void* user,
+                        void* send_dev, void* recv_dev, int64_t send_capacity);
+
 /* ---- host-side logic exported for CPU tests ---------------------------- */
+/* Owner rank of every entry of an ADI shift list under `world` ranks: longest-processing-time
+ * dealing on the lockstep cost model  T(rank) = a max_g it_g + b sum_g it_g  (a / b = 3.2: the
+ * latency floor and the per-group slope of one lockstep iteration) with
+ * predicted iteration counts it(p) that fall with |p| (the small shifts are the slow solves).
+ * Deterministic in (shifts, world): every rank computes the same table.  Returns 0 or <0.   */
+int ricadi_host_deal(const double* shifts, int nshifts, int world, int32_t* owner_out);
 /* Greedy BFS aggregation of the graph of a CSR pattern into blocks of at
  * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */
 int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col,

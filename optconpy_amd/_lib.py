@@ -18,6 +18,9 @@ LIB_PATH = os.environ.get("RICADI_LIB", os.path.join(_HERE, "libricadi_hip.so"))
 RICADI_OK = 0
 RICADI_ENOCONV = -3
 MAX_M = 128
+# ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
+# are part of the ABI and are not covered by the struct handshake below
+ABI_VERSION = 300
 
 
 class RicadiOpts(C.Structure):
@@ -96,9 +99,14 @@ SIGNATURES = {
     "ricadi_setup_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.c_int]),
     "ricadi_time_qr_dev": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ricadi_time_gram_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _dp]),
+    "ricadi_set_recycle": (C.c_int, [_vp, C.c_int]),
+    "ricadi_set_exchange": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int64]),
+    "ricadi_host_deal": (C.c_int, [_dp, C.c_int, C.c_int, _ip]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
 }
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_int64)
 
 _lib = None
 
@@ -126,6 +134,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.ricadi_version() != ABI_VERSION:
+        raise RuntimeError("{0}: library ABI version {1}, optconpy_amd/_lib.py was written for {2} -- rebuild "
+                           "the library (__graft_entry__.build()) or update the mirror"
+                           .format(LIB_PATH, lib.ricadi_version(), ABI_VERSION))
     # struct handshake: the library reads every field of the structs it is handed, so a
     # mirror that is shorter than the library's struct makes it read past our buffer
     # (root cause of the round-1 abort: a rebuilt .so with a new ricadi_adi_params field
@@ -316,6 +328,49 @@ class Context:
             raise ValueError("U and V must have the same shape")
         _chk(self._lib.ricadi_set_lowrank(self._h, _d(U), _d(V), U.shape[1]))
 
+    def set_recycle(self, depth):
+        """Depth of the recycling ring for DIRECT solve calls (the ADI drivers use their own, 3)."""
+        _chk(self._lib.ricadi_set_recycle(self._h, int(depth)))
+
+    def set_exchange(self, group=None, panel_cols=MAX_M, per_rank=2):
+        """Shard the ADI sweeps of this context over the ranks of a ``torch.distributed`` process group
+        (SURVEY.md 8e): the library calls back for ONE all-gather per sweep
+        (``all_gather_into_tensor`` -- RCCL over xGMI with the nccl backend) on two device buffers
+        allocated here: ``per_rank`` solution panels of ``n x panel_cols`` per rank.  ``group=False``
+        removes the exchange."""
+        import torch
+        import torch.distributed as dist
+        if group is False or not (dist.is_available() and dist.is_initialized()):
+            _chk(self._lib.ricadi_set_exchange(self._h, 0, 1, None, None, None, None, 0))
+            self._xchg = None
+            return
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if world == 1:
+            _chk(self._lib.ricadi_set_exchange(self._h, 0, 1, None, None, None, None, 0))
+            self._xchg = None
+            return
+        count = max(512, int(per_rank) * self.n * int(panel_cols))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        send = torch.zeros(count, dtype=torch.float64, device=dev)
+        recv = torch.zeros(count * world, dtype=torch.float64, device=dev)
+
+        def gather(user, sptr, rptr, nbytes):
+            try:
+                k = int(nbytes) // 8
+                dist.all_gather_into_tensor(recv[:k * world], send[:k], group=group)
+                torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception as e:                        # never unwind through the C frames
+                import sys
+                print("ricadi exchange callback: {0!r}".format(e), file=sys.stderr, flush=True)
+                return 1
+
+        cb = EXCHANGE_FN(gather)
+        torch.cuda.synchronize()
+        _chk(self._lib.ricadi_set_exchange(self._h, rank, world, C.cast(cb, _vp), None, send.data_ptr(),
+                                           recv.data_ptr(), count * 8))
+        self._xchg = (cb, send, recv, group, count)          # keep the callback and the buffers alive
+
     # -- kernels ----------------------------------------------------------
     def _need_op(self):
         if not self.n:
@@ -376,7 +431,8 @@ class Context:
             Z = Z.ravel()[:self.nv * c].reshape(self.nv, c)
         info = dict(adi_steps=int(stats[0]), adi_rel_newZ=stats[1], gmres_iters=int(stats[2]),
                     shift_solves=int(stats[3]), res_fro=stats[4], cols=c,
-                    gmres_nonconverged=int(stats[5]), gmres_worst_relres=stats[6])
+                    gmres_nonconverged=int(stats[5]), gmres_worst_relres=stats[6],
+                    storage_escalations=int(stats[7]))
         _warn_nonconverged(info)
         return Z, info
 
@@ -409,7 +465,7 @@ class Context:
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
                     shift_solves=int(stats[5]), cols=c,
                     gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7],
-                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9])
+                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]))
         _warn_nonconverged(info)
         return Z, info
 
@@ -501,7 +557,8 @@ class Context:
         return ms.value
 
     TK = dict(spmm=0, block_v=1, block_p=2, coarse=3, spmm_sy=4, dots=5, update_dots=6, update=7,
-              precond=8, restrict=9)
+              precond=8, restrict=9, pc_restrict=10, pc_coarse=11, pc_sy_prows=12, pc_two_term=13,
+              pc_jprod=14, pc_schur=15, pc_rect=16)
 
     def time_kernel_dev(self, which, alphas, betas, m, nvec=7, reps=100):
         """Milliseconds per launch of one hot-path kernel class (``Context.TK``) as the
@@ -514,10 +571,11 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 11)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 11))
+        a = (C.c_int * 16)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 16))
         return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
-                         "dense_coarse", "fp16_vector_input"), list(a)))
+                         "dense_coarse", "fp16_vector_input", "rect_ks", "two_term_ks", "np_", "nnz_j",
+                         "nnz_sy"), list(a)))
 
     def time_qr_dev(self, z_ptr, c, reps):
         ms = C.c_double(0.0)
@@ -599,6 +657,14 @@ def host_aggregate(pattern, bsize):
     if nb < 0:
         _chk(nb)
     return blk, nb
+
+
+def host_deal(shifts, world):
+    """Owner rank of every shift of an ADI shift list (``ricadi_host_deal``)."""
+    sh = np.ascontiguousarray(shifts, dtype=np.float64)
+    owner = np.empty(sh.size, dtype=np.int32)
+    _chk(load().ricadi_host_deal(_d(sh), sh.size, int(world), _i(owner)))
+    return owner
 
 
 def host_cauchy(shifts):

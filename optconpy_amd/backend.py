@@ -80,3 +80,26 @@ def context_dims(nv):
         ctx.set_dims(nv)
         _ctx_key = ("dims", nv)
     return ctx
+
+
+def ensure_exchange(ctx, panel_cols, nshifts, group=None):
+    """Under ``torch.distributed`` (one process per GPU, world size > 1) the ADI sweeps of the
+    drop-in shard by shift over the ranks (``ricadi_set_exchange``): install / resize the
+    all-gather buffers of ``ctx`` for panels of ``panel_cols`` columns.  ``RICADI_SHIFT_PARALLEL=0``
+    keeps every rank on the whole shift list (replicas).  No-op in a single process."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
+        and os.environ.get("RICADI_SHIFT_PARALLEL", "1") != "0"
+    cur = getattr(ctx, "_xchg", None)
+    if not on:
+        if cur is not None:
+            ctx.set_exchange(False)
+        return
+    world = dist.get_world_size(group)
+    per_rank = min(16, -(-int(nshifts) // world) + 1)
+    need = per_rank * ctx.n * int(panel_cols)
+    if cur is None or cur[3] is not group or cur[4] < need:
+        ctx.set_exchange(group, panel_cols=int(panel_cols), per_rank=per_rank)

@@ -499,6 +499,119 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
 // Cauchy data of one shift-parallel ADI sweep:
 //   C_ij = -1/(p_i + p_j)  (s.p.d. for distinct negative real shifts),
 //   C = R^T R;  rinv = R^-1 (upper, row-major);  cinv1 = C^-1 * ones.
+// Owner rank of every shift of the list (see ricadi_host_deal in include/ricadi.h).
+int deal_shifts(const double* shifts, int ns, int world, int32_t* owner) {
+  double lmin = 1e300, lmax = -1e300;
+  for (int i = 0; i < ns; ++i) {
+    if (!(shifts[i] < 0.0)) return RICADI_EINVAL;
+    const double l = std::log(-shifts[i]);
+    lmin = std::min(lmin, l);
+    lmax = std::max(lmax, l);
+  }
+  // predicted GMRES iterations (relative): slowest at the smallest |p| (cfg2: ~110 at p = -1,
+  // ~30-45 over the upper half of a 1 ... 3e3 list)
+  std::vector<double> it(ns);
+  for (int i = 0; i < ns; ++i) {
+    const double t = lmax > lmin ? (std::log(-shifts[i]) - lmin) / (lmax - lmin) : 1.0;
+    it[i] = 1.0 + 2.5 * (1.0 - t) * (1.0 - t);
+  }
+  std::vector<int> order(ns);
+  for (int i = 0; i < ns; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return it[a] > it[b]; });
+  const double a = 3.2, b = 1.0;   // latency floor : per-group slope of a lockstep iteration
+  std::vector<double> mx(world, 0.0), sm(world, 0.0);
+  std::vector<int> cnt(world, 0);
+  const int cap = (ns + world - 1) / world + 1;   // keeps the per-rank batch (and the exchange slots) small
+  for (int k = 0; k < ns; ++k) {
+    const int i = order[k];
+    int best = -1;
+    double bt = 0.0;
+    for (int r = 0; r < world; ++r) {
+      if (cnt[r] >= cap) continue;
+      const double t = a * std::max(mx[r], it[i]) + b * (sm[r] + it[i]);
+      if (best < 0 || t < bt - 1e-12) {
+        best = r;
+        bt = t;
+      }
+    }
+    owner[i] = best;
+    mx[best] = std::max(mx[best], it[i]);
+    sm[best] += it[i];
+    ++cnt[best];
+  }
+  return RICADI_OK;
+}
+
+// Least squares through the normal equations with a rank-revealing (diagonally pivoted)
+// Cholesky factorisation:  Y = argmin || b - B Y ||_F  given  Ghh = B^T B (h x h) and
+// Ghb = B^T b (h x m), both row-major.  Columns of B whose pivot falls below rtol * the largest
+// diagonal entry are left out (their rows of Y are zero).  Returns the rank used.
+int gram_lstsq(int h, int m, const double* Ghh, const double* Ghb, double rtol, double* Y) {
+  std::vector<double> L((size_t)h * h, 0.0), d(h);
+  std::vector<int> piv(h);
+  double dmax = 0.0;
+  for (int i = 0; i < h; ++i) {
+    d[i] = Ghh[(size_t)i * h + i];
+    piv[i] = i;
+    dmax = std::max(dmax, d[i]);
+  }
+  for (size_t i = 0; i < (size_t)h * m; ++i) Y[i] = 0.0;
+  if (!(dmax > 0.0)) return 0;
+  int r = 0;
+  for (; r < h; ++r) {
+    int best = r;
+    for (int i = r + 1; i < h; ++i)
+      if (d[piv[i]] > d[piv[best]]) best = i;
+    if (!(d[piv[best]] > rtol * dmax)) break;
+    std::swap(piv[r], piv[best]);
+    const int pr = piv[r];
+    const double lrr = std::sqrt(d[pr]);
+    L[(size_t)pr * h + r] = lrr;
+    for (int i = r + 1; i < h; ++i) {
+      const int pi = piv[i];
+      double sum = Ghh[(size_t)pi * h + pr];
+      for (int k = 0; k < r; ++k) sum -= L[(size_t)pi * h + k] * L[(size_t)pr * h + k];
+      const double l = sum / lrr;
+      L[(size_t)pi * h + r] = l;
+      d[pi] -= l * l;
+    }
+  }
+  // L (rows piv[0..r), r columns) L^T Y_P = Ghb_P
+  std::vector<double> t((size_t)r);
+  for (int c = 0; c < m; ++c) {
+    for (int i = 0; i < r; ++i) {
+      double sum = Ghb[(size_t)piv[i] * m + c];
+      for (int k = 0; k < i; ++k) sum -= L[(size_t)piv[i] * h + k] * t[k];
+      t[i] = sum / L[(size_t)piv[i] * h + i];
+    }
+    for (int i = r - 1; i >= 0; --i) {
+      double sum = t[i];
+      for (int k = i + 1; k < r; ++k) sum -= L[(size_t)piv[k] * h + i] * t[k];
+      t[i] = sum / L[(size_t)piv[i] * h + i];
+    }
+    for (int i = 0; i < r; ++i) Y[(size_t)piv[i] * m + c] = t[i];
+  }
+  return r;
+}
+
+int gram_lstsq_scaled(int h, int m, std::vector<double>& Ghh, std::vector<double>& Ghb, double rtol,
+                      std::vector<double>& Y) {
+  std::vector<double> sc(h);
+  for (int i = 0; i < h; ++i) {
+    const double d = Ghh[(size_t)i * h + i];
+    sc[i] = d > 0.0 ? 1.0 / std::sqrt(d) : 0.0;
+  }
+  for (int i = 0; i < h; ++i) {
+    for (int j = 0; j < h; ++j) Ghh[(size_t)i * h + j] *= sc[i] * sc[j];
+    for (int j = 0; j < m; ++j) Ghb[(size_t)i * m + j] *= sc[i];
+  }
+  Y.assign((size_t)h * m, 0.0);
+  const int r = gram_lstsq(h, m, Ghh.data(), Ghb.data(), rtol, Y.data());
+  for (int i = 0; i < h; ++i)
+    for (int j = 0; j < m; ++j) Y[(size_t)i * m + j] *= sc[i];
+  return r;
+}
+
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1) {
   if (g < 1) return RICADI_EINVAL;
   std::vector<double> L((size_t)g * g, 0.0);  // lower Cholesky factor, C = L L^T
@@ -549,6 +662,14 @@ int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col, int 
     return RICADI_EINVAL;
   }
   return ricadi::aggregate(n, rowptr, col, bsize, blk_out);
+}
+
+int ricadi_host_deal(const double* shifts, int ns, int world, int32_t* owner_out) {
+  if (!shifts || !owner_out || ns < 1 || world < 1) {
+    ricadi::set_error("ricadi_host_deal: bad argument");
+    return RICADI_EINVAL;
+  }
+  return ricadi::deal_shifts(shifts, ns, world, owner_out);
 }
 
 int ricadi_host_cauchy(const double* shifts, int g, double* rinv_out, double* cinv1_out) {

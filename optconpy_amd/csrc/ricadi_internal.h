@@ -77,6 +77,11 @@ struct HostSetup {
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
                  HostSetup& hs, int max_levels = 2);
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
+int deal_shifts(const double* shifts, int ns, int world, int32_t* owner);
+int gram_lstsq(int h, int m, const double* Ghh, const double* Ghb, double rtol, double* Y);
+// the same on the column-normalised problem (unit diagonal), solution scaled back; Ghh / Ghb are overwritten
+int gram_lstsq_scaled(int h, int m, std::vector<double>& Ghh, std::vector<double>& Ghb, double rtol,
+                      std::vector<double>& Y);
 
 // ---- batches of panels ------------------------------------------------------------
 // A *batch* is a set of up to RICADI_MAX_GROUPS panels (one per ADI shift of a

@@ -2863,8 +2863,24 @@ __global__ __launch_bounds__(1024) void gj_diag_kernel(double* __restrict__ D, i
       const int i = i0 + ti, j = j0 + tj;
       a[ti][tj] = (i < nbe && j < nbe) ? d[(size_t)i * GJ_NB + j] : (i == j ? 1.0 : 0.0);
     }
-  bool bad = false;
-  for (int p = 0; p < nbe; ++p) {
+  // scale of the block: pivots are judged RELATIVE to the largest entry (a tiny but non-zero pivot would
+  // otherwise pass and leave a garbage inverse behind -- GMRES then stalls instead of the pivoted route running)
+  __shared__ double wmax[16];
+  double amax = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+      if (i0 + ti < nbe && j0 + tj < nbe) amax = fmax(amax, fabs(a[ti][tj]));
+  for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) amax = fmax(amax, wmax[w]);
+  const double ptol = 1e-12 * amax;
+  bool bad = !(amax > 0.0) || !(amax < 1e300);
+  for (int p = 0; p < nbe && !bad; ++p) {
     const int buf = p & 1;
     if ((p >> 2) == bi) {          // owners of the pivot row
 #pragma unroll
@@ -2884,7 +2900,7 @@ __global__ __launch_bounds__(1024) void gj_diag_kernel(double* __restrict__ D, i
     }
     __syncthreads();
     const double piv = rowb[buf][p];
-    if (!(fabs(piv) > 1e-300)) {   // uniform: every thread reads the same pivot
+    if (!(fabs(piv) > ptol)) {     // uniform: every thread reads the same pivot
       bad = true;
       break;
     }

@@ -195,6 +195,14 @@ struct ShiftData {
   DArr<double> smw_w;
   long smw_epoch = -1;
   ShiftData* sub = nullptr;   // the same shift on the child level (multilevel preconditioner)
+  // recycled solves (ricadi_set_recycle): y with S(alpha,beta) y = b for the right-hand side panels of
+  // the context's ring that carry the same serial number; n x w each
+  struct RecY {
+    long serial = -1;
+    int w = 0;
+    DArr<double> y;
+  };
+  std::vector<std::unique_ptr<RecY>> rec;
 };
 
 struct DevCsr {
@@ -319,8 +327,31 @@ struct ricadi_ctx {
   DevPool pool2;
   DArr<int> info2;
   hipEvent_t ev_z = nullptr;
+  // recycling of solved right-hand sides: ring of the last shared rhs panels (nv x w; pressure rows are zero)
+  struct RecB {
+    long serial = -1;
+    int w = 0;
+    DArr<double> b;
+  };
+  std::vector<std::unique_ptr<RecB>> rec_ring;
+  long rec_serial = 0;
+  int rec_depth = 0;          // depth in force for the next solves (the ADI drivers set it for their sweeps)
+  int rec_user_depth = 0;     // ricadi_set_recycle: depth for direct solve calls
+  // Sherman-Morrison-Woodbury: the low-rank factor U equals columns [lr_ucol, lr_ucol + q) of the right-hand
+  // side of the next shared-rhs solve (first sweep of a Newton step: rhs = [W, K_k], U = K_k), so the
+  // augmented columns [b, U] would be duplicates; -1 otherwise
+  int lr_ucol = -1;
+  // shift-parallel sweeps across processes (ricadi_set_exchange)
+  int xrank = 0, xworld = 1;
+  ricadi_allgather_fn xfn = nullptr;
+  void* xuser = nullptr;
+  double* xsend = nullptr;
+  double* xrecv = nullptr;
+  size_t xcap = 0;            // capacity of xsend in bytes
   // stats
   long total_iters = 0, total_solves = 0;
+  long escalations = 0;       // solves repeated with wider storage of basis / preconditioner (safety net)
+  int pc_stage = -1;          // >= 0: precond_apply issues only that stage (ricadi_time_kernel_dev)
   // wall-clock split of the drivers (RICADI_TIMING=1 prints it per Newton step; the stream is
   // drained at the section ends only in that mode)
   bool timing = false;
@@ -485,6 +516,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     sd->alpha = alphas[g];
     sd->beta = betas[g];
     sd->smw_epoch = -1;
+    sd->rec.clear();
     todo.push_back(sd);
   }
   if (todo.empty()) return;
@@ -840,17 +872,21 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   const double* rr = r;
   size_t gsrr = gsr;
   bool folded = false;
+  // ricadi_time_kernel_dev times one stage at a time through exactly these launchers (c->pc_stage >= 0)
+  auto on = [&](int stage) { return c->pc_stage < 0 || c->pc_stage == stage; };
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
     if (!folded || m > 16) r16 = nullptr;
-    if (r16)
+    if (!on(0)) {
+    } else if (r16)
       launch_spmm_h(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, nullptr, r16, m, gsr, c->rc.p, m, bt.gsc,
                     nullptr, 0, 0, 1.0, 0.0, m, 16);
     else
       launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
                     bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
-    if (c->child) {
+    if (!on(1)) {
+    } else if (c->child) {
       // coarse problem by one cycle of the child level's preconditioner (a fixed linear operator)
       Batch cb = *bt.sub;
       cb.tab = gt;
@@ -859,7 +895,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
-    if (folded) {
+    if (!on(2)) {
+    } else if (folded) {
       // only the PRESSURE rows of r - (S Y) ec are formed (short CSR product over np rows); the
       // velocity rows ride inside the first velocity sweep (block_apply2_kernel, below)
       if (r16)
@@ -914,7 +951,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_block_apply_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, in, m, gsi, z,
                            m, bt.gs, m, subtract, pa, cin);
   };
-  if (folded) {
+  if (!on(3)) {
+  } else if (folded) {
     // z_v = Ahat^-1 r_v - (Ahat^-1 D) ec : first velocity sweep on the corrected residual without
     // ever writing it
     Seg2 s1, s2;
@@ -938,8 +976,9 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   }
   if (np > 0) {
     // t = J z_v - r_p
-    launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
-                  rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
+    if (on(4))
+      launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
+                    rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
     static const bool fuse_jt = getenv("RICADI_NOFUSE_JT") == nullptr;
     static const bool rect = getenv("RICADI_NO_RECT") == nullptr;
@@ -961,7 +1000,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
         ppro.gse = bt.gsc;
       }
     }
-    if (c->precond32)
+    if (!on(5)) {
+    } else if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
                            bt.gsp, zp, m, bt.gs, m, 0, ppro);
     else
@@ -970,7 +1010,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // z_v -= Ahat^-1 (J^T z_p): the same block-Jacobi inverse as in the Schur blocks; the
     // J^T product is formed inside the sweep, row by row as the blocks gather them
     // (z_p is small and L2 resident), instead of through an intermediate panel
-    if (fuse_jt && rect && c->gt_ok) {
+    if (!on(6)) {
+    } else if (fuse_jt && rect && c->gt_ok) {
       // z_v -= G z_p with the per-shift blocks G_b = Ahat_b^-1 J^T[rows_b, pcols_b] formed at setup
       pro.nextra = 0;            // the pressure rows already carry their coarse part
       pro.out32 = z32;
@@ -999,7 +1040,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       vel_apply(tmp, bt.gs, 1, true);
     }
   }
-  if (z32 && !mirrored)
+  if (z32 && !mirrored && c->pc_stage < 0)
     for (int i = 0; i < gt.ng; ++i)
       launch_to_f32(st, c->n, m, z + (size_t)gt.gid[i] * bt.gs, m, z32 + (size_t)gt.gid[i] * gs32, m);
 }
@@ -1030,12 +1071,16 @@ static void col_norms2(ricadi_ctx* c, const double* w, int nrows, int m, double*
 struct GmresResult {
   int iters = 0;
   bool converged = false;
+  bool stalled = false;       // gave up before gmres_maxit: three full-length cycles in a row gained < 30 %
   double max_relres = 0.0;
 };
 
-static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
-                              size_t gsb, double* x, int m, bool lowrank, double* relres_host,
-                              GmresResult* res) {
+// have_x0: x holds an initial guess (else it is zeroed);  only: the groups to iterate on (NULL = all; the
+// panels of the other groups are not touched);  allow_stall: a group whose full-length restart cycles no
+// longer gain is given up early (the caller repeats it with wider storage).
+static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, size_t gsb, double* x,
+                       int m, bool lowrank, GmresResult* res, bool have_x0, const std::vector<int>* only,
+                       bool allow_stall) {
   ensure_work(c, m, G, 0);
   hipStream_t st = c->st;
   const int n = c->n, restart = c->opts.gmres_restart, maxit = c->opts.gmres_maxit;
@@ -1073,7 +1118,7 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   for (int j = 0; j < GM; ++j) bn[j] = std::sqrt(std::max(hb[slot + j], 0.0));
   // device copy of the norms (not squared) for the hess kernel
   HIPCHK(hipMemcpyAsync(c->bnorm2.p, bn.data(), sizeof(double) * GM, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * vs, st));
+  if (!have_x0) HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * vs, st));
 
   auto group_converged = [&](const double* r, int g) {
     double worst = 0.0;
@@ -1088,9 +1133,11 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   };
 
   std::vector<char> done(G, 0);
-  std::vector<int> act, live, kk(G, 0);
-  for (int g = 0; g < G; ++g) act.push_back(g);
-  bool first = true;
+  std::vector<int> act, live, kk(G, 0), nstall(G, 0);
+  if (only) act = *only;
+  else
+    for (int g = 0; g < G; ++g) act.push_back(g);
+  bool first = !have_x0;
   // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
   // iteration: three passes over it) small; a cycle that gains less than a factor 10
   // on some column lengthens the following ones, up to gmres_restart.
@@ -1126,10 +1173,18 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       } else if (res[g].iters >= maxit) {
         done[g] = 1;
       } else {
-        next.push_back(g);
+        bool flat = false;
         for (int j = g * m; j < (g + 1) * m; ++j) {
           if (rstart[j] > 0.0 && hb[j] > tol * bn[j] && hb[j] > 0.1 * rstart[j]) slow = true;
+          if (rstart[j] > 0.0 && hb[j] > tol * bn[j] && hb[j] > 0.7 * rstart[j]) flat = true;
           rstart[j] = hb[j];
+        }
+        nstall[g] = (flat && cyc >= restart) ? nstall[g] + 1 : 0;
+        if (allow_stall && nstall[g] >= 3) {
+          res[g].stalled = true;
+          done[g] = 1;
+        } else {
+          next.push_back(g);
         }
       }
     }
@@ -1235,17 +1290,202 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
       launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
     }
   }
+}
+
+// ---- recycled right-hand sides (ricadi_set_recycle) ---------------------------------------------
+// Initial guesses  x_g = sum_e Y_{g,e} C_e  from the stored pairs (B_e, Y_{g,e}),  S_g Y_{g,e} = B_e, with
+// C = argmin || b - [B_e] C ||_F  (normal equations on the matrix cores, rank-revealing Cholesky on the
+// host).  b: the right-hand side shared by the groups (n x m, pressure rows zero).  Returns false when no
+// stored panel is common to all groups (x is not touched then).
+static bool recycle_guess(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, int m, double* x) {
+  std::vector<const ricadi_ctx::RecB*> ent;
+  for (auto& e : c->rec_ring) {
+    if (!e || e->serial < 0) continue;
+    bool all = true;
+    for (int g = 0; g < G && all; ++g) {
+      bool has = false;
+      for (auto& y : sds[g]->rec)
+        if (y && y->serial == e->serial && y->w == e->w) has = true;
+      all = has;
+    }
+    if (all) ent.push_back(e.get());
+  }
+  if (ent.empty()) return false;
+  int h = 0;
+  for (auto* e : ent) h += e->w;
+  hipStream_t st = c->st;
+  const int nv = c->nv, n = c->n, hw = h + m;
+  TArr<double> Gd(c->pool, (size_t)h * hw), Yd(c->pool, (size_t)h * m);
+  HIPCHK(hipMemsetAsync(Gd.p, 0, sizeof(double) * h * hw, st));
+  int r0 = 0;
+  for (size_t i = 0; i < ent.size(); ++i) {
+    int c0 = r0;
+    for (size_t j = i; j < ent.size(); ++j) {
+      launch_gemm_tn(st, nv, ent[i]->w, ent[j]->w, ent[i]->b.p, ent[i]->w, ent[j]->b.p, ent[j]->w,
+                     Gd.p + (size_t)r0 * hw + c0, hw);
+      c0 += ent[j]->w;
+    }
+    launch_gemm_tn(st, nv, ent[i]->w, m, ent[i]->b.p, ent[i]->w, b, m, Gd.p + (size_t)r0 * hw + h, hw);
+    r0 += ent[i]->w;
+  }
+  std::vector<double> Gh((size_t)h * hw);
+  HIPCHK(hipMemcpyAsync(Gh.data(), Gd.p, sizeof(double) * Gh.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<double> Ghh((size_t)h * h), Ghb((size_t)h * m), Y;
+  for (int i = 0; i < h; ++i) {
+    for (int j = 0; j < h; ++j) Ghh[(size_t)i * h + j] = j >= i ? Gh[(size_t)i * hw + j] : Gh[(size_t)j * hw + i];
+    for (int j = 0; j < m; ++j) Ghb[(size_t)i * m + j] = Gh[(size_t)i * hw + h + j];
+  }
+  // the diagonal blocks come from a symmetric kernel, the off-diagonal ones were computed above the
+  // diagonal only: the mirror image is exact
+  const int rank = gram_lstsq_scaled(h, m, Ghh, Ghb, 1e-11, Y);
+  if (rank == 0) return false;
+  HIPCHK(hipMemcpyAsync(Yd.p, Y.data(), sizeof(double) * h * m, hipMemcpyHostToDevice, st));
+  GroupTab all{};
+  all.ng = G;
+  for (int g = 0; g < G; ++g) all.gid[g] = g;
+  r0 = 0;
+  for (size_t i = 0; i < ent.size(); ++i) {
+    GroupPtrs A = same_ptr((const double*)nullptr);
+    for (int g = 0; g < G; ++g)
+      for (auto& y : sds[g]->rec)
+        if (y && y->serial == ent[i]->serial && y->w == ent[i]->w) A.p[g] = y->y.p;
+    launch_gemm_nn_bp(st, all, n, ent[i]->w, m, A, ent[i]->w, Yd.p + (size_t)r0 * m, m, 0, x, m, (size_t)n * m,
+                      1.0, i == 0 ? 0.0 : 1.0);
+    r0 += ent[i]->w;
+  }
+  HIPCHK(hipStreamSynchronize(st));   // Y is a stack object
+  if (c->opts.verbose > 1) fprintf(stderr, "[ricadi] recycled guess from %d stored columns (rank %d)\n", h, rank);
+  return true;
+}
+
+static void recycle_store(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, int m, const double* x) {
+  hipStream_t st = c->st;
+  const int depth = c->rec_depth;
+  ricadi_ctx::RecB* slot = nullptr;
+  if ((int)c->rec_ring.size() < depth) {
+    c->rec_ring.emplace_back(new ricadi_ctx::RecB);
+    slot = c->rec_ring.back().get();
+  } else {
+    for (auto& e : c->rec_ring)
+      if (!slot || e->serial < slot->serial) slot = e.get();
+  }
+  slot->serial = ++c->rec_serial;
+  slot->w = m;
+  slot->b.ensure((size_t)c->nv * m);
+  HIPCHK(hipMemcpyAsync(slot->b.p, b, sizeof(double) * c->nv * m, hipMemcpyDeviceToDevice, st));
+  auto live = [&](long serial) {
+    for (auto& e : c->rec_ring)
+      if (e->serial == serial) return true;
+    return false;
+  };
+  const size_t nm = (size_t)c->n * m;
+  for (int g = 0; g < G; ++g) {
+    ShiftData::RecY* y = nullptr;
+    for (auto& r : sds[g]->rec)
+      if (!live(r->serial)) y = r.get();          // a solution whose right-hand side has left the ring
+    if (!y && (int)sds[g]->rec.size() < depth) {
+      sds[g]->rec.emplace_back(new ShiftData::RecY);
+      y = sds[g]->rec.back().get();
+    }
+    if (!y)
+      for (auto& r : sds[g]->rec)
+        if (!y || r->serial < y->serial) y = r.get();
+    y->serial = slot->serial;
+    y->w = m;
+    y->y.ensure(nm);
+    HIPCHK(hipMemcpyAsync(y->y.p, x + (size_t)g * nm, sizeof(double) * nm, hipMemcpyDeviceToDevice, st));
+  }
+}
+
+// Storage of the Krylov basis / the preconditioner inverses for the solves inside the scope:
+//   level 1: FP32-stored basis, FP64 inverses;  level 2: FP64-stored basis, FP64 inverses
+// (level 0 = the context's defaults: FP16 / FP32 basis by size, FP32 inverses).  All levels of a
+// multilevel preconditioner follow.  The arithmetic is FP64 at every level.
+struct StorageScope {
+  ricadi_ctx* c;
+  bool b16, b32;
+  std::vector<bool> p32;
+  StorageScope(ricadi_ctx* ctx, int level) : c(ctx), b16(ctx->basis16), b32(ctx->basis32) {
+    for (ricadi_ctx* l = c; l; l = l->child.get()) {
+      p32.push_back(l->precond32);
+      l->precond32 = false;
+    }
+    c->basis16 = false;
+    if (level >= 2) {
+      c->basis32 = false;
+      c->basis.ensure((size_t)(c->wrestart + 1) * c->n * c->wcols);
+    }
+  }
+  ~StorageScope() {
+    size_t i = 0;
+    for (ricadi_ctx* l = c; l; l = l->child.get()) l->precond32 = p32[i++];
+    c->basis16 = b16;
+    c->basis32 = b32;
+  }
+};
+static int storage_level(const ricadi_ctx* c) {
+  if (!c->precond32 && !c->basis32) return 2;
+  if (!c->precond32 && !c->basis16) return 1;
+  return 0;
+}
+
+// The batched solve as the drivers call it: recycled initial guess (shared right-hand side, plain
+// operator), the lockstep GMRES, the storage safety net -- a group that stops at gmres_maxit or
+// stagnates is continued from its iterate with the FP32- and then the FP64-stored basis and FP64
+// preconditioner inverses (counted in c->escalations) -- true residuals on request.
+static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
+                              size_t gsb, double* x, int m, bool lowrank, double* relres_host,
+                              GmresResult* res) {
+  static const bool no_net = getenv("RICADI_NO_ESCALATION") != nullptr;
+  hipStream_t st = c->st;
+  const bool plain = !(lowrank && c->q > 0);
+  const bool shared = (gsb == 0 || G == 1) && plain && c->rec_depth > 0;
+  const bool guess = shared && recycle_guess(c, sds, G, b, m, x);
+  const int lvl0 = storage_level(c);
+  gmres_core(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, !no_net && lvl0 < 2);
+  std::vector<int> bad;
+  for (int g = 0; g < G; ++g)
+    if (!res[g].converged) bad.push_back(g);
+  for (int level = lvl0 + 1; level <= 2 && !bad.empty() && !no_net; ++level) {
+    StorageScope wide(c, level);
+    std::vector<GmresResult> r2(G);
+    gmres_core(c, sds, G, b, gsb, x, m, lowrank, r2.data(), true, &bad, level < 2);
+    c->escalations += (long)bad.size();
+    std::vector<int> still;
+    for (int g : bad) {
+      if (c->opts.verbose)
+        fprintf(stderr, "[ricadi] shift (%g, %g): %s after %d iterations at relres %.2e -> storage level %d: %d more, %.2e\n",
+                sds[g]->alpha, sds[g]->beta, res[g].stalled ? "stagnation" : "gmres_maxit", res[g].iters,
+                res[g].max_relres, level, r2[g].iters, r2[g].max_relres);
+      res[g].iters += r2[g].iters;
+      res[g].converged = r2[g].converged;
+      res[g].stalled = r2[g].stalled;
+      res[g].max_relres = r2[g].max_relres;
+      if (!r2[g].converged) still.push_back(g);
+    }
+    bad.swap(still);
+  }
   if (relres_host) {
     // true residuals
-    bt.all();
+    Batch bt = make_batch(c, sds, G, m);
+    const size_t nm = bt.gs;
+    const size_t gspart = (size_t)dots_num_blocks(c->n) * (c->opts.gmres_restart + 2) * m;
+    const int GM = G * m;
+    double* hb = c->h_resid;
     op_apply(c, bt, x, nm, c->wv.p, lowrank);
     launch_axpby_b(st, bt.tab, nm, 1.0, b, gsb, -1.0, c->wv.p, nm);
-    norms2(c->wv.p, nm, c->nrm2.p);
+    launch_cols_dots_b(st, bt.tab, c->n, m, 0, (const double*)nullptr, 0, 0, c->wv.p, nm, 1, c->partial.p,
+                       gspart, c->nrm2.p, (size_t)m);
+    launch_cols_dots_b(st, bt.tab, c->n, m, 0, (const double*)nullptr, 0, 0, b, gsb, 1, c->partial.p,
+                       gspart, c->bnorm2.p, (size_t)m);
     HIPCHK(hipMemcpyAsync(hb, c->nrm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hb + GM, c->bnorm2.p, sizeof(double) * GM, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int j = 0; j < GM; ++j)
-      relres_host[j] = bn[j] > 0.0 ? std::sqrt(std::max(hb[j], 0.0)) / bn[j] : 0.0;
+      relres_host[j] = hb[GM + j] > 0.0 ? std::sqrt(std::max(hb[j], 0.0) / hb[GM + j]) : 0.0;
   }
+  if (shared) recycle_store(c, sds, G, b, m, x);
   for (int g = 0; g < G; ++g) c->total_iters += res[g].iters;
   c->total_solves += G;
 }
@@ -1334,25 +1574,41 @@ static void solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const doubl
   all.ng = G;
   for (int g = 0; g < G; ++g) all.gid[g] = g;
   bool bad = false;
+  // U = columns [ucol, ucol + q) of the (shared) right-hand side: S^-1 U is part of the plain solution,
+  // no augmented columns needed (first sweep of a Newton step without mtxoldb: rhs = [W, K_k], U = K_k)
+  const int ucol = c->lr_ucol;
+  c->lr_ucol = -1;             // the hint holds for one solve
+  const bool dup = need && (gsb == 0 || G == 1) && ucol >= 0 && ucol + q <= m;
   if (need) {
-    const int ma = m + q;
+    const int ma = dup ? m : m + q;
     const size_t nma = (size_t)n * ma;
-    c->smw_rhs.ensure(nma * G);
-    c->smw_x.ensure(nma * G);
-    double* ra = c->smw_rhs.p;
-    double* xa = c->smw_x.p;
-    for (int g = 0; g < G; ++g) {
-      launch_copy_cols(st, n, m, b + (size_t)g * gsb, m, 0, ra + g * nma, ma, 0, 1.0);
-      launch_copy_cols(st, nv, q, c->U.p, q, 0, ra + g * nma, ma, m, 1.0);
-      if (np > 0)
-        HIPCHK(hipMemset2DAsync(ra + g * nma + (size_t)nv * ma + m, sizeof(double) * ma, 0,
-                                sizeof(double) * q, np, st));
+    double* xa;
+    int xoff;     // column of S^-1 U inside the solution panels xa (leading dimension ma)
+    if (dup) {
+      gmres_solve_batch(c, sds, G, b, gsb, x, m, false, nullptr, res);
+      xa = x;
+      xoff = ucol;
+    } else {
+      // augmented panels [b_g, U]; one panel for all groups when they share b
+      const int nra = gsb == 0 ? 1 : G;
+      c->smw_rhs.ensure(nma * nra);
+      c->smw_x.ensure(nma * G);
+      double* ra = c->smw_rhs.p;
+      xa = c->smw_x.p;
+      xoff = m;
+      for (int g = 0; g < nra; ++g) {
+        launch_copy_cols(st, n, m, b + (size_t)g * gsb, m, 0, ra + g * nma, ma, 0, 1.0);
+        launch_copy_cols(st, nv, q, c->U.p, q, 0, ra + g * nma, ma, m, 1.0);
+        if (np > 0)
+          HIPCHK(hipMemset2DAsync(ra + g * nma + (size_t)nv * ma + m, sizeof(double) * ma, 0,
+                                  sizeof(double) * q, np, st));
+      }
+      gmres_solve_batch(c, sds, G, ra, gsb == 0 ? 0 : nma, xa, ma, false, nullptr, res);
     }
-    gmres_solve_batch(c, sds, G, ra, nma, xa, ma, false, nullptr, res);
     // capacitance matrices I - V^T (S^-1 U)
     c->smw_cap.ensure((size_t)G * q * q);
     HIPCHK(hipMemsetAsync(c->smw_cap.p, 0, sizeof(double) * G * q * q, st));
-    launch_gemm_tn_b(st, all, nv, q, q, c->V.p, q, xa + m, ma, nma, c->smw_cap.p, q, (size_t)q * q);
+    launch_gemm_tn_b(st, all, nv, q, q, c->V.p, q, xa + xoff, ma, nma, c->smw_cap.p, q, (size_t)q * q);
     std::vector<double> caps((size_t)G * q * q);
     HIPCHK(hipMemcpyAsync(caps.data(), c->smw_cap.p, sizeof(double) * caps.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1364,14 +1620,15 @@ static void solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const doubl
       if (!host_invert(cap, q) || !res[g].converged) bad = true;
       std::copy(cap.begin(), cap.end(), caps.begin() + (size_t)g * q * q);
     }
-    for (int g = 0; g < G; ++g)
-      launch_copy_cols(st, n, m, xa + g * nma, ma, 0, x + g * nm, m, 0, 1.0);
+    if (!dup)
+      for (int g = 0; g < G; ++g)
+        launch_copy_cols(st, n, m, xa + g * nma, ma, 0, x + g * nm, m, 0, 1.0);
     if (!bad) {
       HIPCHK(hipMemcpyAsync(c->smw_cap.p, caps.data(), sizeof(double) * caps.size(), hipMemcpyHostToDevice, st));
       for (int g = 0; g < G; ++g) {
         ShiftData* sd = sds[g];
         if (sd->smw_w.n != (size_t)n * q) sd->smw_w.alloc((size_t)n * q);
-        launch_gemm_nn(st, n, q, q, xa + g * nma + m, ma, c->smw_cap.p + (size_t)g * q * q, q,
+        launch_gemm_nn(st, n, q, q, xa + g * nma + xoff, ma, c->smw_cap.p + (size_t)g * q * q, q,
                        sd->smw_w.p, q, 1.0, 0.0);
         sd->smw_epoch = c->lr_epoch;
       }
@@ -1596,6 +1853,41 @@ struct AdiStats {
 // and the gain are the same).  The G solves go through ONE batched lockstep GMRES, which
 // is what fills the GPU at n ~ 3e4.  The stopping rule is applied per sweep (mean block
 // norm).  Returns false (nothing done) if the shift list does not allow sweeps.
+// All-gather of `count` doubles per rank through the host's collective (ricadi_set_exchange): the ranks'
+// first `count` doubles of c->xsend arrive rank-major in c->xrecv.  The context stream is drained first.
+static void exchange(ricadi_ctx* c, size_t count) {
+  if (count * sizeof(double) > c->xcap)
+    throw HipError{"exchange buffer too small: " + std::to_string(count * sizeof(double)) + " bytes per rank needed, " +
+                   std::to_string(c->xcap) + " given to ricadi_set_exchange"};
+  HIPCHK(hipStreamSynchronize(c->st));
+  const int rc = c->xfn(c->xuser, c->xsend, c->xrecv, (int64_t)(count * sizeof(double)));
+  if (rc != 0) throw HipError{"the all-gather callback of ricadi_set_exchange failed (" + std::to_string(rc) + ")"};
+}
+static bool sharded(const ricadi_ctx* c) { return c->xworld > 1 && c->xfn != nullptr; }
+// v[0..n) <- rank 0's values (decisions must not differ between the ranks: the norms they rest on come
+// from kernels with atomic accumulation).  One tiny all-gather.
+static void values_of_rank0(ricadi_ctx* c, double* v, int n) {
+  if (!sharded(c)) return;
+  HIPCHK(hipMemcpyAsync(c->xsend, v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+  exchange(c, (size_t)n);
+  HIPCHK(hipMemcpyAsync(v, c->xrecv, sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+}
+// v[0..n) <- sum over the ranks (statistics)
+static void sum_over_ranks(ricadi_ctx* c, double* v, int n) {
+  if (!sharded(c)) return;
+  HIPCHK(hipMemcpyAsync(c->xsend, v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+  exchange(c, (size_t)n);
+  std::vector<double> all((size_t)n * c->xworld);
+  HIPCHK(hipMemcpyAsync(all.data(), c->xrecv, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipStreamSynchronize(c->st));
+  for (int i = 0; i < n; ++i) {
+    double t = 0.0;
+    for (int r = 0; r < c->xworld; ++r) t += all[(size_t)r * n + i];
+    v[i] = t;
+  }
+}
+
 static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
                                 const ricadi_adi_params& prm, AdiStats& stt) {
   const int G = std::min(std::min(prm.sweep_width, ns), RICADI_MAX_GROUPS);
@@ -1618,6 +1910,13 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   hipStream_t st = c->st;
   const int n = c->n, nv = c->nv;
   const size_t nm = (size_t)n * m;
+  // Shift-parallel form (ricadi_set_exchange): every rank owns a fixed subset of the shift list --
+  // fixed, because the per-shift setup, the Sherman-Morrison-Woodbury panels and the recycled
+  // solutions live with the owner -- and solves only its shifts of a sweep; one all-gather per sweep.
+  const bool shard = sharded(c);
+  const int world = shard ? c->xworld : 1, rank = shard ? c->xrank : 0;
+  std::vector<int32_t> owner(ns, 0);
+  if (shard && deal_shifts(shifts, ns, world, owner.data()) != RICADI_OK) throw HipError{"bad shift list"};
   ensure_work(c, m, G);
   Tick tk;
   auto lap = [&](double& acc) {
@@ -1626,17 +1925,22 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
       acc += tk.lap();
     }
   };
-  prefetch_setup(c, shifts, std::min(ns, prm.adi_max_steps), prm.project_w != 0);
+  {
+    std::vector<double> mine;
+    const int nuse = std::min(ns, prm.adi_max_steps);
+    for (int i = 0; i < nuse; ++i)
+      if (owner[i] == rank) mine.push_back(shifts[i]);
+    prefetch_setup(c, mine.data(), (int)mine.size(), prm.project_w != 0);
+  }
   lap(c->t_setup);
   if (prm.project_w) project_panel(c, dW, m);
   lap(c->t_proj);
   const long it0 = c->total_iters;
-  c->sweep_u.ensure(nm * G);
+  if (!shard) c->sweep_u.ensure(nm * G);
   c->sweep_t.ensure((size_t)nv * m);
-  c->sweep_coef.ensure((size_t)(G + 1) * G * m);
   double znorm2 = 0.0;
   int zc_last = c->zc;
-  std::vector<double> be(G, 1.0), coef((size_t)(G + 1) * G * m);
+  std::vector<double> be(G, 1.0), coef;
   std::vector<ShiftData*> sds(G);
   std::vector<GmresResult> res(G);
   static const bool sync_recompress = getenv("RICADI_SYNC_RECOMPRESS") != nullptr;
@@ -1645,7 +1949,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   int steps = 0;
   // relative block norm of the last two visits of every position of the shift cycle
   std::vector<double> rel_h1(ns, 0.0), rel_h2(ns, 0.0);
-  std::vector<double> ps_var, rinv_var, cinv_var;
+  std::vector<double> ps_var, rinv_var, cinv_var, cinv_kept, rdummy, hn;
   for (int sw = 0;; ++sw) {
     // Width of this sweep.  With C = R^T R (R upper triangular) column block j of U R^-1 lies in
     // span{U_1..U_j}: it IS the block the step-by-step iteration appends at step j (up to its
@@ -1693,45 +1997,80 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     const std::vector<double>& rinv = *rinvp;
     const std::vector<double>& cinv1 = *cinvp;
     const int Gs = g_now;
-    get_shifts(c, ps.data(), be.data(), Gs, sds.data());
+    // who solves what, and where solution g sits in the buffer the recombination reads
+    std::vector<int> slot_of(Gs), mine;
+    int per_rank = Gs;
+    if (shard) {
+      std::vector<int> cnt(world, 0);
+      for (int g = 0; g < Gs; ++g) {
+        const int r = owner[(steps + g) % ns];
+        slot_of[g] = cnt[r]++;                       // index among its owner's items, completed below
+        if (r == rank) mine.push_back(g);
+      }
+      per_rank = *std::max_element(cnt.begin(), cnt.end());
+      for (int g = 0; g < Gs; ++g) slot_of[g] += owner[(steps + g) % ns] * per_rank;
+    } else {
+      for (int g = 0; g < Gs; ++g) {
+        slot_of[g] = g;
+        mine.push_back(g);
+      }
+    }
+    const int nslot = world * per_rank, nmine = (int)mine.size();
+    std::vector<double> psm(nmine);
+    for (int k = 0; k < nmine; ++k) psm[k] = ps[mine[k]];
+    if (nmine) get_shifts(c, psm.data(), be.data(), nmine, sds.data());
     lap(c->t_setup);
     load_rhs(c, dW, m, c->bvec.p);
-    solve_batch(c, sds.data(), Gs, c->bvec.p, 0, c->sweep_u.p, m, true, nullptr, res.data());
+    double* usolve = shard ? c->xsend : c->sweep_u.p;
+    if (shard) {
+      if ((size_t)per_rank * nm * sizeof(double) > c->xcap)
+        throw HipError{"exchange buffer too small: " + std::to_string((size_t)per_rank * nm * sizeof(double)) +
+                       " bytes per rank needed"};
+      // padding slots travel as zeros (their coefficients are zero, but 0 * NaN is not)
+      if (nmine < per_rank)
+        HIPCHK(hipMemsetAsync(c->xsend + (size_t)nmine * nm, 0, sizeof(double) * nm * (per_rank - nmine), st));
+    }
+    if (nmine) solve_batch(c, sds.data(), nmine, c->bvec.p, 0, usolve, m, true, nullptr, res.data());
+    c->lr_ucol = -1;            // only the first solve of a Newton step has U among its rhs columns
     lap(c->t_solve);
-    for (int g = 0; g < Gs; ++g)
-      if (!res[g].converged) {
+    for (int k = 0; k < nmine; ++k)
+      if (!res[k].converged) {
         stt.nonconverged++;
-        stt.worst_relres = std::max(stt.worst_relres, res[g].max_relres);
+        stt.worst_relres = std::max(stt.worst_relres, res[k].max_relres);
       }
-    stt.shift_solves += Gs;
-    // coefficient rows (replicated over the m columns): Gs columns of R^-1, then C^-1 1
-    for (int j = 0; j <= Gs; ++j)
-      for (int i = 0; i < Gs; ++i) {
-        const double v = j < Gs ? rinv[(size_t)i * Gs + j] : cinv1[i];
-        for (int cidx = 0; cidx < m; ++cidx) coef[((size_t)j * Gs + i) * m + cidx] = v;
-      }
-    HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * (size_t)(Gs + 1) * Gs * m,
+    stt.shift_solves += nmine;
+    const double* ubase = usolve;
+    if (shard) {
+      exchange(c, (size_t)per_rank * nm);
+      ubase = c->xrecv;
+    }
+    // coefficient rows (replicated over the m columns), in buffer order: Gs columns of R^-1, then C^-1 1
+    coef.assign((size_t)(Gs + 1) * nslot * m, 0.0);
+    auto fill_row = [&](int j, const double* col, int stride, int cnt) {   // row j <- col[i * stride], i < cnt
+      for (int i = 0; i < cnt; ++i)
+        for (int cidx = 0; cidx < m; ++cidx) coef[((size_t)j * nslot + slot_of[i]) * m + cidx] = col[(size_t)i * stride];
+    };
+    for (int j = 0; j < Gs; ++j) fill_row(j, rinv.data() + j, Gs, Gs);
+    c->sweep_coef.ensure(coef.size());
+    HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * (size_t)Gs * nslot * m,
                           hipMemcpyHostToDevice, st));
     // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
     for (int j = 0; j < Gs; ++j) {
-      launch_cols_update(st, nv, m, Gs, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)j * Gs * m, 1.0,
+      launch_cols_update(st, nv, m, nslot, ubase, nm, c->sweep_coef.p + (size_t)j * nslot * m, 1.0,
                          nullptr, nullptr, c->sweep_t.p);
       launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, c->Z.p, c->zld, c->zc + j * m, 1.0);
       col_norms2(c, c->sweep_t.p, nv, m, c->nrm2.p + (size_t)j * m);
     }
-    // W <- W + E (U C^-1 1)
-    launch_cols_update(st, nv, m, Gs, c->sweep_u.p, nm, c->sweep_coef.p + (size_t)Gs * Gs * m, 1.0,
-                       nullptr, nullptr, c->sweep_t.p);
-    launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0,
-                1.0, nullptr, m);
-    HIPCHK(hipMemcpyAsync(c->h_resid, c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
+    hn.resize((size_t)Gs * m);
+    HIPCHK(hipMemcpyAsync(hn.data(), c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    values_of_rank0(c, hn.data(), Gs * m);
     // the reference's rule, block by block; blocks behind the stopping step are dropped
     int kept = Gs;
     bool stop = false;
     for (int j = 0; j < Gs; ++j) {
       double b2 = 0.0;
-      for (int cc = 0; cc < m; ++cc) b2 += c->h_resid[(size_t)j * m + cc];
+      for (int cc = 0; cc < m; ++cc) b2 += hn[(size_t)j * m + cc];
       znorm2 += b2;
       const double relj = znorm2 > 0.0 ? std::sqrt(b2 / znorm2) : 0.0;
       const int pos = (steps + j) % ns;
@@ -1747,19 +2086,39 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     if (!narrow_tail) {
       // sweep granularity (RICADI_FULL_SWEEPS=1): mean block norm of the sweep
       double n2 = 0.0;
-      for (int j = 0; j < Gs * m; ++j) n2 += c->h_resid[j];
+      for (int j = 0; j < Gs * m; ++j) n2 += hn[j];
       stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / Gs / znorm2) : 0.0;
       stop = stt.rel < prm.adi_newZ_reltol;
     }
+    // W <- W + E (U C^-1 1) over the blocks that are KEPT: every U_g was solved against the same W, so
+    // the first `kept` solutions are the sweep of the first `kept` shifts, whose Cauchy data differ only
+    // in C^-1 1 (R^-1 of the leading block is the leading block of R^-1) -- W stays the residual factor
+    // of the truncated Z, and ||W^T W|| the residual norm that is reported
+    const double* cw = cinv1.data();
+    if (kept < Gs) {
+      cinv_kept.assign(kept, 0.0);
+      rdummy.assign((size_t)kept * kept, 0.0);
+      if (cauchy_data(ps.data(), kept, rdummy.data(), cinv_kept.data()) != RICADI_OK)
+        throw HipError{"Cauchy matrix of a truncated ADI sweep is numerically singular"};
+      cw = cinv_kept.data();
+    }
+    fill_row(Gs, cw, 1, kept);
+    HIPCHK(hipMemcpyAsync(c->sweep_coef.p + (size_t)Gs * nslot * m, coef.data() + (size_t)Gs * nslot * m,
+                          sizeof(double) * (size_t)nslot * m, hipMemcpyHostToDevice, st));
+    launch_cols_update(st, nv, m, nslot, ubase, nm, c->sweep_coef.p + (size_t)Gs * nslot * m, 1.0,
+                       nullptr, nullptr, c->sweep_t.p);
+    launch_spmm(st, nv, c->E.rp.p, c->E.ci.p, c->E.v.p, c->sweep_t.p, m, nullptr, dW, m, dW, m, 1.0,
+                1.0, nullptr, m);
+    HIPCHK(hipStreamSynchronize(st));     // `coef` is reused by the next sweep
     c->zc += kept * m;
     steps += kept;
     stt.steps = steps;
     lap(c->t_recomb);
     if (prm.verbose) {
       int its = 0;
-      for (int g = 0; g < Gs; ++g) its = std::max(its, res[g].iters);
-      fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d\n",
-              sw + 1, steps - Gs + 1, steps, stt.rel, its);
+      for (int k = 0; k < nmine; ++k) its = std::max(its, res[k].iters);
+      fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d%s\n",
+              sw + 1, steps - kept + 1, steps, stt.rel, its, shard ? " (this rank)" : "");
     }
     if (stop) break;
     if (steps >= prm.adi_max_steps) break;
@@ -1778,13 +2137,29 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   job.finish();
   lap(c->t_compress);
   stt.gmres_iters = c->total_iters - it0;
+  if (shard) {
+    // a rank has only seen its own solves
+    double v[3] = {(double)stt.gmres_iters, (double)stt.shift_solves, (double)stt.nonconverged};
+    sum_over_ranks(c, v, 3);
+    stt.gmres_iters = (long)(v[0] + 0.5);
+    stt.shift_solves = (long)(v[1] + 0.5);
+    stt.nonconverged = (long)(v[2] + 0.5);
+  }
   DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
   return true;
+}
+
+// Depth of the recycling ring inside the ADI drivers (RICADI_RECYCLE=d; 0 switches it off)
+static int adi_recycle_depth() {
+  const char* e = getenv("RICADI_RECYCLE");     // read per call: tests toggle it
+  return e ? std::max(0, std::min(8, atoi(e))) : 3;
 }
 
 static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
                              const ricadi_adi_params& prm) {
   AdiStats stt;
+  Restore<int> keep_rec(c->rec_depth);
+  c->rec_depth = std::max(c->rec_user_depth, adi_recycle_depth());
   if (prm.sweep_width > 1 && lyap_adi_sweeps_dev(c, shifts, ns, dW, m, prm, stt)) return stt;
   stt = AdiStats();
   hipStream_t st = c->st;
@@ -2123,7 +2498,7 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 210; }
+int ricadi_version(void) { return 300; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
@@ -2515,13 +2890,48 @@ int ricadi_clear_cache(ricadi_ctx* c) {
   API_BEGIN
   HIPCHK(hipStreamSynchronize(c->st));
   for (ricadi_ctx* l = c; l; l = l->child.get())
-    for (auto& kv : l->cache) kv.second->valid = false;   // buffers (and iteration graphs) stay
+    for (auto& kv : l->cache) {
+      kv.second->valid = false;   // buffers stay
+      for (auto& r : kv.second->rec) r->serial = -1;
+    }
+  for (auto& e : c->rec_ring) e->serial = -1;
   API_END
+}
+
+int ricadi_set_recycle(ricadi_ctx* c, int depth) {
+  REQUIRE(c && depth >= 0 && depth <= 8, RICADI_EINVAL, "recycling depth must be in [0, 8]");
+  c->rec_user_depth = c->rec_depth = depth;
+  return RICADI_OK;
+}
+
+int ricadi_set_exchange(ricadi_ctx* c, int rank, int world, ricadi_allgather_fn fn, void* user,
+                        void* send_dev, void* recv_dev, int64_t send_capacity) {
+  REQUIRE(c, RICADI_EINVAL, "NULL ctx");
+  if (world <= 1 || !fn) {
+    c->xrank = 0;
+    c->xworld = 1;
+    c->xfn = nullptr;
+    c->xuser = nullptr;
+    c->xsend = c->xrecv = nullptr;
+    c->xcap = 0;
+    return RICADI_OK;
+  }
+  REQUIRE(rank >= 0 && rank < world && world <= 64, RICADI_EINVAL, "bad rank / world size");
+  REQUIRE(send_dev && recv_dev && send_capacity >= 4096, RICADI_EINVAL, "exchange buffers missing or too small");
+  c->xrank = rank;
+  c->xworld = world;
+  c->xfn = fn;
+  c->xuser = user;
+  c->xsend = static_cast<double*>(send_dev);
+  c->xrecv = static_cast<double*>(recv_dev);
+  c->xcap = (size_t)send_capacity;
+  return RICADI_OK;
 }
 
 int ricadi_set_dims(ricadi_ctx* c, int nv) {
   REQUIRE(c && nv > 0, RICADI_EINVAL, "bad argument");
   c->cache.clear();
+  for (auto& e : c->rec_ring) e->serial = -1;
   c->has_op = false;
   c->nv = nv;
   c->np = 0;
@@ -2984,6 +3394,16 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, c->wv.p, m, nm, nullptr, c->rc.p, m,
                       bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
         break;
+      case 10: case 11: case 12: case 13: case 14: case 15: case 16: {
+        // ONE stage of the preconditioner application, through the launcher precond_apply itself uses
+        Restore<int> keep(c->pc_stage);
+        c->pc_stage = which - 10;
+        if (b16 && precond_reads_h16(c, m))
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, false, Vh);
+        else
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm);
+        break;
+      }
       default:
         throw HipError{"unknown kernel class"};
     }
@@ -3042,6 +3462,13 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   // [10]: 1 if the iteration reads the current vector from the FP16 basis (no FP64 copy written), 16-column panels
   if (nout > 10) out[10] = (c->has_op && (getenv("RICADI_BASIS64") == nullptr) && (getenv("RICADI_BASIS32") == nullptr) &&
                             c->n <= (1 << 21) && precond_reads_h16_static(c)) ? 1 : 0;
+  // [11], [12]: padded widths of the dense rectangles of the last / first velocity sweep (0: sweep not in that form);
+  // [13]: pressure dofs per Schur block list entry count (np), [14]: nnz(J), [15]: nnz of the pressure rows of S*Y
+  if (nout > 11) out[11] = c->gt_ok ? c->gt_ks : 0;
+  if (nout > 12) out[12] = (c->ady_ok && c->kc > 0) ? c->ady_ks : 0;
+  if (nout > 13) out[13] = c->np;
+  if (nout > 14) out[14] = (int)c->J.ci.n;
+  if (nout > 15) out[15] = c->kc > 0 && c->np > 0 ? (int)(c->synnz) : 0;
   return RICADI_OK;
 }
 
@@ -3098,6 +3525,7 @@ int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W
   REQUIRE(prm->adi_max_steps > 0, RICADI_EINVAL, "adi_max_steps must be positive");
   API_BEGIN
   ensure_work(c, m);
+  const long esc0 = c->escalations;
   factor_reserve(c, prm->adi_max_steps * m);
   DArr<double> dW;
   dW.alloc((size_t)c->nv * m);
@@ -3117,6 +3545,7 @@ int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W
     stats_out[4] = s.res_fro;
     stats_out[5] = (double)s.nonconverged;
     stats_out[6] = s.worst_relres;
+    stats_out[7] = (double)(c->escalations - esc0);
   }
   API_END
 }
@@ -3174,7 +3603,8 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
   p2.project_w = 0;
   if (p2.compress_cols <= 0) p2.compress_cols = 512;
   double upd = 0, updrel = 0;
-  long adi_total = 0, it0 = c->total_iters, sol0 = c->total_solves, nonconv = 0;
+  long adi_total = 0, gm_total = 0, sol_total = 0, nonconv = 0;
+  const long esc0 = c->escalations;
   double worst = 0.0, last_res = 0.0, last_rhs = 0.0;
   int steps = 0;
   for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
@@ -3205,9 +3635,14 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     if (m > mw) launch_copy_cols(st, nv, nb, dK.p, nb, 0, dRhs.p, m, mw, 1.0);
     factor_reserve(c, prm->adi_max_steps * m);
     DScalar::gram_norms(c, dRhs.p, nv, m, &last_rhs, nullptr);
+    // without mtxoldb the low-rank factor U = K_k is the last nb columns of the rhs itself
+    c->lr_ucol = (lr && !oldB && m > mw) ? mw : -1;
     AdiStats s = lyap_adi_dev(c, shifts, ns, dRhs.p, m, p2);
+    c->lr_ucol = -1;
     last_res = s.res_fro;
     adi_total += s.steps;
+    gm_total += s.gmres_iters;
+    sol_total += s.shift_solves;
     nonconv += s.nonconverged;
     worst = std::max(worst, s.worst_relres);
     // compressed copy of the new iterate (truncation at the Gram noise floor)
@@ -3221,6 +3656,12 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     double x1 = 0.0;
     upd = diff_zzt_fnorm(c, Znew.p, knew, Zk.p, kk, &x1);
     updrel = x1 > 0.0 ? upd / x1 : 0.0;
+    {
+      double dec[2] = {upd, updrel};       // the stopping decision is rank 0's
+      values_of_rank0(c, dec, 2);
+      upd = dec[0];
+      updrel = dec[1];
+    }
     if (c->timing) {
       c->t_updnorm += tkc.lap();
       fprintf(stderr, "[ricadi timing] Newton step %d: total %.1f ms = setup %.1f + projection %.1f + solves %.1f + "
@@ -3248,13 +3689,14 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     stats_out[1] = upd;
     stats_out[2] = updrel;
     stats_out[3] = (double)adi_total;
-    stats_out[4] = (double)(c->total_iters - it0);
-    stats_out[5] = (double)(c->total_solves - sol0);
+    stats_out[4] = (double)gm_total;
+    stats_out[5] = (double)sol_total;
     stats_out[6] = (double)nonconv;
     stats_out[7] = worst;
     stats_out[8] = last_res;
     stats_out[9] = last_rhs;
-    stats_out[10] = stats_out[11] = 0.0;
+    stats_out[10] = (double)(c->escalations - esc0);
+    stats_out[11] = 0.0;
   }
   API_END
 }

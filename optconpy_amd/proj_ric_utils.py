@@ -76,6 +76,7 @@ def solve_proj_lyap_stein(amat=None, mmat=None, jmat=None, wmat=None,
     try:
         if W.shape[1] > _lib.MAX_M:
             raise ValueError("right-hand side factor wider than {0} columns".format(_lib.MAX_M))
+        backend.ensure_exchange(ctx, W.shape[1], len(_shifts(d)))
         Z, info = ctx.lyap_adi(_shifts(d), W, prm)
         if d.get("check_lyap_res", False):
             # optcont_main.py:130 -- the residual of the equation just solved, evaluated
@@ -113,7 +114,9 @@ def proj_alg_ric_newtonadi(mmat=None, amat=None, jmat=None, bmat=None,
         # throughput of one shift-solve at a time on one GPU.  ``sweep_width=1`` in the
         # dict restores the step-by-step recurrence of the reference.
         prm.sweep_width = 16
-    Z, info = ctx.ric_newtonadi(_shifts(d), _dense(bmat), _dense(wmat), prm,
+    B, W = _dense(bmat), _dense(wmat)
+    backend.ensure_exchange(ctx, B.shape[1] + W.shape[1], len(_shifts(d)))
+    Z, info = ctx.ric_newtonadi(_shifts(d), B, W, prm,
                                 Z0=None if z0 is None else _dense(z0),
                                 oldB=None if mtxoldb is None else _dense(mtxoldb))
     out = dict(zfac=Z)

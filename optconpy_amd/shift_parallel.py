@@ -386,6 +386,18 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             dec = W.new_tensor([float(kept), 1.0 if stop else 0.0, rel])
             dist.broadcast(dec, src=0, group=group)
             kept, stop, rel = int(round(dec[0].item())), bool(dec[1].item() > 0.5), float(dec[2].item())
+        if kept < g_now:
+            # W was advanced with C^-1 1 of all g_now shifts; the factor keeps only the first `kept` blocks.
+            # Every U_g was solved against the same W, so the kept solutions ARE the sweep of the first
+            # `kept` shifts, whose Cauchy data differ only in C^-1 1: correct W by the difference, so that
+            # it stays the residual factor of the truncated Z (and `res_fro` / `resfac` its residual).
+            _, cinv_k = _lib.host_cauchy(ps[:kept])
+            for q in range(parts):
+                delta = np.zeros(nslot)
+                for it in items:
+                    if it["q"] == q:
+                        delta[it["pos"]] = (cinv_k[it["g"]] if it["g"] < kept else 0.0) - cinv1[it["g"]]
+                ops.apply_E(1.0, ops.lincomb(delta, U_all), Wq[q])
         znorm2 += float(bn2[:kept].sum())
         for j in range(kept):
             for q in range(parts):

@@ -155,3 +155,37 @@ def test_load_refuses_mismatched_struct(monkeypatch):
     monkeypatch.undo()
     _lib._lib = None
     _lib.load()
+
+
+def test_load_refuses_other_abi_version(monkeypatch):
+    """The stats arrays' lengths are part of the ABI but not of the struct handshake: a library of another
+    ricadi_version() must not get past load() either."""
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load()
+    monkeypatch.undo()
+    _lib._lib = None
+    _lib.load()
+
+
+def test_host_deal_shift_owners():
+    """Dealing of an ADI shift list to ranks (the shift-parallel sweeps): deterministic, every
+    rank used, per-rank batches bounded, and the slow (small |p|) shifts are not stacked on one rank."""
+    ms = -np.logspace(0.0, np.log10(3e3), 16)
+    assert (_lib.host_deal(ms, 1) == 0).all()
+    for world in (2, 4, 8, 16):
+        own = _lib.host_deal(ms, world)
+        assert (own == _lib.host_deal(ms, world)).all()
+        cnt = np.bincount(own, minlength=world)
+        assert cnt.min() >= 1 and cnt.max() <= -(-16 // world) + 1
+        # the `world` slowest shifts (smallest |p|) all have different owners
+        slow = np.argsort(-ms)[:world]
+        assert len(set(own[slow])) == world
+    # the order of the list does not matter for who shares a rank with whom
+    perm = np.random.default_rng(0).permutation(16)
+    a, b = _lib.host_deal(ms, 4), _lib.host_deal(ms[perm], 4)
+    groups = lambda o, idx: sorted(tuple(sorted(np.round(idx[o == r], 9))) for r in range(4))
+    assert groups(a, ms) == groups(b, ms[perm])
+    with pytest.raises(ValueError):
+        _lib.host_deal([1.0, -1.0], 2)           # positive shift

@@ -236,3 +236,27 @@ def test_two_ranks_gloo_column_split(tmp_path, width, col_parts):
     Zs = opru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=W, adi_dict=d)["zfac"]
     Ks = opru.get_mTzzTtb(pr.M.T, Zs, tb)
     assert np.linalg.norm(r0["K"] - Ks) <= 1e-6 * np.linalg.norm(Ks)
+
+
+def test_truncated_sweep_keeps_residual_factor_consistent():
+    """A sweep that stops before its last block (kept < G) must leave W = the residual factor of the
+    TRUNCATED Z: the reported residual then equals the factored residual of the returned factor
+    (W used to be advanced with the Cauchy data of all G solves)."""
+    pr, F, W, tb = _problem()
+    ms = pb.logshifts(1.0, 500.0, 8)
+    ops = OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+    W0 = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=W, transposedprj=True)
+    # a tolerance the iteration meets in the middle of one of its first two sweeps: no block-norm history
+    # yet, so the sweep is NOT cut at the predicted stopping step and blocks are really dropped
+    tol = None
+    for cand in (0.5, 0.3, 0.2, 0.1, 0.05, 0.02, 0.01):
+        blocks, info = lyap_adi_shift_parallel(OracleOps(F.T.tocsr(), pr.M.T.tocsr(), pr.J), ms,
+                                               torch.from_numpy(W0.copy()), adi_max_steps=40,
+                                               adi_newZ_reltol=cand, width=8)
+        if info["adi_steps"] % 8 != 0 and info["sweeps"] <= 2:
+            tol = cand
+            break
+    assert tol is not None, "no tolerance found that stops inside a sweep"
+    Zb = torch.cat(blocks, dim=1).numpy()
+    res2 = opru.comp_proj_lyap_res_norm(Zb, F, pr.M, W0, pr.J)
+    assert np.isclose(info["res_fro"], np.sqrt(res2), rtol=1e-6), (info["res_fro"], np.sqrt(res2))
