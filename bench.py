@@ -492,8 +492,8 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-        sys.stdout.write(r.stdout)
-        sys.stdout.flush()
+        for ln in r.stdout.splitlines():          # ONE JSON line on stdout; library chatter (gloo) goes to stderr
+            print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr, flush=True)
         sys.exit(r.returncode)
 
     import torch

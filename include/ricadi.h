@@ -358,8 +358,8 @@ int ricadi_time_gram_dev(ricadi_ctx* ctx, const double* dZ, int c, double* dG, i
  * afterwards.  The residual factors of consecutive ADI sweeps span nearly the same space
  * (cfg2: ||b - B C|| / ||b|| = 5e-2 ... 7e-4 per column from the fourth sweep on), which
  * saves that many digits of every later solve; the tolerance stays relative to ||b||.
- * The ADI / Newton drivers switch it on for their own sweeps (depth 3; RICADI_RECYCLE=d
- * overrides, 0 = off); this call sets the depth for direct ricadi_shift_solve*_dev calls
+ * The ADI / Newton drivers switch it on for their own sweeps (depth 5, 3 beyond n = 2e5;
+ * RICADI_RECYCLE=d overrides, 0 = off); this call sets the depth for direct ricadi_shift_solve*_dev calls
  * (default 0, so that repeated identical solves measure what they seem to measure).
  * ricadi_clear_cache() drops the stored panels.  No reference counterpart (SuperLU is direct). */
 int ricadi_set_recycle(ricadi_ctx* ctx, int depth);
@@ -376,8 +376,9 @@ int ricadi_set_recycle(ricadi_ctx* ctx, int depth);
  *   of send_dev at recv_dev + r * bytes_per_rank on EVERY rank and return 0 once the data are
  *   visible to work enqueued afterwards on any stream (the library has synchronised its own
  *   stream before the call).
- * send_dev holds send_capacity bytes, recv_dev world * send_capacity.  world = 1 (or fn NULL)
- * removes the exchange.  All ranks must make the same sequence of solver calls with the same
+ * send_dev holds send_capacity bytes, recv_dev world * send_capacity; the last 4096 bytes of send_dev
+ * (and the last world * 4096 of recv_dev) carry the small control messages, so fn is also called with
+ * pointers INSIDE the two buffers and must honour them.  world = 1 (or fn NULL) removes the exchange.  All ranks must make the same sequence of solver calls with the same
  * arguments.  SURVEY.md section 8e; the reference has nothing distributed
  * (/root/reference/solve_dae_ric.py:122 and optcont_main.py:577 are sequential loops).      */
 typedef int (*ricadi_allgather_fn)(void* user, const void* send_dev, void* recv_dev,

@@ -349,7 +349,7 @@ class Context:
             _chk(self._lib.ricadi_set_exchange(self._h, 0, 1, None, None, None, None, 0))
             self._xchg = None
             return
-        count = max(512, int(per_rank) * self.n * int(panel_cols))
+        count = int(per_rank) * self.n * int(panel_cols) + 512        # + 4096 bytes of control messages
         dev = torch.device("cuda", torch.cuda.current_device())
         send = torch.zeros(count, dtype=torch.float64, device=dev)
         recv = torch.zeros(count * world, dtype=torch.float64, device=dev)
@@ -357,7 +357,9 @@ class Context:
         def gather(user, sptr, rptr, nbytes):
             try:
                 k = int(nbytes) // 8
-                dist.all_gather_into_tensor(recv[:k * world], send[:k], group=group)
+                so = (int(sptr) - send.data_ptr()) // 8           # the library also calls with pointers INTO the
+                ro = (int(rptr) - recv.data_ptr()) // 8           # buffers (control messages in their tails)
+                dist.all_gather_into_tensor(recv[ro:ro + k * world], send[so:so + k], group=group)
                 torch.cuda.current_stream().synchronize()
                 return 0
             except Exception as e:                        # never unwind through the C frames

@@ -100,6 +100,6 @@ def ensure_exchange(ctx, panel_cols, nshifts, group=None):
         return
     world = dist.get_world_size(group)
     per_rank = min(16, -(-int(nshifts) // world) + 1)
-    need = per_rank * ctx.n * int(panel_cols)
+    need = per_rank * ctx.n * int(panel_cols) + 512
     if cur is None or cur[3] is not group or cur[4] < need:
         ctx.set_exchange(group, panel_cols=int(panel_cols), per_rank=per_rank)

@@ -1855,31 +1855,44 @@ struct AdiStats {
 // norm).  Returns false (nothing done) if the shift list does not allow sweeps.
 // All-gather of `count` doubles per rank through the host's collective (ricadi_set_exchange): the ranks'
 // first `count` doubles of c->xsend arrive rank-major in c->xrecv.  The context stream is drained first.
-static void exchange(ricadi_ctx* c, size_t count) {
-  if (count * sizeof(double) > c->xcap)
-    throw HipError{"exchange buffer too small: " + std::to_string(count * sizeof(double)) + " bytes per rank needed, " +
-                   std::to_string(c->xcap) + " given to ricadi_set_exchange"};
+// The last RICADI_XCTL bytes of the send buffer (and the last world * RICADI_XCTL of the receive buffer) are
+// kept for the small control messages (decisions, statistics), so that they never touch panels in flight.
+#define RICADI_XCTL 4096
+static size_t exchange_panel_capacity(const ricadi_ctx* c) { return c->xcap > RICADI_XCTL ? c->xcap - RICADI_XCTL : 0; }
+static void exchange_at(ricadi_ctx* c, double* send, double* recv, size_t count) {
   HIPCHK(hipStreamSynchronize(c->st));
-  const int rc = c->xfn(c->xuser, c->xsend, c->xrecv, (int64_t)(count * sizeof(double)));
+  const int rc = c->xfn(c->xuser, send, recv, (int64_t)(count * sizeof(double)));
   if (rc != 0) throw HipError{"the all-gather callback of ricadi_set_exchange failed (" + std::to_string(rc) + ")"};
+}
+static void exchange(ricadi_ctx* c, size_t count) {
+  if (count * sizeof(double) > exchange_panel_capacity(c))
+    throw HipError{"exchange buffer too small: " + std::to_string(count * sizeof(double) + RICADI_XCTL) +
+                   " bytes per rank needed, " + std::to_string(c->xcap) + " given to ricadi_set_exchange"};
+  exchange_at(c, c->xsend, c->xrecv, count);
+}
+static double* ctl_send(ricadi_ctx* c) { return c->xsend + exchange_panel_capacity(c) / sizeof(double); }
+static double* ctl_recv(ricadi_ctx* c) {
+  return c->xrecv + (size_t)c->xworld * exchange_panel_capacity(c) / sizeof(double);
 }
 static bool sharded(const ricadi_ctx* c) { return c->xworld > 1 && c->xfn != nullptr; }
 // v[0..n) <- rank 0's values (decisions must not differ between the ranks: the norms they rest on come
 // from kernels with atomic accumulation).  One tiny all-gather.
 static void values_of_rank0(ricadi_ctx* c, double* v, int n) {
   if (!sharded(c)) return;
-  HIPCHK(hipMemcpyAsync(c->xsend, v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
-  exchange(c, (size_t)n);
-  HIPCHK(hipMemcpyAsync(v, c->xrecv, sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
+  if ((size_t)n * sizeof(double) > RICADI_XCTL) throw HipError{"control message too long"};
+  HIPCHK(hipMemcpyAsync(ctl_send(c), v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+  exchange_at(c, ctl_send(c), ctl_recv(c), (size_t)n);
+  HIPCHK(hipMemcpyAsync(v, ctl_recv(c), sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
 }
 // v[0..n) <- sum over the ranks (statistics)
 static void sum_over_ranks(ricadi_ctx* c, double* v, int n) {
   if (!sharded(c)) return;
-  HIPCHK(hipMemcpyAsync(c->xsend, v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
-  exchange(c, (size_t)n);
+  if ((size_t)n * sizeof(double) > RICADI_XCTL) throw HipError{"control message too long"};
+  HIPCHK(hipMemcpyAsync(ctl_send(c), v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
+  exchange_at(c, ctl_send(c), ctl_recv(c), (size_t)n);
   std::vector<double> all((size_t)n * c->xworld);
-  HIPCHK(hipMemcpyAsync(all.data(), c->xrecv, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->st));
+  HIPCHK(hipMemcpyAsync(all.data(), ctl_recv(c), sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   for (int i = 0; i < n; ++i) {
     double t = 0.0;
@@ -2023,9 +2036,9 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     load_rhs(c, dW, m, c->bvec.p);
     double* usolve = shard ? c->xsend : c->sweep_u.p;
     if (shard) {
-      if ((size_t)per_rank * nm * sizeof(double) > c->xcap)
-        throw HipError{"exchange buffer too small: " + std::to_string((size_t)per_rank * nm * sizeof(double)) +
-                       " bytes per rank needed"};
+      if ((size_t)per_rank * nm * sizeof(double) > exchange_panel_capacity(c))
+        throw HipError{"exchange buffer too small: " + std::to_string((size_t)per_rank * nm * sizeof(double) + RICADI_XCTL) +
+                       " bytes per rank needed, " + std::to_string(c->xcap) + " given to ricadi_set_exchange"};
       // padding slots travel as zeros (their coefficients are zero, but 0 * NaN is not)
       if (nmine < per_rank)
         HIPCHK(hipMemsetAsync(c->xsend + (size_t)nmine * nm, 0, sizeof(double) * nm * (per_rank - nmine), st));
@@ -2064,7 +2077,8 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     hn.resize((size_t)Gs * m);
     HIPCHK(hipMemcpyAsync(hn.data(), c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    values_of_rank0(c, hn.data(), Gs * m);
+    for (int o = 0; o < Gs * m; o += RICADI_XCTL / 8)
+      values_of_rank0(c, hn.data() + o, std::min(RICADI_XCTL / 8, Gs * m - o));
     // the reference's rule, block by block; blocks behind the stopping step are dropped
     int kept = Gs;
     bool stop = false;
@@ -2114,9 +2128,16 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     steps += kept;
     stt.steps = steps;
     lap(c->t_recomb);
-    if (prm.verbose) {
+    static const bool dbg = getenv("RICADI_DEBUG_SWEEPS") != nullptr;
+    if (prm.verbose || dbg) {
       int its = 0;
       for (int k = 0; k < nmine; ++k) its = std::max(its, res[k].iters);
+      if (dbg) {
+        double wf = 0.0;
+        DScalar::gram_norms(c, dW, c->nv, m, &wf, nullptr);
+        fprintf(stderr, "[ricadi rank %d] sweep %d: Gs %d kept %d per_rank %d nmine %d  ||W^T W|| %.6e  znorm2 %.6e\n", rank, sw + 1,
+                Gs, kept, per_rank, nmine, wf, znorm2);
+      }
       fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d%s\n",
               sw + 1, steps - kept + 1, steps, stt.rel, its, shard ? " (this rank)" : "");
     }
@@ -2150,16 +2171,19 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
 }
 
 // Depth of the recycling ring inside the ADI drivers (RICADI_RECYCLE=d; 0 switches it off)
-static int adi_recycle_depth() {
+// (cfg2, same-call A/B: depth 0 / 2 / 3 / 5 / 8 -> 63.1 / 56.3 / 55.3 / 53.4 / 52.7 iterations per solve,
+// 436.7 / 405.9 / 405.9 / 401.9 / 409.8 ms per step.)  Every stored pair costs n x m doubles per shift:
+// 5 where that is small, 3 beyond n = 2e5 (cfg5: 128 shifts x 3 x 64 MB).
+static int adi_recycle_depth(const ricadi_ctx* c) {
   const char* e = getenv("RICADI_RECYCLE");     // read per call: tests toggle it
-  return e ? std::max(0, std::min(8, atoi(e))) : 3;
+  return e ? std::max(0, std::min(8, atoi(e))) : (c->n <= 200000 ? 5 : 3);
 }
 
 static AdiStats lyap_adi_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
                              const ricadi_adi_params& prm) {
   AdiStats stt;
   Restore<int> keep_rec(c->rec_depth);
-  c->rec_depth = std::max(c->rec_user_depth, adi_recycle_depth());
+  c->rec_depth = std::max(c->rec_user_depth, adi_recycle_depth(c));
   if (prm.sweep_width > 1 && lyap_adi_sweeps_dev(c, shifts, ns, dW, m, prm, stt)) return stt;
   stt = AdiStats();
   hipStream_t st = c->st;
