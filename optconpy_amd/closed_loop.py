@@ -4,8 +4,10 @@ Counterpart of what ``optcon_nse`` does after the Riccati solve
 (``/root/reference/optcont_main.py:529-536,609-626``: ``snu.solve_nse(closed_loop=True,
 feedbackthroughdict=..., tb_mat=...)``) and of ``eval_costfunc``
 (``optcont_main.py:213-264``).  ``snu`` (dolfin_navier_scipy) is not available,
-so the time stepper here is this repo's own implicit Euler scheme for the
-*linearised* flow (the reference's ``linearized_nse=True`` branch):
+so the time steppers here are this repo's own implicit Euler schemes: :func:`simulate_nse_flow` for the
+nonlinear flow (Picard / Newton steps per time step over the discrete convection linearisation
+:func:`problems.convection_from_vector`), and for the *linearised* flow (the reference's
+``linearized_nse=True`` branch):
 
     M (v_{k+1} - v_k)/tau + (A + N(t_{k+1})) v_{k+1} + J^T p = f + B~ u_{k+1},
     u = mtxtb(t)^T v + B~^T w(t)          (mtxtb = -M^T Z Z^T B~ is what the Riccati sweep stores)
@@ -25,7 +27,8 @@ from . import lin_alg_utils as _lau
 
 from . import proj_ric_utils as _pru
 
-__all__ = ["simulate_linearized_flow", "eval_costfunc", "steady_state_feedback"]
+__all__ = ["simulate_linearized_flow", "simulate_nse_flow", "get_tdpart_from_velocities", "eval_costfunc",
+           "steady_state_feedback"]
 
 
 def steady_state_feedback(mmat=None, amat=None, jmat=None, convc_mat=None, tb_mat=None,
@@ -96,6 +99,78 @@ def simulate_linearized_flow(mmat=None, amat=None, jmat=None, tb_mat=None, rhsv=
         v = x[:NV]
         vels[t1] = v.copy()
     return vels
+
+
+def get_tdpart_from_velocities(N, dictofvalues, store=None, ordering="component"):
+    """The ``get_tdpart`` of the time-dependent branch (``optcont_main.py:556-568``): the convection
+    linearisation about the velocity STORED for that time -- ``dictofvalues[time]`` is the array itself or
+    its name in ``store`` (the reference keeps file names, ``dou.load_npa(dictofvalues[time])``).
+    Returns ``get_tdpart(time=...) -> (convc_mat, rhs_con)`` as ``solve_flow_daeric`` and the flow
+    simulations consume it (``solve_dae_ric.py:131``)."""
+    from . import problems as pb
+
+    def get_tdpart(time=None, **kw):
+        cur = dictofvalues[time]
+        if isinstance(cur, str):
+            cur = store.load(cur)
+        convc_mat, rhs_con = pb.convection_from_vector(N, cur, ordering=ordering)
+        return convc_mat, rhs_con
+    return get_tdpart
+
+
+def simulate_nse_flow(mmat=None, amat=None, jmat=None, N=None, tb_mat=None, rhsv=None, iniv=None,
+                      tmesh=None, feedbackthroughdict=None, store=None, closed_loop=False,
+                      static_feedback=False, vel_pcrd_stps=1, vel_nwtn_stps=2, ordering="component",
+                      lau=None, return_info=False):
+    """Implicit Euler for the NONLINEAR Navier-Stokes flow, optionally in closed loop -- the
+    ``snu.solve_nse(closed_loop=True, feedbackthroughdict=..., vel_pcrd_stps=1, vel_nwtn_stps=2)`` of
+    ``optcont_main.py:609-626`` (and, without feedback, the forward solve of ``:548-550`` whose stored
+    velocities feed ``get_tdpart``):
+
+        M (v1 - v0)/tau + A v1 + H(v1) + J^T p = f + B~ u(t1),   J v1 = 0,
+        u = mtxtb(t1)^T v1 + B~^T w(t1)                          (closed loop)
+
+    Per time step ``vel_pcrd_stps`` Picard steps, ``H(v) ~ (vbar . grad) v``, then ``vel_nwtn_stps`` Newton
+    steps, ``H(v) ~ N(vbar) v - H(vbar)``, each one saddle-point solve through ``lau.solve_sadpnt_smw``
+    (the feedback as its low-rank term, the call of ``solve_dae_ric.py:192-194``), starting from the
+    previous time step.  The convection operators come from :func:`problems.convection_from_vector`
+    (the discrete ``snu.get_v_conv_conts``).  Returns ``{t: v(t)}`` (and, with ``return_info``, the
+    norm of the last Newton update of every step)."""
+    from . import problems as pb
+    lau = _lau if lau is None else lau
+    NV = mmat.shape[0]
+    tb = sps.csr_matrix(tb_mat) if tb_mat is not None else None
+    v = np.zeros((NV, 1)) if iniv is None else np.asarray(iniv, dtype=float).reshape(NV, 1)
+    rhsv = np.zeros((NV, 1)) if rhsv is None else np.asarray(rhsv, dtype=float).reshape(NV, 1)
+    vels = {tmesh[0]: v.copy()}
+    last_upd = {}
+    for k in range(len(tmesh) - 1):
+        t1 = tmesh[k + 1]
+        tau = t1 - tmesh[k]
+        base = (mmat @ v) / tau + rhsv
+        gain = w = None
+        if closed_loop and feedbackthroughdict is not None:
+            key = None if (static_feedback or t1 not in feedbackthroughdict) else t1
+            gain = store.load(feedbackthroughdict[key]["mtxtb"])          # NV x NU
+            w = store.load(feedbackthroughdict[key]["w"])
+            base = base + tb @ (tb.T @ w)
+        vbar = v.copy()
+        upd = 0.0
+        for it in range(int(vel_pcrd_stps) + int(vel_nwtn_stps)):
+            newton = it >= int(vel_pcrd_stps)
+            nmat, hv = pb.convection_from_vector(N, vbar, ordering=ordering, newton_term=newton)
+            op = sps.csr_matrix(mmat / tau + amat + nmat)
+            rhs = base + hv if newton else base
+            if gain is not None:
+                x = lau.solve_sadpnt_smw(amat=op, jmat=jmat, rhsv=rhs, umat=tb.toarray(), vmat=gain.T)
+            else:
+                x = lau.solve_sadpnt_smw(amat=op, jmat=jmat, rhsv=rhs)
+            upd = float(np.linalg.norm(x[:NV] - vbar))
+            vbar = x[:NV]
+        v = vbar
+        vels[t1] = v.copy()
+        last_upd[t1] = upd
+    return (vels, dict(last_update=last_upd)) if return_info else vels
 
 
 def eval_costfunc(V=None, W=None, cmat=None, ystar=None, tbmat=None, tmesh=None,

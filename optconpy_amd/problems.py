@@ -23,6 +23,7 @@ import scipy.sparse as sps
 
 __all__ = [
     "drivcav_sizes", "stokes_system", "convection_matrix", "vortex_field",
+    "convection_from_vector", "nodal_interpolant", "convection_term",
     "control_observation", "get_tint", "default_nwtn_adi_dict", "RicProblem",
     "ricc_problem", "logshifts",
 ]
@@ -214,15 +215,41 @@ def vortex_field(xy, amp=1.0):
     return v, gv
 
 
-def convection_matrix(N, field=vortex_field, amp=1.0, ordering="component",
-                      newton_term=True):
-    """Linearised convection ``N(v) u = (v.grad) u + (u.grad) v``.
+def _analytic_fields(mesh, field, amp):
+    """Per triangle family: the field and its gradient at the quadrature points, from a function."""
+    x, y, _ = _duffy_rule(5)
+    ref = np.stack([x, y], axis=0)                                # (2, q)
 
-    Stand-in for ``snu.get_v_conv_conts`` (``optcont_main.py:185-198,
-    456-462``); ``newton_term=False`` gives the Oseen (Picard) part only.
-    """
-    mesh = _Mesh(N)
-    NV, _ = drivcav_sizes(N)
+    def at(key):
+        pts = mesh.orig[key][:, None, :] + (mesh.B[key] @ ref).T[None, :, :]   # (ne, q, 2)
+        return field(pts, amp)                                    # (2,ne,q), (2,2,ne,q)
+    return at
+
+
+def _discrete_fields(mesh, vvec, ordering):
+    """The same for a DISCRETE velocity: the P2 finite element function of the condensed dof vector
+    ``vvec`` (boundary values zero: homogeneous Dirichlet dofs are condensed, ``optcont_main.py:332-334``)
+    and its gradient, interpolated element by element at the quadrature points."""
+    x, y, _ = _duffy_rule(5)
+    phi, dphi = _p2_ref(x, y)
+    vvec = np.asarray(vvec, dtype=float).ravel()
+    vpad = np.concatenate([vvec, [0.0]])                          # index -1 -> boundary value 0
+
+    def at(key):
+        Binv = np.linalg.inv(mesh.B[key])
+        g = np.einsum("dk,ikq->idq", Binv.T, dphi)                # (6, 2, q) physical gradients
+        p2 = mesh.p2[key]
+        v, gv = [], []
+        for c in range(2):
+            loc = vpad[_vel_index(mesh, c, p2, ordering)]         # (ne, 6) nodal values of component c
+            v.append(loc @ phi)                                   # (ne, q)
+            gv.append(np.einsum("ej,jdq->deq", loc, g))           # (2, ne, q): d v_c / d x_d
+        return np.stack(v), np.stack(gv)
+    return at
+
+
+def _assemble_convection(mesh, fields, ordering, newton_term):
+    NV, _ = drivcav_sizes(mesh.N)
     x, y, wt = _duffy_rule(5)
     phi, dphi = _p2_ref(x, y)
     rows, cols, vals = [], [], []
@@ -231,9 +258,7 @@ def convection_matrix(N, field=vortex_field, amp=1.0, ordering="component",
         det = abs(np.linalg.det(B))
         Binv = np.linalg.inv(B)
         g = np.einsum("dk,ikq->idq", Binv.T, dphi)                # (6, 2, q)
-        ref = np.stack([x, y], axis=0)                            # (2, q)
-        pts = mesh.orig[key][:, None, :] + (B @ ref).T[None, :, :]  # (ne, q, 2)
-        v, gv = field(pts, amp)                                   # (2,ne,q), (2,2,ne,q)
+        v, gv = fields(key)                                       # (2,ne,q), (2,2,ne,q)
         # (v . grad phi_j) phi_i
         vgrad = np.einsum("ceq,jcq->ejq", v, g)                   # (ne, 6, q)
         adv = np.einsum("ejq,iq,q->eij", vgrad, phi, wt) * det    # (ne, 6, 6)
@@ -255,6 +280,63 @@ def convection_matrix(N, field=vortex_field, amp=1.0, ordering="component",
                 vals.append(loc.ravel())
     return _coo_to_csr(np.concatenate(rows), np.concatenate(cols),
                        np.concatenate(vals), (NV, NV))
+
+
+def convection_matrix(N, field=vortex_field, amp=1.0, ordering="component",
+                      newton_term=True):
+    """Linearised convection ``N(v) u = (v.grad) u + (u.grad) v`` about an ANALYTIC field.
+
+    Stand-in for ``snu.get_v_conv_conts`` (``optcont_main.py:185-198,
+    456-462``); ``newton_term=False`` gives the Oseen (Picard) part only.
+    """
+    mesh = _Mesh(N)
+    return _assemble_convection(mesh, _analytic_fields(mesh, field, amp), ordering, newton_term)
+
+
+def convection_term(N, vvec, ordering="component"):
+    """The nonlinear term itself, tested: ``H(v)_i = int ((v.grad) v) . phi_i`` for the discrete
+    velocity ``vvec`` (NV x 1).  ``snu.get_v_conv_conts`` returns it as ``rhs_con``
+    (``optcont_main.py:194-198``): Newton's linearisation ``(u.grad)u ~ N(v) u - H(v)``."""
+    mesh = _Mesh(N)
+    NV, _ = drivcav_sizes(N)
+    x, y, wt = _duffy_rule(5)
+    phi, _ = _p2_ref(x, y)
+    fields = _discrete_fields(mesh, vvec, ordering)
+    out = np.zeros(NV + 1)
+    for key in ("lo", "up"):
+        det = abs(np.linalg.det(mesh.B[key]))
+        v, gv = fields(key)
+        for c in range(2):
+            adv = v[0] * gv[c, 0] + v[1] * gv[c, 1]                # (ne, q): (v . grad) v_c
+            loc = np.einsum("eq,iq,q->ei", adv, phi, wt) * det     # (ne, 6)
+            np.add.at(out, _vel_index(mesh, c, mesh.p2[key], ordering).ravel(), loc.ravel())
+    return out[:NV].reshape(-1, 1)
+
+
+def convection_from_vector(N, vvec, ordering="component", newton_term=True):
+    """Convection linearisation about a DISCRETE velocity -- ``snu.get_v_conv_conts(prev_v=...)`` as
+    ``get_convmats_rhs`` / ``get_tdpart`` call it with a stored velocity per time step
+    (``optcont_main.py:185-198,556-568``).  Returns ``(convc_mat, rhs_con)``:
+
+        convc_mat = N(v):  u -> (v.grad) u + (u.grad) v     (NV x NV, same element loops and quadrature as
+                                                             :func:`convection_matrix`)
+        rhs_con   = H(v) = N(v) v / 2                        (the constant of Newton's linearisation)
+
+    The Dirichlet part ``rhsv_conbc`` of the reference vanishes: the boundary values are zero."""
+    mesh = _Mesh(N)
+    mat = _assemble_convection(mesh, _discrete_fields(mesh, vvec, ordering), ordering, newton_term)
+    return mat, convection_term(N, vvec, ordering)
+
+
+def nodal_interpolant(N, field=vortex_field, amp=1.0, ordering="component"):
+    """Condensed dof vector (NV x 1) of the P2 nodal interpolant of an analytic field."""
+    mesh = _Mesh(N)
+    NV, _ = drivcav_sizes(N)
+    v, _ = field(mesh.fine_xy[mesh.inner_nodes], amp)              # (2, n_inner)
+    out = np.zeros(NV)
+    for c in range(2):
+        out[_vel_index(mesh, c, mesh.inner_nodes, ordering)] = v[c]
+    return out.reshape(-1, 1)
 
 
 def _hat_family(t, n):

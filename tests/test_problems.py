@@ -42,3 +42,35 @@ def test_time_mesh_matches_reference_formula():
     t = pb.get_tint(0.0, 2.0, 8, True)     # optcont_main.py:141-150
     assert t[0] == 0.0 and abs(t[-1] - 2.0) < 1e-15 and np.all(np.diff(t) > 0)
     assert abs(t[4] - 1.0) < 1e-15
+
+
+def test_convection_about_a_discrete_velocity():
+    """snu.get_v_conv_conts(prev_v=...) (optcont_main.py:185-198,556-568): the linearisation about a dof
+    vector -- third-order agreement with the analytic-field assembly for the nodal interpolant of the
+    vortex, N(v) v = 2 H(v), and N(v) is exactly the derivative of the tested nonlinear term H."""
+    import scipy.sparse.linalg as sla
+    errs = []
+    for N in (6, 12):
+        v = pb.nodal_interpolant(N)
+        Na = pb.convection_matrix(N)
+        Nd, H = pb.convection_from_vector(N, v)
+        assert Nd.shape == Na.shape and H.shape == (Na.shape[0], 1)
+        errs.append(sla.norm(Nd - Na) / sla.norm(Na))
+        assert np.linalg.norm(Nd @ v - 2.0 * H) <= 1e-12 * np.linalg.norm(H)
+    assert errs[1] < errs[0] / 5.0 and errs[1] < 5e-3          # O(h^3)
+    N = 5
+    rng = np.random.default_rng(0)
+    NV = pb.drivcav_sizes(N)[0]
+    v, u = rng.standard_normal((NV, 1)), rng.standard_normal((NV, 1))
+    Nd, H = pb.convection_from_vector(N, v)
+    e = 1e-3                    # H is quadratic: the central difference is exact up to rounding
+    fd = (pb.convection_term(N, v + e * u) - pb.convection_term(N, v - e * u)) / (2 * e)
+    assert np.linalg.norm(fd - Nd @ u) <= 1e-9 * np.linalg.norm(Nd @ u)
+    # Oseen part only: (v.grad) u, and H(v) = N_oseen(v) v
+    No, _ = pb.convection_from_vector(N, v, newton_term=False)
+    assert np.linalg.norm(No @ v - H) <= 1e-12 * np.linalg.norm(H)
+    # the dof ordering is a permutation
+    vi = pb.nodal_interpolant(N, ordering="interleaved")
+    Ni, Hi = pb.convection_from_vector(N, vi, ordering="interleaved")
+    Nc, Hc = pb.convection_from_vector(N, pb.nodal_interpolant(N))
+    assert np.isclose(abs(Ni).sum(), abs(Nc).sum()) and np.isclose(np.linalg.norm(Hi), np.linalg.norm(Hc))
