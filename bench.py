@@ -443,6 +443,92 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
     return res
 
 
+def dre_workload(args, rank):
+    """`--workload cfg4-dre`: BASELINE cfg4 as what it is -- the time-varying differential Riccati loop at
+    n ~ 1e5 (solve_dae_ric.py:121-211 through optconpy_amd.dae_ric.solve_flow_daeric, the boundary calls
+    of every backward time step: Newton-ADI with z0 / w_mat = [M^T Z_c, sqrt(tau) C~^T] (m <= comprz_maxc +
+    NY' + NU = 66), compression to comprz_maxc = 50, gain, feed-forward saddle solve), on the sine-squeezed
+    time mesh get_tint(0, 1, Nts) (optcont_main.py:141-150) with a NEW operator per step
+    (-(M^T/2 + tau_k (A + N(t_k))^T), N(t) = (1 + 0.5 sin(2 pi t)) N(vortex)).  One step = one whole
+    backward sweep; per time step wall-clock, Newton / ADI steps and shift-solves are reported."""
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    from optconpy_amd import backend, problems as pb
+    from optconpy_amd.dae_ric import MemoryStore, solve_flow_daeric
+    xopts = _xopts()
+    if xopts:
+        backend.configure(**xopts)
+    N = args.N if args.N != 58 else 106
+    nu, Nts, ns = 0.15 / 60.0, args.nts, (args.shifts if args.shifts != 16 else 64)
+    pr = pb.ricc_problem(N, nu, NU=4, NY=4, alphau=1e-2)
+    mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+    tmesh = pb.get_tint(0.0, 1.0, Nts, True)
+    nad = dict(pb.default_nwtn_adi_dict(), ms=pb.logshifts(0.5, 2e3, ns))
+    NY2 = mct.shape[1]
+
+    def ystar(t):
+        return (0.1 * np.sin(5 * np.pi * t) * np.arange(1, NY2 + 1)).reshape(-1, 1)
+
+    def tdpart(time=None, **kw):
+        return (1.0 + 0.5 * np.sin(2 * np.pi * time)) * pr.Nc, np.zeros((pr.NV, 1))
+
+    rec = []
+
+    class Timed:
+        def __getattr__(self, name):
+            f = getattr(pru, name)
+            if name != "proj_alg_ric_newtonadi":
+                return f
+
+            def g(*a, **k):
+                t0 = time.perf_counter()
+                o = f(*a, **k)
+                rec.append(dict(seconds=round(time.perf_counter() - t0, 3), newton_steps=o["nwtn_steps"],
+                                adi_steps=o["adi_steps"], shift_solves=o["shift_solves"],
+                                gmres_iters=o["gmres_iters"], rhs_cols=int(k["wmat"].shape[1] + k["bmat"].shape[1]),
+                                nonconverged=o["gmres_nonconverged"], escalations=o.get("storage_escalations", 0)))
+                return o
+            return g
+
+    sweep = [0]
+
+    def one():
+        sweep[0] += 1
+        kw = dict(mmat=pr.M, amat=pr.A, jmat=pr.J, bmat=pr.b_mat, mcmat=mct.T, v_is_my=True, rmat=pr.rmat,
+                  vmat=pr.y_masmat, rhsv=np.zeros((pr.NV, 1)), gamma=1e-1, tmesh=tmesh, ystarvec=ystar,
+                  nwtn_adi_dict=nad, comprz_thresh=5e-5, comprz_maxc=50, get_tdpart=tdpart,
+                  get_datastr=lambda time=None, **k: "dre%d_t%.6f" % (sweep[0], time), gtdtstrargs={})
+        del rec[:]
+        store = MemoryStore()
+        t0 = time.perf_counter()
+        fb = solve_flow_daeric(store=store, **kw)
+        el = time.perf_counter() - t0
+        K0 = store.load(fb[tmesh[0]]["mtxtb"])
+        return el, list(rec), float(np.linalg.norm(K0))
+
+    for _ in range(args.warmup):
+        one()
+    tot, steps_rec, k0 = 0.0, None, None
+    for _ in range(args.steps):
+        el, steps_rec, k0 = one()
+        tot += el
+    units = sum(r["shift_solves"] for r in steps_rec)
+    info = backend.context().setup_info()
+    return {
+        "metric": "ADI shift-solves/sec (wall-clock of the backward DRE sweep in ms_per_step)",
+        "value": round(units * args.steps / tot, 3), "unit": "shift-solves/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tot / args.steps, 1),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "cfg4-dre: driven-cavity pattern N=%d (n=%d), nu=%g, differential Riccati sweep over "
+                        "get_tint(0,1,%d) (sine-squeezed), %d ADI shifts, comprz_maxc=50, time-varying "
+                        "convection; through solve_flow_daeric -> pru.proj_alg_ric_newtonadi / compress_Zsvd / "
+                        "get_mTzzTtb / lau.solve_sadpnt_smw" % (N, pr.NV + pr.NP, nu, Nts, ns),
+            "time_steps": steps_rec, "seconds_in_newton_adi": round(sum(r["seconds"] for r in steps_rec), 2),
+            "shift_solves_per_sweep": units, "gain_norm_at_t0": k0,
+            "preconditioner_levels": info["levels"], "dense_coarse_dim": info["dense_coarse"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,7 +548,8 @@ def main():
                     help="N>1: column parts per shift (0 = automatic: 2 when the ranks would otherwise "
                          "hold fewer than 4 groups)")
     ap.add_argument("--streams", type=int, default=1, help="Python driver only: concurrent batches per rank")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2"] + sorted(WORKLOADS),
+    ap.add_argument("--nts", type=int, default=8, help="cfg4-dre: time steps of the backward sweep")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4-dre"] + sorted(WORKLOADS),
                     help="cfg2 (default): the metric's configuration, one Newton step to K.  cfg3 / cfg4 / cfg5: "
                          "the larger BASELINE.json configurations as fixed-work shift cycles (see WORKLOADS)")
     ap.add_argument("--also-baseline-config", action="store_true",
@@ -528,6 +615,14 @@ def main():
         torch.cuda.synchronize()
         cx.synchronize()
 
+    if args.workload == "cfg4-dre":
+        line = dre_workload(args, rank)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        backend.reset()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.workload != "cfg2":
         res = cycle_workload(args.workload, world, rank, local, args.steps, args.warmup, args.col_split, bar)
         if rank == 0:

@@ -61,9 +61,27 @@ def context():
     return _ctx
 
 
+_mass_hint = None
+
+
+def mass_hint(nv):
+    """The last mass-like ``cal E`` (more than two entries per row) an operator was set with, if it has
+    ``nv`` rows.  ``lau.solve_sadpnt_smw`` receives ONE matrix (``M^T + tau (A+N)^T``,
+    ``solve_dae_ric.py:173,192-194``); with the mass matrix of the Riccati solve of the same time step as
+    ``cal E`` -- at coefficient alpha = 0, so it does not enter the operator -- the preconditioner's
+    aggregates follow the mass matrix's graph (velocity components kept apart) instead of the union
+    pattern: N = 58: 92 instead of 215-285 GMRES iterations, and the three-level hierarchy of n ~ 1e5
+    works at all (it stagnates on mixed-component aggregates)."""
+    if _mass_hint is not None and _mass_hint.shape[0] == nv:
+        return _mass_hint
+    return None
+
+
 def context_for(calA, calE, J):
     """Context with the operator ``[[beta*calA + alpha*calE, J^T],[J,0]]`` set."""
-    global _ctx_key
+    global _ctx_key, _mass_hint
+    if calE is not None and sps.issparse(calE) and calE.nnz > 2 * calE.shape[0]:
+        _mass_hint = calE
     key = (_fingerprint(calA), _fingerprint(calE), _fingerprint(J))
     ctx = context()
     if key != _ctx_key:

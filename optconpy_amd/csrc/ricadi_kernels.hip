@@ -3486,4 +3486,5 @@ void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a
 
 // identity matrix (for getrs against I)
 
+
 }  // namespace ricadi

@@ -58,7 +58,17 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, umat=None,
         jmat = sps.csr_matrix(jmatT).T
     amat = sps.csr_matrix(amat)
     nv = amat.shape[0]
-    ctx = backend.context_for(amat, sps.csr_matrix((nv, nv)), jmat)
+    # cal E enters with coefficient alpha = 0: it only lends its graph to the preconditioner's aggregation
+    # (backend.mass_hint); without a remembered mass matrix the operator's own pattern serves
+    hint = backend.mass_hint(nv)
+    if hint is not None:
+        # the hint must belong to this problem: its pattern lies inside the operator's (sampled rows)
+        h = sps.csr_matrix(hint)
+        for r in np.linspace(0, nv - 1, 48).astype(int):
+            if not set(h.indices[h.indptr[r]:h.indptr[r + 1]]) <= set(amat.indices[amat.indptr[r]:amat.indptr[r + 1]]):
+                hint = None
+                break
+    ctx = backend.context_for(amat, hint if hint is not None else sps.csr_matrix((nv, nv)), jmat)
     if umat is not None and vmat is not None:
         ctx.set_lowrank(_dense(umat), _dense(vmat).T)
     else:

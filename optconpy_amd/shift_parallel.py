@@ -305,6 +305,12 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             buffers[g] = (items, per_rank, U_loc, U_all)
         return buffers[g]
 
+    # the sweeps of one call solve nearly the same right-hand-side space again and again: let the library
+    # start every batched solve from the least-squares combination of its last solved panels
+    # (ricadi_set_recycle; the C++ drivers do the same for their own sweeps)
+    recycle = getattr(getattr(ops, "ctx", None), "set_recycle", None)
+    if recycle is not None:
+        recycle(3)
     step_rule = stop_rule == "step" and adi_newZ_reltol > 0.0
     rel_h1, rel_h2 = np.zeros(ns), np.zeros(ns)
     blocks = []
@@ -408,6 +414,8 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             print("sweep {0:3d}: {1} shifts, kept {2}, rel new Z {3:9.3e}".format(nsweeps, g_now, kept, rel))
         if stop:
             break
+    if recycle is not None:
+        recycle(0)
     Wend = Wq[0] if parts == 1 else torch.cat(Wq, dim=1).contiguous()
     info = dict(adi_steps=steps, sweeps=nsweeps, width=G, col_parts=parts, adi_rel_newZ=rel,
                 res_fro=ops.gram_fro(Wend), resfac=Wend,

@@ -101,8 +101,32 @@ def main_cfg2():
           ro["nwtn_steps"], "upd_hist", out["upd_hist"].tolist(), "seconds", out["oracle_seconds"].tolist())
 
 
+def main_dre30():
+    """The differential-Riccati sweep (solve_dae_ric.py:121-211 through optconpy_amd.dae_ric with the
+    ORACLE's modules injected) at N = 30, Nts = 4: per time step the gain mtxtb and the feed-forward w.
+    ~4 minutes of oracle time; the GPU test tests/test_dae_ric.py::test_sweep_n30_gpu_vs_oracle_fixture
+    runs the same sweep through the MI355X modules and compares per step."""
+    import time
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from test_dae_ric import _setup
+    from optconpy_amd.dae_ric import MemoryStore, solve_flow_daeric
+    t0 = time.time()
+    pr, kw, tmesh = _setup(N=30, Nts=4)
+    store = MemoryStore()
+    fb = solve_flow_daeric(store=store, pru=pru, lau=lau, **kw)
+    out = dict(tmesh=np.asarray(tmesh),
+               mat_checks=np.array([pr.M.data.sum(), pr.A.data.sum(), abs(pr.J.data).sum(), abs(pr.Nc.data).sum()]))
+    for k, t in enumerate(tmesh):
+        out["mtxtb_%d" % k] = store.load(fb[t]["mtxtb"])
+        out["w_%d" % k] = store.load(fb[t]["w"])
+    np.savez_compressed(os.path.join(HERE, "dre30_golden.npz"), **out)
+    print("dre30 fixture written in %.0f s" % (time.time() - t0))
+
+
 if __name__ == "__main__":
-    if "--cfg2" in sys.argv:
+    if "--dre30" in sys.argv:
+        main_dre30()
+    elif "--cfg2" in sys.argv:
         main_cfg2()
     else:
         main()

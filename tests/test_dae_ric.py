@@ -101,6 +101,31 @@ def test_sweep_gpu_vs_oracle():
     backend.reset()
 
 
+@pytest.mark.gpu
+def test_sweep_n30_gpu_vs_oracle_fixture():
+    """The backward sweep of the differential Riccati equation at a size where the operator changes
+    matter (N = 30, n = 7 922, four time steps on the sine-squeezed mesh, compression to 20 columns,
+    z0 / w_mat hand-over between the steps): per time step the gain mtxtb and the feed-forward w against
+    the ORACLE's sweep (tests/golden/dre30_golden.npz, made by make_golden.py --dre30: 4 minutes of
+    oracle time, hence a fixture).  solve_dae_ric.py:121-211."""
+    import os
+    from optconpy_amd import backend
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dre30_golden.npz"))
+    backend.reset()
+    pr, kw, tmesh = _setup(N=30, Nts=4)
+    assert np.allclose(tmesh, g["tmesh"])
+    assert np.allclose(g["mat_checks"], [pr.M.data.sum(), pr.A.data.sum(), abs(pr.J.data).sum(),
+                                         abs(pr.Nc.data).sum()], rtol=1e-12)
+    sg = MemoryStore()
+    fg = solve_flow_daeric(store=sg, **kw)             # MI355X modules
+    for k, t in enumerate(tmesh):
+        Kg, wg = sg.load(fg[t]["mtxtb"]), sg.load(fg[t]["w"])
+        Ko, wo = g["mtxtb_%d" % k], g["w_%d" % k]
+        assert np.linalg.norm(Kg - Ko) <= 1e-6 * np.linalg.norm(Ko), (k, t)
+        assert np.linalg.norm(wg - wo) <= 1e-6 * np.linalg.norm(wo), (k, t)
+    backend.reset()
+
+
 # ------------------------------------------- outer-Newton accumulation (curnwtnsdict)
 def _cns_dict(tmesh, prefix="cns"):
     """Names as optcont_main.py:201-210 (init_nwtnstps_value_dict) builds them."""
