@@ -487,6 +487,7 @@ def dre_workload(args, rank):
                                 adi_steps=o["adi_steps"], shift_solves=o["shift_solves"],
                                 gmres_iters=o["gmres_iters"], rhs_cols=int(k["wmat"].shape[1] + k["bmat"].shape[1]),
                                 nonconverged=o["gmres_nonconverged"], escalations=o.get("storage_escalations", 0)))
+                log("cfg4-dre: time step %d of %d: %s" % (len(rec), Nts, rec[-1]))
                 return o
             return g
 
@@ -501,7 +502,7 @@ def dre_workload(args, rank):
         del rec[:]
         store = MemoryStore()
         t0 = time.perf_counter()
-        fb = solve_flow_daeric(store=store, **kw)
+        fb = solve_flow_daeric(store=store, pru=Timed(), lau=lau, **kw)
         el = time.perf_counter() - t0
         K0 = store.load(fb[tmesh[0]]["mtxtb"])
         return el, list(rec), float(np.linalg.norm(K0))
