@@ -259,7 +259,15 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
                          double* g, double* scale, double* resid, const double* bnorm, double tol,
-                         double* host_resid = nullptr);
+                         double* host_resid = nullptr, double* zero_h1 = nullptr, double* zero_h2 = nullptr);
+// the two dot passes of the hot Arnoldi path (FP16 basis, m = 16) with atomic accumulation: no partial rows, no
+// reduce launches; `out` must be zero at launch (the Hessenberg kernel clears zero_h1 / zero_h2 as it goes)
+bool dots_atomic_ok(int m);
+void launch_cols_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                               size_t vstride, size_t gsb, const double* w, size_t gsw, double* out, size_t gso);
+void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                      size_t vstride, size_t gsb, const double* h, size_t gsh, double* w, size_t gsw,
+                                      double* out, size_t gso);
 void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
                               int restart, const double* H, const double* g, double* y);
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
@@ -366,6 +374,21 @@ void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag);
 void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);
+
+// K2p: the pressure step of the SIMPLE cycle fused into one launch (m = 16, 32 x 32 Schur blocks):
+//   out[rows_b] = inv_b (J z + (S Y)_p ec - r_p)[rows_b]  with the epilogue options of the Schur sweep (pa);
+// rows / jrp / syrp are pressure-local (syrp = NULL: no coarse term), z is the n x 16 panel whose velocity rows
+// are read, rp_ / rp16 the pressure rows of the residual (FP64 or FP16-stored), out the pressure rows of z.
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
+                            const GroupPtrsF& inv, const int* jrp, const int* jci, const double* jv, const double* z,
+                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+                            const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
+                            const ProlongArgs& pa);
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
+                            const GroupPtrs& inv, const int* jrp, const int* jci, const double* jv, const double* z,
+                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+                            const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
+                            const ProlongArgs& pa);
 
 void set_error(const std::string& msg);
 

@@ -971,6 +971,7 @@ __device__ __forceinline__ double dpp_row_sum(double v) {
 constexpr int WLS = 18;
 // dot products of the chunk held in wl (DOT_ROWS rows of 16 doubles, stride WLS; rows >= nr zeroed) against the
 // basis vectors [0, nvec) and, if want_self, against itself (output row nvec)
+template <bool ATOMIC = false>
 __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis, size_t vstride, int r0, int nr,
                                              int nvec, int want_self, const double* wl,
                                              double* __restrict__ pout) {
@@ -1008,15 +1009,23 @@ __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis,
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = dpp_row_sum(acc[t]);
     if (s == 0 && i < ntot) {
-      double2* o = reinterpret_cast<double2*>(pout + (size_t)i * 16 + half * 8);
-      o[0] = make_double2(acc[0], acc[1]);
-      o[1] = make_double2(acc[2], acc[3]);
-      o[2] = make_double2(acc[4], acc[5]);
-      o[3] = make_double2(acc[6], acc[7]);
+      if (ATOMIC) {
+        // straight into the (pre-zeroed) result: no partial rows, no reduce launch
+#pragma unroll
+        for (int t = 0; t < 8; ++t) atomicAdd(pout + (size_t)i * 16 + half * 8 + t, acc[t]);
+      } else {
+        double2* o = reinterpret_cast<double2*>(pout + (size_t)i * 16 + half * 8);
+        o[0] = make_double2(acc[0], acc[1]);
+        o[1] = make_double2(acc[2], acc[3]);
+        o[2] = make_double2(acc[4], acc[5]);
+        o[3] = make_double2(acc[6], acc[7]);
+      }
     }
   }
 }
 
+// ATOMIC: `partial` is the result array itself (group stride gsp), zeroed beforehand
+template <bool ATOMIC = false>
 __global__ __launch_bounds__(256) void cols_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
@@ -1034,11 +1043,12 @@ __global__ __launch_bounds__(256) void cols_dots16_kernel(
   }
   __syncthreads();
   const int nout = (nvec + (want_self ? 1 : 0)) * 16;
-  chunk_dots16(basis, vstride, r0, nr, nvec, want_self, wl, partial + (size_t)blockIdx.x * nout);
+  chunk_dots16<ATOMIC>(basis, vstride, r0, nr, nvec, want_self, wl, ATOMIC ? partial : partial + (size_t)blockIdx.x * nout);
 }
 
 // w' = w - V h (written back), then the dots of w' against V and itself (chunk_dots16; the basis chunk
 // is cache resident by then, so the LDS side decides: with unpadded rows this phase was 2x slower)
+template <bool ATOMIC = false>
 __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
@@ -1106,7 +1116,8 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
     }
   }
   __syncthreads();
-  chunk_dots16(basis, vstride, r0, nr, nvec, 1, wl, partial + (size_t)blockIdx.x * (nvec + 1) * 16);
+  chunk_dots16<ATOMIC>(basis, vstride, r0, nr, nvec, 1, wl,
+                       ATOMIC ? partial : partial + (size_t)blockIdx.x * (nvec + 1) * 16);
 }
 
 // ---- the same two dot kernels for panels of 8 * NOCT columns (NOCT = 1, 3, 4: the projection solve, the
@@ -1403,7 +1414,7 @@ static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
       return;
     }
     if (m == 16 && arnoldi16(1)) {
-      hipLaunchKernelGGL(cols_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
+      hipLaunchKernelGGL(cols_dots16_kernel<false>, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
                          vstride, gsb, w, gsw, want_self, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                          nblk, nout, partial, gsp, out, gso, 0);
@@ -1434,6 +1445,30 @@ void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, in
                         size_t gso) {
   cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
                  gso);
+}
+// The two dot passes of the hot Arnoldi path (FP16-stored basis, 16-column panels) WITHOUT partial rows and
+// reduce launches: every workgroup adds its sums to the result with FP64 atomics.  `out` (group stride gso, (nvec (+1))
+// x 16 doubles used) must be zero when the kernel starts -- the Hessenberg kernel clears what it has consumed
+// (launch_gmres_hess_b, zero_h1 / zero_h2).  MEASURED SLOWER and therefore OFF by default (RICADI_DOTS_ATOMIC=1 switches
+// it on): 468 workgroups per group add to the same 112-192 addresses, and contended FP64 atomics serialise at the
+// memory side -- cfg2 step 393 -> 741 ms (same-call A/B, round 3), although two launches per iteration disappear.
+bool dots_atomic_ok(int m) {
+  static const bool on = getenv("RICADI_DOTS_ATOMIC") && atoi(getenv("RICADI_DOTS_ATOMIC")) == 1;
+  return on && m == 16 && arnoldi16(1) && arnoldi16(2);
+}
+void launch_cols_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                               size_t vstride, size_t gsb, const double* w, size_t gsw, double* out, size_t gso) {
+  if (nvec <= 0 || gt.ng <= 0) return;
+  hipLaunchKernelGGL(cols_dots16_kernel<true>, dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec,
+                     basis, vstride, gsb, w, gsw, 0, out, gso);
+}
+void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                      size_t vstride, size_t gsb, const double* h, size_t gsh, double* w, size_t gsw,
+                                      double* out, size_t gso) {
+  if (gt.ng <= 0) return;
+  hipLaunchKernelGGL(cols_update_dots16_kernel<true>, dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256),
+                     (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb, h, gsh,
+                     w, gsw, out, gso);
 }
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
@@ -1529,7 +1564,7 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
       return;
     }
     if (m == 16 && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double) <= 48 * 1024) {
-      hipLaunchKernelGGL(cols_update_dots16_kernel, dim3(nblk, 1, gt.ng), dim3(256),
+      hipLaunchKernelGGL(cols_update_dots16_kernel<false>, dim3(nblk, 1, gt.ng), dim3(256),
                          (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
                          gsb, h, gsh, w, gsw, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
@@ -1706,7 +1741,7 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     const double* __restrict__ h2, double* __restrict__ H, double* __restrict__ cs,
     double* __restrict__ sn, double* __restrict__ g, double* __restrict__ scale,
     double* __restrict__ resid, const double* __restrict__ bnorm, double tol,
-    double* __restrict__ host_resid) {
+    double* __restrict__ host_resid, double* __restrict__ zero_h1, double* __restrict__ zero_h2) {
   extern __shared__ double sh[];       // hcol[restart+2], csl[restart], snl[restart]
   if (host_resid) host_resid += (size_t)gt.gid[blockIdx.z] * m;
   {
@@ -1714,6 +1749,8 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     const size_t grp = (size_t)gt.gid[blockIdx.z];
     h1 += grp * (restart + 2) * m;
     h2 += grp * (restart + 2) * m;
+    if (zero_h1) zero_h1 += grp * (restart + 2) * m;
+    if (zero_h2) zero_h2 += grp * (restart + 2) * m;
     H += grp * m * (restart + 1) * restart;
     cs += grp * m * restart;
     sn += grp * m * restart;
@@ -1738,6 +1775,12 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     part += b * b;
     hcol[i] = h1[i * m + c] + b;
   }
+  // atomic dot passes (launch_cols_dots16_atomic): clear what has been consumed -- this column of the first-pass
+  // sums, and of the second-pass buffer of the NEXT iteration (last read by the update of the previous one)
+  if (zero_h1)
+    for (int i = lane; i < nv; i += 64) zero_h1[i * m + c] = 0.0;
+  if (zero_h2)
+    for (int i = lane; i <= nv + 1 && i < restart + 2; i += 64) zero_h2[i * m + c] = 0.0;
   for (int i = lane; i < j; i += 64) {
     csl[i] = csc[i];
     snl[i] = snc[i];
@@ -1785,11 +1828,11 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
                          double* g, double* scale, double* resid, const double* bnorm, double tol,
-                         double* host_resid) {
+                         double* host_resid, double* zero_h1, double* zero_h2) {
   if (gt.ng <= 0) return;
   hipLaunchKernelGGL(gmres_hess_kernel, dim3(m, 1, gt.ng), dim3(64),
                      (3 * restart + 4) * sizeof(double), st, gt, m, j, restart, h1, h2, H, cs, sn, g,
-                     scale, resid, bnorm, tol, host_resid);
+                     scale, resid, bnorm, tol, host_resid, zero_h1, zero_h2);
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.
@@ -3486,5 +3529,149 @@ void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a
 
 // identity matrix (for getrs against I)
 
+
+// ---------------------------------------------------------------------------
+// K2p: the pressure step of the SIMPLE cycle in ONE launch (16-column panels, 32 x 32 Schur blocks):
+//     t   = J z_v + (S Y)_p e - r_p          (CSR rows of J over the panel z, of the prolongated operator over
+//                                              the coarse correction e; r_p from the FP64 or the FP16-stored vector)
+//     z_p = Shat_b^-1 t[rows_b]               (FP64 MFMA 16x16x4 on the FP32- / FP64-stored block inverse)
+// with the epilogue of the Schur sweep it replaces (plain copy for the J^T product of the last velocity sweep,
+// coarse prolongation, FP32 copy).  Round 2 issued three dependent launches here (pressure rows of r - (S Y) e,
+// J product, Schur sweep: 10 + 25 + 9 us at 16 groups, ~20 us of latency floor at one group).  One workgroup of
+// four waves per block: the 16-lane rows of all four waves form the block's 32 rows of t in two passes (index /
+// value chunks by one coalesced load, DPP row broadcasts, 16 gathers in flight as in spmm_kernel_v2), t goes
+// through LDS, waves 0 and 1 apply the inverse.
+// ---------------------------------------------------------------------------
+template <class T, class RT>
+__global__ __launch_bounds__(256) void pressure_step_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows, GroupPtrsT<T> invs,
+    const int* __restrict__ jrp, const int* __restrict__ jci, const double* __restrict__ jv,
+    const double* __restrict__ z, size_t gsz,
+    const int* __restrict__ syrp, const int* __restrict__ syci, GroupPtrs syv, const double* __restrict__ ec, size_t gse,
+    const RT* __restrict__ rp_, size_t gsr, double* __restrict__ out, size_t gso, ProlongArgs pa) {
+  __shared__ double tl[32][17];
+  const int grp = gt.gid[blockIdx.z];
+  const T* __restrict__ inv = invs.p[grp] + (size_t)blockIdx.x * 1024;
+  z += (size_t)grp * gsz;
+  rp_ += (size_t)grp * gsr;
+  out += (size_t)grp * gso;
+  const double* __restrict__ sval = syrp ? syv.p[grp] : nullptr;
+  const double* __restrict__ ecg = ec ? ec + (size_t)grp * gse : nullptr;
+  const int b0 = bptr[blockIdx.x], nb = bptr[blockIdx.x + 1] - b0;
+  const int g = threadIdx.x & 15, rg = threadIdx.x >> 4;        // column, row group (16 of them)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int il = rg + 16 * pass;
+    const bool live = il < nb;
+    const int prow = live ? rows[b0 + il] : 0;
+    double acc = 0.0;
+    {
+      const int k0 = live ? jrp[prow] : 0, k1 = live ? jrp[prow + 1] : 0;
+      int nch = (k1 - k0 + 15) >> 4;
+      nch = max(nch, __shfl_xor(nch, 16, 64));
+      nch = max(nch, __shfl_xor(nch, 32, 64));
+      for (int ch = 0; ch < nch; ++ch) {
+        const int k = k0 + ch * 16 + g;
+        int myc = 0;
+        double myv = 0.0;
+        if (k < k1) {
+          myc = jci[k];
+          myv = jv[k];
+        }
+#define RICADI_PS_STEP(TT)                                  \
+  {                                                         \
+    const int c0 = bc16i<TT>(myc);                          \
+    const double v0 = bc16d<TT>(myv);                       \
+    acc = fma(v0, z[(size_t)c0 * 16 + g], acc);             \
+  }
+        RICADI_FOR16(RICADI_PS_STEP)
+#undef RICADI_PS_STEP
+      }
+    }
+    if (syrp) {
+      const int k0 = live ? syrp[prow] : 0, k1 = live ? syrp[prow + 1] : 0;
+      int nch = (k1 - k0 + 7) >> 3;
+      nch = max(nch, __shfl_xor(nch, 16, 64));
+      nch = max(nch, __shfl_xor(nch, 32, 64));
+      for (int ch = 0; ch < nch; ++ch) {
+        const int k = k0 + ch * 8 + g;
+        int myc = 0;
+        double myv = 0.0;
+        if (g < 8 && k < k1) {
+          myc = syci[k];
+          myv = sval[k];
+        }
+#define RICADI_PS_STEP(TT)                                  \
+  {                                                         \
+    const int c0 = bc16i<TT>(myc);                          \
+    const double v0 = bc16d<TT>(myv);                       \
+    acc = fma(v0, ecg[(size_t)c0 * 16 + g], acc);           \
+  }
+        RICADI_PS_STEP(0) RICADI_PS_STEP(1) RICADI_PS_STEP(2) RICADI_PS_STEP(3)
+        RICADI_PS_STEP(4) RICADI_PS_STEP(5) RICADI_PS_STEP(6) RICADI_PS_STEP(7)
+#undef RICADI_PS_STEP
+      }
+    }
+    const double rv = live ? (double)rp_[(size_t)prow * 16 + g] : 0.0;
+    tl[il][g] = live ? acc - rv : 0.0;
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  if (wave >= 2) return;
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4, t = wave;
+  d4 acc4 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    double a4[4];
+    load4(inv + (size_t)(16 * t + r) * 32 + kc * 16 + 4 * q, a4);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2)
+      acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s2], tl[kc * 16 + 4 * q + s2][r], acc4, 0, 0, 0);
+  }
+  const double* __restrict__ pec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int il = 16 * t + q + 4 * e;
+    if (il < nb) {
+      const int row = rows[b0 + il];
+      double v = acc4[e];
+      if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * 16 + r] = v;
+      if (pec) v += pec[(size_t)pa.aggof[row] * 16 + r];
+      if (!(pa.out32 && pa.only32)) out[(size_t)row * 16 + r] = v;
+      if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * 16 + r] = (float)v;
+    }
+  }
+}
+template <class T>
+static void pressure_step_impl(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
+                               const GroupPtrsT<T>& inv, const int* jrp, const int* jci, const double* jv, const double* z,
+                               size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec,
+                               size_t gse, const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
+                               const ProlongArgs& pa) {
+  if (nblocks <= 0 || gt.ng <= 0) return;
+  dim3 grid(nblocks, 1, gt.ng), block(256);
+  if (rp16)
+    hipLaunchKernelGGL((pressure_step_kernel<T, _Float16>), grid, block, 0, st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z,
+                       gsz, syrp, syci, syv, ec, gse, rp16, gsr, out, gso, pa);
+  else
+    hipLaunchKernelGGL((pressure_step_kernel<T, double>), grid, block, 0, st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z,
+                       gsz, syrp, syci, syv, ec, gse, rp_, gsr, out, gso, pa);
+}
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
+                            const GroupPtrsF& inv, const int* jrp, const int* jci, const double* jv, const double* z,
+                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+                            const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
+                            const ProlongArgs& pa) {
+  pressure_step_impl(st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z, gsz, syrp, syci, syv, ec, gse, rp_, rp16, gsr, out,
+                     gso, pa);
+}
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
+                            const GroupPtrs& inv, const int* jrp, const int* jci, const double* jv, const double* z,
+                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+                            const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
+                            const ProlongArgs& pa) {
+  pressure_step_impl(st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z, gsz, syrp, syci, syv, ec, gse, rp_, rp16, gsr, out,
+                     gso, pa);
+}
 
 }  // namespace ricadi

@@ -424,7 +424,7 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   c->ec.alloc((size_t)std::max(c->kc, 1) * gm);
   c->partial.alloc((size_t)dots_num_blocks(c->n) * (restart + 2) * gm);
   c->h1.alloc((size_t)(restart + 2) * gm);
-  c->h2.alloc((size_t)(restart + 2) * gm);
+  c->h2.alloc((size_t)2 * (restart + 2) * gm);      // two buffers (atomic dot passes alternate between them)
   c->H.alloc(gm * (restart + 1) * restart);
   c->cs.alloc(gm * restart);
   c->sn.alloc(gm * restart);
@@ -874,6 +874,11 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   bool folded = false;
   // ricadi_time_kernel_dev times one stage at a time through exactly these launchers (c->pc_stage >= 0)
   auto on = [&](int stage) { return c->pc_stage < 0 || c->pc_stage == stage; };
+  // the pressure step -- pressure rows of r - (S Y) e, J product, Schur sweep -- as ONE launch (K2p) for
+  // 16-column panels (RICADI_PFUSE=0: the three launches of round 2)
+  static const bool pfuse_env = !(getenv("RICADI_PFUSE") && atoi(getenv("RICADI_PFUSE")) == 0);
+  static const bool fuse_jt_env = getenv("RICADI_NOFUSE_JT") == nullptr;
+  const bool fusedp = pfuse_env && fuse_jt_env && np > 0 && m == 16 && c->bs == 32;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
@@ -895,7 +900,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
-    if (!on(2)) {
+    if (!on(2) || (fusedp && folded)) {
     } else if (folded) {
       // only the PRESSURE rows of r - (S Y) ec are formed (short CSR product over np rows); the
       // velocity rows ride inside the first velocity sweep (block_apply2_kernel, below)
@@ -976,7 +981,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   }
   if (np > 0) {
     // t = J z_v - r_p
-    if (on(4))
+    if (on(4) && !fusedp)
       launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
                     rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
@@ -1001,6 +1006,21 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       }
     }
     if (!on(5)) {
+    } else if (fusedp) {
+      // r_p: of the folded cycle the input vector itself (FP64 or FP16-stored) with the coarse term formed in
+      // the kernel; else the pressure rows of the corrected residual r2
+      const bool sy = folded;
+      const double* rp64 = sy ? (r16 ? nullptr : r + (size_t)nv * m) : rr + (size_t)nv * m;
+      const _Float16* rp16 = sy && r16 ? r16 + (size_t)nv * m : nullptr;
+      const size_t gsrp = sy ? gsr : gsrr;
+      if (c->precond32)
+        launch_pressure_step_b(st, gt, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->J.rp.p, c->J.ci.p, c->J.v.p, z,
+                               bt.gs, sy ? c->sy_rp.p + nv : nullptr, c->sy_ci.p, bt.syval, c->ec.p, bt.gsc, rp64, rp16,
+                               gsrp, zp, bt.gs, ppro);
+      else
+        launch_pressure_step_b(st, gt, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->J.rp.p, c->J.ci.p, c->J.v.p, z,
+                               bt.gs, sy ? c->sy_rp.p + nv : nullptr, c->sy_ci.p, bt.syval, c->ec.p, bt.gsc, rp64, rp16,
+                               gsrp, zp, bt.gs, ppro);
     } else if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
                            bt.gsp, zp, m, bt.gs, m, 0, ppro);
@@ -1100,6 +1120,9 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   // launch, cycle +2 %; at cfg2 the FP32 gathers are no faster and the step was 1.4 % slower)
   // the preconditioner reads the current vector from the FP16 basis itself; its FP64 copy is then not written
   const bool h16 = precond_reads_h16(c, m);
+  // dot passes with atomic accumulation (no partial rows, no reduce launches): FP16 basis, 16 columns
+  const bool adots = b16 && dots_atomic_ok(m);
+  const size_t h2buf = (size_t)(restart + 2) * c->wcols;        // doubles between the two second-pass buffers
   const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
@@ -1205,6 +1228,11 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
     live = act;
     for (int g : act) kk[g] = 0;
+    if (adots) {
+      HIPCHK(hipMemsetAsync(c->h1.p, 0, sizeof(double) * gsh * G, st));
+      HIPCHK(hipMemsetAsync(c->h2.p, 0, sizeof(double) * gsh * G, st));
+      HIPCHK(hipMemsetAsync(c->h2.p + h2buf, 0, sizeof(double) * gsh * G, st));
+    }
     for (int j = 0; j < cyc && !live.empty(); ++j) {
       bt.set(live);
       const double* vj = (b32 || b16) ? c->vcur.p : V + (size_t)j * vs;
@@ -1215,7 +1243,11 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       float* zj = flex ? c->zbasisf.p + (size_t)j * vs : nullptr;
       precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32, h16 ? Vh + (size_t)j * vs : nullptr);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr);
-      if (b16) {
+      double* h2cur = adots ? c->h2.p + (size_t)(j & 1) * h2buf : c->h2.p;
+      if (adots) {
+        launch_cols_dots16_atomic(st, bt.tab, n, j + 1, Vh, vs, nm, c->wv.p, nm, c->h1.p, gsh);
+        launch_cols_update_dots16_atomic(st, bt.tab, n, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, h2cur, gsh);
+      } else if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
                            c->h1.p, gsh);
         launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm,
@@ -1235,10 +1267,11 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       // the residual estimates also go straight to a pinned host slot (read one
       // iteration later, behind the event below)
       double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
-      launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, c->h2.p, c->H.p, c->cs.p, c->sn.p,
-                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur);
+      launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
+                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, adots ? c->h1.p : nullptr,
+                          adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr);
       if (b16)
-        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
+        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, h2cur, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
       else if (b32)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
@@ -3393,12 +3426,14 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
                               -1.0, 1.0, m, c->syb_max_cols);
         break;
       case 5:
-        if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        if (b16 && dots_atomic_ok(m)) launch_cols_dots16_atomic(st, gt, n, nvec, Vh, vs, nm, c->wv.p, nm, c->h1.p, gsh);
+        else if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else if (b32) launch_cols_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else launch_cols_dots_b(st, gt, n, m, nvec, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         break;
       case 6:
-        if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        if (b16 && dots_atomic_ok(m)) launch_cols_update_dots16_atomic(st, gt, n, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->h2.p, gsh);
+        else if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else if (b32) launch_cols_update_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         break;
