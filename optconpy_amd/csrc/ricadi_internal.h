@@ -259,7 +259,12 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
                          double* g, double* scale, double* resid, const double* bnorm, double tol,
-                         double* host_resid = nullptr, double* zero_h1 = nullptr, double* zero_h2 = nullptr);
+                         double* host_resid = nullptr, double* zero_h1 = nullptr, double* zero_h2 = nullptr,
+                         double* hsum = nullptr);
+// 16-column FP16 Arnoldi path: the update+dots launch may leave w as it was BEFORE the first projection (no 8-byte
+// store per element); the Hessenberg kernel then writes h1 + h2 to `hsum` and the final update uses those on w
+bool update_dots_keeps_w(int m, bool fp16_basis, int nvec_max);
+void set_update_dots_nostore(bool v);
 // the two dot passes of the hot Arnoldi path (FP16 basis, m = 16) with atomic accumulation: no partial rows, no
 // reduce launches; `out` must be zero at launch (the Hessenberg kernel clears zero_h1 / zero_h2 as it goes)
 bool dots_atomic_ok(int m);

@@ -1048,7 +1048,9 @@ __global__ __launch_bounds__(256) void cols_dots16_kernel(
 
 // w' = w - V h (written back), then the dots of w' against V and itself (chunk_dots16; the basis chunk
 // is cache resident by then, so the LDS side decides: with unpadded rows this phase was 2x slower)
-template <bool ATOMIC = false>
+// STORE = false: w' is only staged in LDS for the dots, the panel w keeps the vector BEFORE the first projection (the
+// final update then subtracts the basis with the SUM of both passes' coefficients: one 8-byte store per element less)
+template <bool ATOMIC = false, bool STORE = true>
 __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
       const double v = ok[k] ? wv[k] - sacc[k] : 0.0;
-      if (ok[k]) w[base + e[k]] = v;
+      if (STORE && ok[k]) w[base + e[k]] = v;
       wl[(e[k] >> 4) * WLS + c] = v;
     }
   }
@@ -1466,7 +1468,7 @@ void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nr
                                       size_t vstride, size_t gsb, const double* h, size_t gsh, double* w, size_t gsw,
                                       double* out, size_t gso) {
   if (gt.ng <= 0) return;
-  hipLaunchKernelGGL(cols_update_dots16_kernel<true>, dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256),
+  hipLaunchKernelGGL((cols_update_dots16_kernel<true, true>), dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256),
                      (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb, h, gsh,
                      w, gsw, out, gso);
 }
@@ -1537,6 +1539,14 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
     partial[(size_t)blockIdx.x * nout + o] = s0 + s1;
   }
 }
+// set by update_dots_keeps_w(): the 16-column FP16 launch leaves w untouched (see cols_update_dots16_kernel)
+static thread_local bool g_update_dots_nostore = false;
+bool update_dots_keeps_w(int m, bool fp16_basis, int nvec_max) {
+  static const bool on = !(getenv("RICADI_KEEP_W") && atoi(getenv("RICADI_KEEP_W")) == 0);
+  return on && fp16_basis && m == 16 && arnoldi16(2) && arnoldi16(4) &&
+         (size_t)(DOT_ROWS * 18 + nvec_max * 16) * sizeof(double) <= 48 * 1024;
+}
+void set_update_dots_nostore(bool v) { g_update_dots_nostore = v; }
 template <class BT>
 static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                                   const BT* basis, size_t vstride, size_t gsb, const double* h,
@@ -1564,9 +1574,14 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
       return;
     }
     if (m == 16 && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double) <= 48 * 1024) {
-      hipLaunchKernelGGL(cols_update_dots16_kernel<false>, dim3(nblk, 1, gt.ng), dim3(256),
-                         (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
-                         gsb, h, gsh, w, gsw, partial, gsp);
+      if (g_update_dots_nostore)
+        hipLaunchKernelGGL((cols_update_dots16_kernel<false, false>), dim3(nblk, 1, gt.ng), dim3(256),
+                           (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
+                           gsb, h, gsh, w, gsw, partial, gsp);
+      else
+        hipLaunchKernelGGL((cols_update_dots16_kernel<false, true>), dim3(nblk, 1, gt.ng), dim3(256),
+                           (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
+                           gsb, h, gsh, w, gsw, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                          nblk, nout, partial, gsp, out, gso, 0);
       return;
@@ -1741,7 +1756,8 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     const double* __restrict__ h2, double* __restrict__ H, double* __restrict__ cs,
     double* __restrict__ sn, double* __restrict__ g, double* __restrict__ scale,
     double* __restrict__ resid, const double* __restrict__ bnorm, double tol,
-    double* __restrict__ host_resid, double* __restrict__ zero_h1, double* __restrict__ zero_h2) {
+    double* __restrict__ host_resid, double* __restrict__ zero_h1, double* __restrict__ zero_h2,
+    double* __restrict__ hsum) {
   extern __shared__ double sh[];       // hcol[restart+2], csl[restart], snl[restart]
   if (host_resid) host_resid += (size_t)gt.gid[blockIdx.z] * m;
   {
@@ -1750,6 +1766,7 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     h1 += grp * (restart + 2) * m;
     h2 += grp * (restart + 2) * m;
     if (zero_h1) zero_h1 += grp * (restart + 2) * m;
+    if (hsum) hsum += grp * (restart + 2) * m;
     if (zero_h2) zero_h2 += grp * (restart + 2) * m;
     H += grp * m * (restart + 1) * restart;
     cs += grp * m * restart;
@@ -1774,6 +1791,7 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
     const double b = h2[i * m + c];
     part += b * b;
     hcol[i] = h1[i * m + c] + b;
+    if (hsum) hsum[i * m + c] = hcol[i];       // coefficients of BOTH passes, for an update that starts from the unprojected w
   }
   // atomic dot passes (launch_cols_dots16_atomic): clear what has been consumed -- this column of the first-pass
   // sums, and of the second-pass buffer of the NEXT iteration (last read by the update of the previous one)
@@ -1828,11 +1846,11 @@ __global__ __launch_bounds__(64) void gmres_hess_kernel(
 void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int restart,
                          const double* h1, const double* h2, double* H, double* cs, double* sn,
                          double* g, double* scale, double* resid, const double* bnorm, double tol,
-                         double* host_resid, double* zero_h1, double* zero_h2) {
+                         double* host_resid, double* zero_h1, double* zero_h2, double* hsum) {
   if (gt.ng <= 0) return;
   hipLaunchKernelGGL(gmres_hess_kernel, dim3(m, 1, gt.ng), dim3(64),
                      (3 * restart + 4) * sizeof(double), st, gt, m, j, restart, h1, h2, H, cs, sn, g,
-                     scale, resid, bnorm, tol, host_resid, zero_h1, zero_h2);
+                     scale, resid, bnorm, tol, host_resid, zero_h1, zero_h2, hsum);
 }
 
 // y[i*m + c] solves R y = g for the k x k triangle of column c.

@@ -1122,6 +1122,12 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   const bool h16 = precond_reads_h16(c, m);
   // dot passes with atomic accumulation (no partial rows, no reduce launches): FP16 basis, 16 columns
   const bool adots = b16 && dots_atomic_ok(m);
+  // w is not rewritten between the two Gram-Schmidt passes: the final update subtracts V (h1 + h2) from the original w
+  const bool keepw = !adots && update_dots_keeps_w(m, b16, restart);
+  struct NoStoreScope {
+    explicit NoStoreScope(bool v) { set_update_dots_nostore(v); }
+    ~NoStoreScope() { set_update_dots_nostore(false); }
+  } nostore_scope(keepw);
   const size_t h2buf = (size_t)(restart + 2) * c->wcols;        // doubles between the two second-pass buffers
   const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
@@ -1269,9 +1275,10 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
       launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
                           c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, adots ? c->h1.p : nullptr,
-                          adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr);
+                          adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr,
+                          keepw ? c->h2.p + h2buf : nullptr);
       if (b16)
-        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, h2cur, gsh, -1.0, c->wv.p, nm,
+        launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, keepw ? c->h2.p + h2buf : h2cur, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
       else if (b32)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm,
@@ -3432,10 +3439,12 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         else launch_cols_dots_b(st, gt, n, m, nvec, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         break;
       case 6:
+        set_update_dots_nostore(!dots_atomic_ok(m) && update_dots_keeps_w(m, b16, restart));   // as the iteration launches it
         if (b16 && dots_atomic_ok(m)) launch_cols_update_dots16_atomic(st, gt, n, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->h2.p, gsh);
         else if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else if (b32) launch_cols_update_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        set_update_dots_nostore(false);
         break;
       case 7:
         if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
