@@ -314,6 +314,15 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       }
       std::sort(cols.begin(), cols.end());
       for (size_t j = 0; j < cols.size(); ++j) pos[cols[j]] = (int)j;
+      // Rows of similar length next to each other: a wave of the kernel steps through the 16-entry chunks of FOUR
+      // consecutive local rows together (DPP broadcasts need all lanes), i.e. through the LONGEST of the four;
+      // sorted by (half-)chunk count the four rows of a wave-pass need the same number of steps almost everywhere
+      // (P2 vertex / edge-midpoint rows differ by a factor two in their entry counts).  RICADI_SB_SORT=0: visit order.
+      static const bool sort_rows_by_len = !(getenv("RICADI_SB_SORT") && atoi(getenv("RICADI_SB_SORT")) == 0);
+      if (sort_rows_by_len)
+        std::stable_sort(brows.begin(), brows.end(), [&](int a, int b) {
+          return (hs.s_rp[a + 1] - hs.s_rp[a] + 7) / 8 > (hs.s_rp[b + 1] - hs.s_rp[b] + 7) / 8;   // half chunks
+        });
       const size_t nnz0 = hs.sb_perm.size();
       // Entry order within a row: the kernel's 32-lane halves pair the local rows (2j, 2j+1), and
       // their two ds_read_b64 of a step (16 columns = 128 B each) are conflict free iff the two tile
