@@ -123,6 +123,9 @@ class HipOps:
             if self._pool is None:
                 self._pool = ThreadPoolExecutor(max_workers=len(self.ctxs))
             bounds = [round(i * len(pairs) / nctx) for i in range(nctx + 1)]
+            import os
+            if nctx == 2 and os.environ.get("RICADI_SPLIT"):      # developer probe: slow / fast split point
+                bounds = [0, min(len(pairs) - 1, max(1, int(os.environ["RICADI_SPLIT"]))), len(pairs)]
 
             def lane(k):
                 return self._batch_on(self.ctxs[k], pairs[bounds[k]:bounds[k + 1]])
@@ -308,7 +311,13 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
     # the sweeps of one call solve nearly the same right-hand-side space again and again: let the library
     # start every batched solve from the least-squares combination of its last solved panels
     # (ricadi_set_recycle; the C++ drivers do the same for their own sweeps)
-    recycle = getattr(getattr(ops, "ctx", None), "set_recycle", None)
+    ctxs = [cx for cx in getattr(ops, "ctxs", [getattr(ops, "ctx", None)]) if hasattr(cx, "set_recycle")]
+
+    def recycle(depth):
+        for cx in ctxs:
+            cx.set_recycle(depth)
+    if not ctxs:
+        recycle = None
     if recycle is not None:
         recycle(3)
     step_rule = stop_rule == "step" and adi_newZ_reltol > 0.0

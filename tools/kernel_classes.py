@@ -13,7 +13,8 @@ pr = pb.ricc_problem(N, 0.05)
 ctx = _lib.Context(0)
 ctx.set_operator((-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr(), pr.J)
 ms = pb.logshifts(1.0, 3e3, 16)[:G]
-for k in ("spmm", "block_v", "coarse", "spmm_sy", "dots", "update_dots", "update", "restrict"):
+for k in ("spmm", "dots", "update_dots", "update", "pc_restrict", "pc_coarse", "pc_sy_prows", "pc_two_term", "pc_jprod",
+          "pc_schur", "pc_rect", "precond"):
     t = ctx.time_kernel_dev(k, ms, [1.0] * G, 16, nvec=7, reps=reps)
     print("%-12s %8.2f us per launch (HIP events, %d launches)" % (k, 1e3 * t, reps))
 ctx.close()
