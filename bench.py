@@ -212,6 +212,15 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
         "pc_rect": ("ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl) if rk else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
                     G * (pb_ * nb * 32.0 * max(rk, 32) + (8.0 + 8.0) * nv * m + 4.0 * n * m + 8.0 * npn * m + 8.0 * kc0 * m)),
     }
+    if m == 16 and os.environ.get("RICADI_PFUSE", "1") != "0" and info["bs"] == 32 and npn > 0:
+        # K2p: the three launches of the pressure step are ONE kernel; its bytes: J once (shared by the groups), per
+        # group the Schur block inverses, the gathered velocity rows of z, r_p, the coarse correction and z_p (+ plain
+        # copy for the J^T product and the FP32 copy)
+        stages["pc_sy_prows"] = ("(fused into pc_schur: ricadi::pressure_step_kernel)", None)
+        stages["pc_jprod"] = ("(fused into pc_schur: ricadi::pressure_step_kernel)", None)
+        stages["pc_schur"] = ("ricadi::pressure_step_kernel<%s,%s>" % (fl, "_Float16" if h16 else "double"),
+                              12.0 * info.get("nnz_j", 0) + G * (pb_ * info["nbp"] * 1024.0 + 8.0 * nv * m +
+                                                                   (vin + 20.0) * npn * m + 8.0 * kc0 * m))
     tot = 0.0
     for key, (kname, nbytes) in stages.items():
         try:
