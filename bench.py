@@ -92,7 +92,7 @@ def trials(fn, ntrial=5):
 
 
 def traffic_entry(key):
-    for name in ("r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+    for name in ("r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 e = json.load(f).get(key)

@@ -3669,7 +3669,12 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
             std::min(ns, prm->adi_max_steps), 1e3 * t_pre, 1e3 * tk0.lap());
   }
   p2.project_w = 0;
-  if (p2.compress_cols <= 0) p2.compress_cols = 512;
+  if (p2.compress_cols <= 0) {
+    // columns the factor may grow by before it is recompressed (RICADI_COMPRESS_COLS overrides): rocSOLVER's
+    // tridiagonalisation is launch bound at these sizes (~32 us per column), so fewer, larger eigenproblems are cheaper
+    static const int cc = getenv("RICADI_COMPRESS_COLS") ? std::max(64, atoi(getenv("RICADI_COMPRESS_COLS"))) : 512;
+    p2.compress_cols = cc;
+  }
   double upd = 0, updrel = 0;
   long adi_total = 0, gm_total = 0, sol_total = 0, nonconv = 0;
   const long esc0 = c->escalations;
