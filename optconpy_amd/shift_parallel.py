@@ -235,17 +235,30 @@ def plan_items(G, world, col_parts=0):
     return max(1, -(-world // G))
 
 
-def item_layout(G, parts, world):
-    """Dealing of the ``G * parts`` items of a sweep: item ``i = g * parts + q`` goes to rank
-    ``i % world``, local slot ``i // world``; in the rank-major buffer an all-gather fills it
-    sits at ``(i % world) * per_rank + i // world``.  With the shifts sorted by magnitude a
-    rank's items are spread over the whole range, which pairs slow and fast solves."""
+def item_layout(G, parts, world, owners=None):
+    """Dealing of the ``G * parts`` items of a sweep.  Round robin (``owners=None``): item
+    ``i = g * parts + q`` goes to rank ``i % world``, local slot ``i // world``.  With ``owners`` (one rank
+    per shift of the sweep, ``parts == 1``): the FIXED owners of ``_lib.host_deal`` -- the dealing the library's
+    own sharded sweeps use (``ricadi_set_exchange``): slow small-|p| shifts alone, fast ones stacked, and a shift
+    never changes its rank, so that its per-shift setup and recycled solutions stay where they are.  In the
+    rank-major buffer an all-gather fills an item sits at ``rank * per_rank + slot``."""
     nitems = G * parts
-    per_rank = -(-nitems // world)
     items = []
-    for i in range(nitems):
-        items.append(dict(g=i // parts, q=i % parts, rank=i % world, slot=i // world,
-                          pos=(i % world) * per_rank + i // world))
+    if owners is not None:
+        if parts != 1 or len(owners) != G:
+            raise ValueError("fixed owners need one rank per shift and a single column part")
+        cnt = [0] * world
+        for g in range(G):
+            r = int(owners[g])
+            items.append(dict(g=g, q=0, rank=r, slot=cnt[r]))
+            cnt[r] += 1
+        per_rank = max(1, max(cnt))
+    else:
+        per_rank = -(-nitems // world)
+        for i in range(nitems):
+            items.append(dict(g=i // parts, q=i % parts, rank=i % world, slot=i // world))
+    for it in items:
+        it["pos"] = it["rank"] * per_rank + it["slot"]
     return items, per_rank
 
 
@@ -298,15 +311,21 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
     # residual factor kept as `parts` contiguous NV x m' panels (the right-hand sides of the
     # items and the operands of the recombination)
     Wq = [W[:, q * mp_:(q + 1) * mp_].contiguous().clone() for q in range(parts)]
-    buffers = {}                      # per sweep width: (items, per_rank, U_loc, U_all)
+    buffers = {}                      # per (first step, sweep width): (items, per_rank, U_loc, U_all)
+    # fixed owner of every shift of the list (the library's dealing) where the shifts cover the ranks
+    fixed = None
+    if world > 1 and parts == 1 and len(set(float(p) for p in ms)) == ns:
+        fixed = [int(o) for o in _lib.host_deal(ms, world)]
 
-    def layout(g):
-        if g not in buffers:
-            items, per_rank = item_layout(g, parts, world)
+    def layout(first, g):
+        key = (first % ns, g) if fixed is not None else g
+        if key not in buffers:
+            own = None if fixed is None else [fixed[(first + j) % ns] for j in range(g)]
+            items, per_rank = item_layout(g, parts, world, own)
             U_loc = W.new_zeros((per_rank, nv, mp_))          # padding slots stay zero
             U_all = W.new_zeros((world * per_rank, nv, mp_)) if world > 1 else U_loc
-            buffers[g] = (items, per_rank, U_loc, U_all)
-        return buffers[g]
+            buffers[key] = (items, per_rank, U_loc, U_all)
+        return buffers[key]
 
     # the sweeps of one call solve nearly the same right-hand-side space again and again: let the library
     # start every batched solve from the least-squares combination of its last solved panels
@@ -345,7 +364,9 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
         ps = [float(ms[(steps + g) % ns]) for g in range(g_now)]
         if len(set(ps)) != g_now:
             raise ValueError("shifts within one sweep must be distinct: {0}".format(ps))
-        items, per_rank, U_loc, U_all = layout(g_now)
+        items, per_rank, U_loc, U_all = layout(steps, g_now)
+        if world > 1 and len([it for it in items if it["rank"] == rank]) < per_rank:
+            U_loc.zero_()                 # padding slots of THIS sweep travel as zeros
         mine = [it for it in items if it["rank"] == rank]
         nslot = world * per_rank
         if hasattr(ops, "solve_items"):
@@ -426,7 +447,7 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
     if recycle is not None:
         recycle(0)
     Wend = Wq[0] if parts == 1 else torch.cat(Wq, dim=1).contiguous()
-    info = dict(adi_steps=steps, sweeps=nsweeps, width=G, col_parts=parts, adi_rel_newZ=rel,
+    info = dict(adi_steps=steps, sweeps=nsweeps, width=G, col_parts=parts, adi_rel_newZ=rel, owners=fixed,
                 res_fro=ops.gram_fro(Wend), resfac=Wend,
                 gmres_nonconverged=int(getattr(ops, "nonconverged", 0)),
                 gmres_worst_relres=float(getattr(ops, "worst_relres", 0.0)),

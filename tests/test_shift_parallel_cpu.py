@@ -98,6 +98,16 @@ def test_item_layout_and_plan():
             assert it["pos"] == it["rank"] * per_rank + it["slot"] and it["slot"] < per_rank
         load = np.bincount([it["rank"] for it in items], minlength=world)
         assert load.max() - load.min() <= 1
+    # fixed owners (the library's dealing): every item with its owner, slots counted per rank
+    from optconpy_amd import _lib
+    ms16 = pb.logshifts(1.0, 3e3, 16)
+    for world in (2, 4, 8):
+        own = _lib.host_deal(ms16, world)
+        items, per_rank = item_layout(16, 1, world, own)
+        assert [it["rank"] for it in items] == [int(o) for o in own]
+        assert per_rank == np.bincount(own, minlength=world).max()
+        pos = [it["pos"] for it in items]
+        assert len(set(pos)) == 16 and max(pos) < world * per_rank
 
 
 @pytest.mark.parametrize("G,parts", [(4, 2), (8, 4), (2, 1)])
@@ -195,7 +205,9 @@ def _worker(rank, world, port, outdir, width=4, col_parts=0):
         dist.broadcast(ref, src=0)
         same = bool(torch.allclose(ref, Kt, rtol=0, atol=0))
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), K=K, steps=info["adi_steps"],
-                 solved=len(ops.lus), same=same, parts=info["col_parts"])
+                 solved=len(ops.lus), same=same, parts=info["col_parts"],
+                 owners=np.array(info["owners"] if info["owners"] is not None else [-1]),
+                 mine=np.array(sorted(ops.lus)))
     finally:
         dist.destroy_process_group()
 
@@ -209,8 +221,15 @@ def test_two_ranks_gloo(tmp_path):
     r1 = np.load(tmp_path / "rank1.npz")
     assert bool(r0["same"]) and bool(r1["same"])
     assert np.array_equal(r0["K"], r1["K"])
-    # each rank only ever factorised its own half of the shifts
-    assert int(r0["solved"]) == 4 and int(r1["solved"]) == 4
+    # each rank only ever factorised its OWN shifts: the fixed owners of the library's dealing
+    # (ricadi_host_deal -- the same table the sharded sweeps inside libricadi_hip.so use)
+    from optconpy_amd import _lib
+    ms8 = pb.logshifts(1.0, 500.0, 8)
+    own = _lib.host_deal(ms8, 2)
+    assert np.array_equal(r0["owners"], own) and np.array_equal(r1["owners"], own)
+    assert np.allclose(r0["mine"], sorted(p for p, o in zip(ms8, own) if o == 0))
+    assert np.allclose(r1["mine"], sorted(p for p, o in zip(ms8, own) if o == 1))
+    assert int(r0["solved"]) + int(r1["solved"]) == 8
     pr, F, W, tb = _problem()
     ms = pb.logshifts(1.0, 500.0, 8)
     d = dict(adi_max_steps=200, adi_newZ_reltol=1e-9, ms=ms)
