@@ -68,9 +68,10 @@ typedef struct ricadi_opts {
                             0.55 k_v + k_p <= coarse_max (n ~ 1e5 keeps agg_v / agg_p).  A harder-
                             coarsened child makes GMRES stagnate              */
   int verbose;
-  int compress_qr;       /* ricadi_compress: 0 = Gram matrix + eigendecomposition
-                            (fast; resolves singular values down to sqrt(eps)*s_1),
-                            1 = TSQR block QR + SVD of R (resolves them to eps*s_1) */
+  int compress_qr;       /* ricadi_compress: 1 (default) = thin block QR + SVD of R, the reference's
+                            "QR ... SVD" (singular values resolved to eps*s_1), for factors of up to
+                            1024 columns -- wider ones take the Gram route;  0 = always Gram matrix +
+                            eigendecomposition (resolves singular values down to sqrt(eps)*s_1)      */
 } ricadi_opts;
 
 /* Parameters of the ADI / Newton loops; same meaning as the keys of the

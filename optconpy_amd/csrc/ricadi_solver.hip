@@ -2580,7 +2580,7 @@ void ricadi_default_opts(ricadi_opts* o) {
   o->use_coarse = 1;
   o->max_levels = 3;
   o->verbose = 0;
-  o->compress_qr = 0;
+  o->compress_qr = 1;
 }
 
 void ricadi_default_adi_params(ricadi_adi_params* p) {
@@ -3796,7 +3796,12 @@ int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int k
   }
   out.alloc((size_t)c->nv * cz);
   std::vector<double> sv;
-  int k = compress_dev(c, dZ, cz, ld, thresh, kmax, false, out.p, &sv, c->opts.compress_qr != 0);
+  // the reference's route -- thin QR, then SVD of R ("QR ... SVD", optcont_main.py:133-134) -- up to 1024 columns
+  // (the factors the Newton iteration returns are recompressed to a few hundred); raw factors beyond that take the
+  // Gram route (singular values resolved to sqrt(eps) sigma_1 instead of eps sigma_1): an O(n c^2) block QR with
+  // re-orthogonalisation of thousands of columns costs seconds
+  const bool qr_route = c->opts.compress_qr != 0 && cz <= 1024;
+  int k = compress_dev(c, dZ, cz, ld, thresh, kmax, false, out.p, &sv, qr_route);
   *k_out = k;
   if (k > 0) {
     HIPCHK(hipMemcpyAsync(Zc_out, out.p, sizeof(double) * c->nv * k, hipMemcpyDeviceToHost, c->st));

@@ -135,8 +135,10 @@ def compress_Zsvd(Z, thresh=None, k=None, shplot=False):
     """Column compression ``Zc Zc^T ~ Z Z^T`` (``solve_dae_ric.py:162-163``).
 
     Keeps the singular values above ``thresh`` (absolute) and at most ``k``.
-    On the GPU: Gram matrix ``Z^T Z`` on the FP64 matrix cores, symmetric
-    eigendecomposition, ``Zc = Z V_k``.  ``shplot`` is accepted and ignored.
+    On the GPU, as the reference's comment has it ("QR ... SVD", ``optcont_main.py:133-134``):
+    thin block QR of ``Z`` on the FP64 matrix cores, SVD of the small ``R``, ``Zc = Z V_k``
+    (factors wider than 1024 columns, or ``backend.configure(compress_qr=0)``: Gram matrix +
+    symmetric eigendecomposition).  ``shplot`` is accepted and ignored.
     """
     Z = _dense(Z)
     ctx = backend.context_dims(Z.shape[0])
