@@ -177,7 +177,9 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
         "dots": ("ricadi::cols_dots_kernel (+reduce_partials)", G * ((nvec * b + 8.0) * n * m)),
         "update_dots": ("ricadi::cols_update_dots_kernel (+reduce_partials)", G * ((nvec * b + 16.0) * n * m)),
         # ... + w read + the new vector in storage precision (+ its FP64 copy unless the preconditioner reads the FP16 one)
-        "update": ("ricadi::cols_update_kernel", G * ((nvec * b + 8.0 + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
+        "update": ("ricadi::cols_update16_hess_kernel (last Arnoldi pass + Hessenberg / Givens update)" if b == 2 and m == 16
+                   and os.environ.get("RICADI_HESS_FUSE", "1") != "0" else "ricadi::cols_update_kernel",
+                   G * ((nvec * b + 8.0 + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
     }
     out = {}
     for key, (kname, nbytes) in models.items():

@@ -395,6 +395,14 @@ void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, con
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                             const ProlongArgs& pa);
 
+// K3h: last Arnoldi pass + Hessenberg / Givens update in one launch (FP16 basis, m = 16)
+bool update_hess_fused_ok(int m, bool fp16_basis);
+void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                 size_t vstride, size_t gsb, const double* h1, const double* h2, size_t gsh, int use_sum,
+                                 const double* w, size_t gsw, double* out, size_t gso, _Float16* outf, size_t gsf, int j,
+                                 int restart, double* H, double* cs, double* sn, double* g, const double* resid_in,
+                                 double* resid_out, const double* bnorm, double tol, double* host_resid);
+
 void set_error(const std::string& msg);
 
 }  // namespace ricadi

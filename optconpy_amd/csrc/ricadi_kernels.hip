@@ -3701,4 +3701,143 @@ void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, con
                      gso, pa);
 }
 
+// ---------------------------------------------------------------------------
+// K3h: the last Arnoldi pass of the hot path (FP16-stored basis, 16 columns) WITH the Hessenberg / Givens update
+// in the same launch -- one dependent launch per iteration less.  Every workgroup derives the normalisation
+// 1 / h_{j+1,j} of its 16 columns itself from the (already reduced) Gram-Schmidt coefficients,
+//     h_{j+1,j}^2 = ||w'||^2 - sum_i h2_i^2,   frozen columns (converged, or exact breakdown) -> 0,
+// so nothing it needs comes from another workgroup of the launch; workgroup 0 of every group ALSO does what
+// gmres_hess_kernel did (column of H through the stored rotations, new rotation, g, residual estimate into
+// pinned host memory).  The residual estimates are double buffered (resid_in read by everybody, resid_out
+// written by workgroup 0): a value that decides "frozen" must not change under the other workgroups' feet.
+//   use_sum = 1: w is the vector BEFORE the first projection, coefficients h1 + h2 (cols_update_dots16<.., false>);
+//   use_sum = 0: w has been projected once, coefficients h2.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cols_update16_hess_kernel(
+    GroupTab gt, size_t nhalf, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
+    const double* __restrict__ h1, const double* __restrict__ h2, size_t gsh, int use_sum,
+    const double* __restrict__ w, size_t gsw, double* __restrict__ out, size_t gso, _Float16* __restrict__ outf,
+    size_t gsf, int j, int restart, double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
+    double* __restrict__ g, const double* __restrict__ resid_in, double* __restrict__ resid_out,
+    const double* __restrict__ bnorm, double tol, double* __restrict__ host_resid) {
+  extern __shared__ double hl[];           // nvec x 16 coefficients, then 16 scales
+  const int m = 16;
+  const int grp = gt.gid[blockIdx.z];
+  basis += (size_t)grp * gsb;
+  h1 += (size_t)grp * gsh;
+  h2 += (size_t)grp * gsh;
+  w += (size_t)grp * gsw;
+  if (out) out += (size_t)grp * gso;
+  outf += (size_t)grp * gsf;
+  double* scl = hl + nvec * m;
+  const double tiny = 1e-300;
+  for (int e = threadIdx.x; e < nvec * m; e += 256) hl[e] = use_sum ? h1[e] + h2[e] : h2[e];
+  double hnext = 0.0;
+  if (threadIdx.x < m) {
+    const int c = threadIdx.x;
+    double h2sq = 0.0;
+    for (int i = 0; i < nvec; ++i) {
+      const double b = h2[i * m + c];
+      h2sq = fma(b, b, h2sq);
+    }
+    const double hn2 = h2[nvec * m + c] - h2sq;          // ||w'||^2 before the second projection, minus it
+    hnext = hn2 > 0.0 ? sqrt(hn2) : 0.0;
+    const double rprev = resid_in[(size_t)grp * m + c];  // |g_j|
+    if (!(hnext > tiny) || rprev <= 0.01 * tol * bnorm[(size_t)grp * m + c]) hnext = 0.0;   // frozen column
+    scl[c] = hnext > tiny ? 1.0 / hnext : 0.0;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < m) {
+    // the Hessenberg column of this iteration (what gmres_hess_kernel did), one lane per panel column
+    const int c = threadIdx.x;
+    const size_t gq = (size_t)grp;
+    double* Hc = H + gq * m * (restart + 1) * restart + (size_t)c * (restart + 1) * restart + (size_t)j * (restart + 1);
+    double* csc = cs + gq * m * restart + (size_t)c * restart;
+    double* snc = sn + gq * m * restart + (size_t)c * restart;
+    double* gc = g + gq * m * (restart + 1) + (size_t)c * (restart + 1);
+    const double gj = gc[j];
+    double cur = h1[c] + h2[c];
+    for (int i = 0; i < j; ++i) {
+      const double nxt = h1[(i + 1) * m + c] + h2[(i + 1) * m + c];
+      const double t = csc[i] * cur + snc[i] * nxt;
+      const double u = -snc[i] * cur + csc[i] * nxt;
+      Hc[i] = t;
+      cur = u;
+    }
+    const double d = hypot(cur, hnext);
+    double cj = 1.0, sj = 0.0;
+    if (d > tiny) {
+      cj = cur / d;
+      sj = hnext / d;
+    }
+    csc[j] = cj;
+    snc[j] = sj;
+    Hc[j] = (d > tiny) ? d : 1.0;          // keep R non-singular for frozen columns
+    Hc[j + 1] = 0.0;
+    gc[j + 1] = (d > tiny) ? -sj * gj : 0.0;
+    gc[j] = (d > tiny) ? cj * gj : 0.0;
+    const double rnew = (d > tiny) ? fabs(sj * gj) : 0.0;
+    resid_out[gq * m + c] = rnew;
+    if (host_resid) host_resid[gq * m + c] = rnew;
+  }
+  for (size_t idx = blockIdx.x * (size_t)256 + threadIdx.x; idx < nhalf; idx += (size_t)gridDim.x * 256) {
+    const size_t e = idx * 8;
+    const int c0 = (int)(idx & 1) * 8;
+    double a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = 0.0;
+    const _Float16* v = basis + e;
+    int i = 0;
+    for (; i + 3 < nvec; i += 4) {
+      half8_t x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const half8_t*>(v + (size_t)(i + u) * vstride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) a[t] = fma(hl[(i + u) * m + c0 + t], (double)x[u][t], a[t]);
+    }
+    for (; i < nvec; ++i) {
+      const half8_t x = *reinterpret_cast<const half8_t*>(v + (size_t)i * vstride);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) a[t] = fma(hl[i * m + c0 + t], (double)x[t], a[t]);
+    }
+    const double2* wp = reinterpret_cast<const double2*>(w + e);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double2 ww = wp[t];
+      a[2 * t] = (ww.x - a[2 * t]) * scl[c0 + 2 * t];
+      a[2 * t + 1] = (ww.y - a[2 * t + 1]) * scl[c0 + 2 * t + 1];
+    }
+    half8_t f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f[t] = (_Float16)a[t];
+      a[t] = (double)f[t];
+    }
+    *reinterpret_cast<half8_t*>(outf + e) = f;
+    if (out) {
+      double2* op = reinterpret_cast<double2*>(out + e);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) op[t] = make_double2(a[2 * t], a[2 * t + 1]);
+    }
+  }
+}
+bool update_hess_fused_ok(int m, bool fp16_basis) {
+  static const bool on = !(getenv("RICADI_HESS_FUSE") && atoi(getenv("RICADI_HESS_FUSE")) == 0);
+  return on && fp16_basis && m == 16 && arnoldi16(4);
+}
+void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                 size_t vstride, size_t gsb, const double* h1, const double* h2, size_t gsh, int use_sum,
+                                 const double* w, size_t gsw, double* out, size_t gso, _Float16* outf, size_t gsf, int j,
+                                 int restart, double* H, double* cs, double* sn, double* g, const double* resid_in,
+                                 double* resid_out, const double* bnorm, double tol, double* host_resid) {
+  if (gt.ng <= 0) return;
+  const size_t nhalf = (size_t)nrows * 2;
+  const int grid = (int)std::min<size_t>((nhalf + 255) / 256, 8192);
+  hipLaunchKernelGGL(cols_update16_hess_kernel, dim3(grid, 1, gt.ng), dim3(256), (size_t)(nvec * 16 + 16) * sizeof(double),
+                     st, gt, nhalf, nvec, basis, vstride, gsb, h1, h2, gsh, use_sum, w, gsw, out, gso, outf, gsf, j, restart,
+                     H, cs, sn, g, resid_in, resid_out, bnorm, tol, host_resid);
+}
+
 }  // namespace ricadi

@@ -430,7 +430,7 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   c->sn.alloc(gm * restart);
   c->g.alloc(gm * (restart + 1));
   c->scale.alloc(gm);
-  c->resid.alloc(gm);
+  c->resid.alloc(2 * gm);          // two buffers (the fused update + Hessenberg launch alternates between them)
   c->yv.alloc((size_t)restart * gm);
   c->bnorm2.alloc(gm);
   c->nrm2.alloc(gm);
@@ -1124,6 +1124,9 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   const bool adots = b16 && dots_atomic_ok(m);
   // w is not rewritten between the two Gram-Schmidt passes: the final update subtracts V (h1 + h2) from the original w
   const bool keepw = !adots && update_dots_keeps_w(m, b16, restart);
+  // last Arnoldi pass and Hessenberg update in ONE launch (K3h)
+  const bool fuseh = !adots && update_hess_fused_ok(m, b16);
+  const size_t resbuf = (size_t)c->wcols;                    // doubles between the two residual-estimate buffers
   struct NoStoreScope {
     explicit NoStoreScope(bool v) { set_update_dots_nostore(v); }
     ~NoStoreScope() { set_update_dots_nostore(false); }
@@ -1273,11 +1276,18 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       // the residual estimates also go straight to a pinned host slot (read one
       // iteration later, behind the event below)
       double* cur = hb + 2 * slot + (size_t)(j & 1) * slot;
-      launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
-                          c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, adots ? c->h1.p : nullptr,
-                          adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr,
-                          keepw ? c->h2.p + h2buf : nullptr);
-      if (b16)
+      if (fuseh)
+        launch_cols_update16_hess_b(st, bt.tab, n, j + 1, Vh, vs, nm, c->h1.p, h2cur, gsh, keepw ? 1 : 0, c->wv.p, nm,
+                                    h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm, j, restart, c->H.p,
+                                    c->cs.p, c->sn.p, c->g.p, c->resid.p + (size_t)(j & 1) * resbuf,
+                                    c->resid.p + (size_t)((j + 1) & 1) * resbuf, c->bnorm2.p, tol, cur);
+      else
+        launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
+                            c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, adots ? c->h1.p : nullptr,
+                            adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr,
+                            keepw ? c->h2.p + h2buf : nullptr);
+      if (fuseh) {
+      } else if (b16)
         launch_cols_update_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, keepw ? c->h2.p + h2buf : h2cur, gsh, -1.0, c->wv.p, nm,
                              c->scale.p, h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm);
       else if (b32)
@@ -3362,6 +3372,11 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
   HIPCHK(hipMemsetAsync(c->h1.p, 0x3C, sizeof(double) * gsh * ng, st));
   HIPCHK(hipMemsetAsync(c->h2.p, 0x3C, sizeof(double) * gsh * ng, st));
   HIPCHK(hipMemsetAsync(c->scale.p, 0x3C, sizeof(double) * (size_t)ng * m, st));
+  HIPCHK(hipMemsetAsync(c->resid.p, 0x3C, sizeof(double) * 2 * c->wcols, st));
+  HIPCHK(hipMemsetAsync(c->bnorm2.p, 0x3C, sizeof(double) * (size_t)ng * m, st));
+  HIPCHK(hipMemsetAsync(c->g.p, 0x3C, sizeof(double) * (size_t)ng * m * (restart + 1), st));
+  HIPCHK(hipMemsetAsync(c->cs.p, 0x3C, sizeof(double) * (size_t)ng * m * restart, st));
+  HIPCHK(hipMemsetAsync(c->sn.p, 0x3C, sizeof(double) * (size_t)ng * m * restart, st));
   if (c->kc > 0) {
     HIPCHK(hipMemsetAsync(c->rc.p, 0x3C, sizeof(double) * bt.gsc * ng, st));
     HIPCHK(hipMemsetAsync(c->ec.p, 0x3C, sizeof(double) * bt.gsc * ng, st));
@@ -3447,7 +3462,12 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         set_update_dots_nostore(false);
         break;
       case 7:
-        if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
+        if (b16 && !dots_atomic_ok(m) && update_hess_fused_ok(m, b16))     // as the iteration launches it: with the Hessenberg update
+          launch_cols_update16_hess_b(st, gt, n, nvec, Vh, vs, nm, c->h1.p, c->h2.p, gsh, update_dots_keeps_w(m, b16, restart) ? 1 : 0,
+                                      c->wv.p, nm, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm,
+                                      nvec - 1, restart, c->H.p, c->cs.p, c->sn.p, c->g.p, c->resid.p, c->resid.p + c->wcols,
+                                      c->bnorm2.p, c->opts.gmres_tol, nullptr);
+        else if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
         else if (b32) launch_cols_update_b(st, gt, n, m, nvec, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vf + (size_t)nvec * vs, nm);
         else launch_cols_update_b(st, gt, n, m, nvec, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, V + (size_t)nvec * vs, nm);
         break;
