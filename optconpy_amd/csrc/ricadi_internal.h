@@ -231,8 +231,8 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
                           size_t gsh, double sign, const double* w, size_t gsw, const double* scale,
                           double* out, size_t gso, _Float16* outf, size_t gsf);
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
-                           const _Float16* basis, size_t vstride, size_t gsb, const double* h,
-                           size_t gsh, double* out, size_t gso);
+                           const _Float16* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso, const double* acc = nullptr, size_t gsa = 0);
 // FP32-stored Krylov basis (arithmetic stays FP64): overloads reading `const float* basis`
 void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
                         const float* basis, size_t vstride, size_t gsb, const double* w, size_t gsw,
@@ -276,11 +276,11 @@ void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nr
 void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
                               int restart, const double* H, const double* g, double* y);
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
-                           const double* basis, size_t vstride, size_t gsb, const double* h,
-                           size_t gsh, double* out, size_t gso);
+                           const double* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso, const double* acc = nullptr, size_t gsa = 0);
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
                            const float* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
-                           double* out, size_t gso);
+                           double* out, size_t gso, const double* acc = nullptr, size_t gsa = 0);
 void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart,
                           const double* nrm2, double* g, double* scale, double* resid);
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,

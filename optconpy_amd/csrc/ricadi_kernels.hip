@@ -1723,21 +1723,24 @@ void launch_cols_update_b(hipStream_t st, const GroupTab& gt, int nrows, int m, 
 }
 // correction step of a restart cycle: group g combines its first nvec.v[g] vectors
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
-                           const double* basis, size_t vstride, size_t gsb, const double* h,
-                           size_t gsh, double* out, size_t gso) {
-  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                           const double* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso, const double* acc, size_t gsa) {
+  // acc (optional): out = acc + sum; acc may be `out` itself (every thread reads its elements before it writes them)
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, acc, gsa,
                    (const double*)nullptr, out, gso, (double*)nullptr, 0);
 }
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
-                           const _Float16* basis, size_t vstride, size_t gsb, const double* h,
-                           size_t gsh, double* out, size_t gso) {
-  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                           const _Float16* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
+                           double* out, size_t gso, const double* acc, size_t gsa) {
+  // acc (optional): out = acc + sum; acc may be `out` itself (every thread reads its elements before it writes them)
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, acc, gsa,
                    (const double*)nullptr, out, gso, (_Float16*)nullptr, 0);
 }
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,
                            const float* basis, size_t vstride, size_t gsb, const double* h, size_t gsh,
-                           double* out, size_t gso) {
-  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, (const double*)nullptr, 0,
+                           double* out, size_t gso, const double* acc, size_t gsa) {
+  // acc (optional): out = acc + sum; acc may be `out` itself (every thread reads its elements before it writes them)
+  cols_update_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, h, gsh, 1.0, acc, gsa,
                    (const double*)nullptr, out, gso, (float*)nullptr, 0);
 }
 void launch_cols_update(hipStream_t st, int nrows, int m, int nvec, const double* basis,

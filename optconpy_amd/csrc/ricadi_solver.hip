@@ -1187,9 +1187,12 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
           HIPCHK(hipMemcpyAsync(c->wv.p + (size_t)g * nm, b + (size_t)g * gsb, sizeof(double) * nm,
                                 hipMemcpyDeviceToDevice, st));
       }
-    } else {
+    } else if (lowrank && c->q > 0) {
       op_apply(c, bt, x, nm, c->wv.p, lowrank);
       launch_axpby_b(st, bt.tab, nm, 1.0, b, gsb, -1.0, c->wv.p, nm);
+    } else {
+      // r = b - S x in one launch (the residual form of the SpMM)
+      saddle_spmm(c, bt, x, nm, nullptr, c->wv.p, nm, b, gsb, -1.0, 1.0);
     }
     first = false;
     norms2(c->wv.p, nm, c->nrm2.p);
@@ -1323,8 +1326,8 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       GroupInts ks = same_int(0);
       for (int g : act) ks.v[g] = kk[g];
       launch_gmres_backsolve_b(st, bt.tab, m, ks, restart, c->H.p, c->g.p, c->yv.p);
-      if (flex)
-        launch_cols_update_bk(st, bt.tab, n, m, ks, c->zbasisf.p, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
+      if (flex)      // x += Z y in one launch
+        launch_cols_update_bk(st, bt.tab, n, m, ks, c->zbasisf.p, vs, nm, c->yv.p, (size_t)restart * m, x, nm, x, nm);
       else if (b16)
         launch_cols_update_bk(st, bt.tab, n, m, ks, Vh, vs, nm, c->yv.p, (size_t)restart * m, c->wv.p, nm);
       else if (b32)
@@ -1334,7 +1337,6 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
     }
     bt.set(act);
     if (flex) {
-      launch_axpby_b(st, bt.tab, nm, 1.0, c->wv.p, nm, 1.0, x, nm);
     } else {
       precond_apply(c, bt, c->wv.p, nm, c->zv.p);
       launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
