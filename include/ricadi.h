@@ -207,6 +207,14 @@ int ricadi_ric_newtonadi(ricadi_ctx* ctx, const double* shifts, int nshifts,
 int ricadi_compress(ricadi_ctx* ctx, const double* Z, int c, double thresh, int kmax,
                     double* Zc_out, int* k_out, double* sv_out);
 
+/* The recompression the ADI / Newton drivers apply to their own factor while it grows (no counterpart
+ * in the reference, which compresses once through pru.compress_Zsvd,
+ * /root/reference/solve_dae_ric.py:161-165): Zc with Zc Zc^T = Z Z^T up to rel^2 ||Z Z^T||, by a pivoted
+ * Cholesky factorisation of the Gram matrix and an orthonormalisation of its factor's rows -- no
+ * eigensolver, no singular values.  Exposed for tests and timing; `rel` <= 0 takes the drivers' own
+ * level (3e-8).  Zc_out must hold NV x c doubles; *k_out columns are written (row-major, ld = *k_out).  */
+int ricadi_recompress(ricadi_ctx* ctx, const double* Z, int c, double rel, double* Zc_out, int* k_out);
+
 /* ---- a4: factored product  E * (Z * (Z^T * B)) -------------------------
  * pru.get_mTzzTtb(MT, Z, tb) (/root/reference/optcont_main.py:505-506,
  * solve_dae_ric.py:101,183,189); the feedback gain is its negative.

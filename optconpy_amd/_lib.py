@@ -20,7 +20,7 @@ RICADI_ENOCONV = -3
 MAX_M = 128
 # ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
 # are part of the ABI and are not covered by the struct handshake below
-ABI_VERSION = 300
+ABI_VERSION = 301
 
 
 class RicadiOpts(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_int), _dp]),
     "ricadi_compress": (C.c_int, [_vp, _dp, C.c_int, C.c_double, C.c_int, _dp,
                                   C.POINTER(C.c_int), _dp]),
+    "ricadi_recompress": (C.c_int, [_vp, _dp, C.c_int, C.c_double, _dp, C.POINTER(C.c_int)]),
     "ricadi_gain": (C.c_int, [_vp, _ip, _ip, _dp, _dp, C.c_int, _dp, C.c_int, _dp]),
     "ricadi_lyap_res_norm": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp]),
     "ricadi_factor_cols": (C.c_int, [_vp, C.POINTER(C.c_int)]),
@@ -489,6 +490,17 @@ class Context:
                                        0 if k is None else int(k), _d(out), C.byref(kk), _d(sv)))
         kk = kk.value
         return out.ravel()[:self.nv * kk].reshape(self.nv, kk).copy(), sv[:min(c, self.nv)]
+
+    def recompress(self, Z, rel=0.0):
+        """The drivers' internal recompression (pivoted Cholesky of the Gram matrix, no eigensolver):
+        ``Zc`` with ``Zc Zc^T = Z Z^T`` up to ``rel^2 ||Z Z^T||`` (``rel=0``: the drivers' own level)."""
+        Z = as_panel(Z, self.nv)
+        c = Z.shape[1]
+        out = np.empty((self.nv, c))
+        kk = C.c_int(0)
+        _chk(self._lib.ricadi_recompress(self._h, _d(Z), c, float(rel), _d(out), C.byref(kk)))
+        kk = kk.value
+        return out.ravel()[:self.nv * kk].reshape(self.nv, kk).copy()
 
     def gain(self, B, Z=None, MT=None):
         """``MT (Z (Z^T B))`` with ``MT`` = calE of the context when None."""

@@ -403,6 +403,23 @@ void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, 
                                  int restart, double* H, double* cs, double* sn, double* g, const double* resid_in,
                                  double* resid_out, const double* bnorm, double tol, double* host_resid);
 
+// K5c: pivoted Cholesky of a (possibly augmented) symmetric matrix, 8 / 16 / 32 pivots per launch pair --
+// the eigensolver-free recompression (ricadi_kernels.hip).  State lives on the device so that the host can
+// issue all blocks without a read-back: once `stop` is set the remaining launches return at once.
+struct PcholState {
+  double d0;     // first pivot (scale of the tolerance)
+  int rank;      // rows of the factor written so far
+  int stop;      // 1: tolerance / row limit reached
+  int nblk;      // rows written by the last panel launch
+  int pad;
+};
+int pchol_block(int nc);          // pivots per panel launch for nc columns (0: nc too large)
+void launch_pchol_panel(hipStream_t st, const double* A, int ld, int nr, int nc, double tol, int kmax,
+                        PcholState* stt, double* Rout, int ldr, int* done);
+void launch_pchol_trail(hipStream_t st, double* A, int ld, int nr, int nc, const PcholState* stt,
+                        const double* Rall, int ldr);
+void launch_transpose(hipStream_t st, int rows, int cols, const double* in, int ldi, double* out, int ldo);
+
 void set_error(const std::string& msg);
 
 }  // namespace ricadi

@@ -3543,6 +3543,227 @@ void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const dou
   hipLaunchKernelGGL(transpose_sign_kernel, dim3(grid), dim3(256), 0, st, k, k1, sneg, in, out);
 }
 
+// out[j, i] = in[i, j]  (rows x cols -> cols x rows, both row-major with their own leading dimensions)
+__global__ void transpose_kernel(int rows, int cols, const double* __restrict__ in, int ldi,
+                                 double* __restrict__ out, int ldo) {
+  __shared__ double tile[32][33];
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows of the tile per pass
+  for (int r = ty; r < 32; r += 8)
+    tile[r][tx] = (i0 + r < rows && j0 + tx < cols) ? in[(size_t)(i0 + r) * ldi + j0 + tx] : 0.0;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (j0 + r < cols && i0 + tx < rows) out[(size_t)(j0 + r) * ldo + i0 + tx] = tile[tx][r];
+}
+void launch_transpose(hipStream_t st, int rows, int cols, const double* in, int ldi, double* out, int ldo) {
+  if (rows <= 0 || cols <= 0) return;
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, rows, cols,
+                     in, ldi, out, ldo);
+}
+
+// ---------------------------------------------------------------------------
+// K5c: pivoted Cholesky in blocks (LAPACK dpstrf's scheme: inside a block the pivots are chosen from
+// the lazily updated diagonal, the trailing matrix is updated once per block).
+//
+// The matrix is nr x nc, nc >= nr, row-major: its leading nr x nr part is symmetric positive
+// semi-definite, columns nr.. are carried along (the factor's rows then hold R^-T times them: one
+// factorisation of [H | B] gives chol(H) AND the triangular solve with B).  Nothing is swapped: row j of
+// the factor belongs to pivot j and keeps the ORIGINAL column order, with exact zeros in the columns of
+// earlier pivots.
+//
+// pchol_panel_kernel: ONE workgroup, one thread per column (CPT columns per thread beyond 1024); the
+// thread keeps its entries of the block's rows in registers.  Per pivot: argmax of the current diagonal
+// (wave shuffles + 16 LDS slots), the owner of the pivot column publishes its block entries, every
+// thread forms its entry of the new row from row `p` of the trailing matrix.  Two barriers per pivot.
+// pchol_trail_kernel:  A -= R_b^T R_b over all nr x nc entries (64 x 64 tiles).
+// ---------------------------------------------------------------------------
+// One pivot step (J = position in the block: a template parameter, so that the thread's block entries
+// rb[.][J] are registers -- inside a loop, even a fully unrolled one, the array went to scratch memory).
+template <int CPT, int NB, int J>
+__device__ __forceinline__ void pchol_steps(const double* __restrict__ A, int ld, int nr, int nc, double tol, int kmax,
+                                            int rank0, double* __restrict__ Rout, int ldr, int* __restrict__ done,
+                                            double (&rb)[CPT][NB], double (&base)[CPT], double (&dots)[CPT],
+                                            bool (&cand)[CPT], bool (&zero)[CPT], double& d0, int& made,
+                                            bool& stopped, double* s_rp, double* s_val, int* s_idx) {
+  if constexpr (J < NB) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (stopped) return;                      // uniform
+    if (rank0 + J >= kmax) {
+      stopped = true;
+      return;
+    }
+    // pivot = largest remaining diagonal entry (lowest index on ties)
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const double v = base[q] - dots[q];
+      if (cand[q] && v > bv) {
+        bv = v;
+        bi = tid + q * 1024;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      s_val[wv] = bv;
+      s_idx[wv] = bi;
+    }
+    __syncthreads();
+    bv = s_val[0];
+    bi = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+      const double ov = s_val[w];
+      const int oi = s_idx[w];
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    const int p = bi;
+    const double dp = bv;
+    if (rank0 + J == 0) d0 = dp;
+    if (!(dp > tol * d0) || !(dp > 0.0) || p >= nr) {     // uniform: every thread holds the same (p, dp)
+      stopped = true;
+      return;
+    }
+    if (tid == (p & 1023)) {
+#pragma unroll
+      for (int q = 0; q < CPT; ++q)
+        if (q == (p >> 10)) {
+#pragma unroll
+          for (int i = 0; i < J; ++i) s_rp[i] = rb[q][i];
+        }
+    }
+    __syncthreads();
+    const double sq = sqrt(dp), inv = 1.0 / sq;
+    const double* __restrict__ arow = A + (size_t)p * ld;
+    double* __restrict__ rrow = Rout + (size_t)(rank0 + J) * ldr;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+      const int t = tid + q * 1024;
+      if (t < nc) {
+        double acc = arow[t];
+#pragma unroll
+        for (int i = 0; i < J; ++i) acc = fma(-s_rp[i], rb[q][i], acc);
+        double r = zero[q] ? 0.0 : acc * inv;
+        if (t == p) {
+          r = sq;
+          cand[q] = false;
+          zero[q] = true;
+          done[t] = 1;
+        }
+        rb[q][J] = r;
+        dots[q] = fma(r, r, dots[q]);
+        rrow[t] = r;
+      }
+    }
+    made = J + 1;
+    pchol_steps<CPT, NB, J + 1>(A, ld, nr, nc, tol, kmax, rank0, Rout, ldr, done, rb, base, dots, cand, zero, d0,
+                                made, stopped, s_rp, s_val, s_idx);
+  }
+}
+
+template <int CPT, int NB>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void pchol_panel_kernel(
+    const double* __restrict__ A, int ld, int nr, int nc, double tol, int kmax, PcholState* __restrict__ stt,
+    double* __restrict__ Rout, int ldr, int* __restrict__ done) {
+  if (stt->stop) return;                      // uniform
+  __shared__ double s_rp[NB];
+  __shared__ double s_val[16];
+  __shared__ int s_idx[16];
+  const int tid = threadIdx.x;
+  const int rank0 = stt->rank;
+  double d0 = stt->d0;
+  double rb[CPT][NB], base[CPT], dots[CPT];
+  bool cand[CPT], zero[CPT];
+#pragma unroll
+  for (int q = 0; q < CPT; ++q) {
+    const int t = tid + q * 1024;
+    const bool isdone = t < nr ? done[t] != 0 : false;
+    base[q] = t < nr ? A[(size_t)t * ld + t] : 0.0;
+    dots[q] = 0.0;
+    cand[q] = t < nr && !isdone;
+    zero[q] = isdone;
+  }
+  int made = 0;
+  bool stopped = false;
+  pchol_steps<CPT, NB, 0>(A, ld, nr, nc, tol, kmax, rank0, Rout, ldr, done, rb, base, dots, cand, zero, d0, made,
+                          stopped, s_rp, s_val, s_idx);
+  if (tid == 0) {
+    stt->d0 = d0;
+    stt->rank = rank0 + made;
+    stt->nblk = made;
+    if (stopped || rank0 + made >= kmax) stt->stop = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void pchol_trail_kernel(double* __restrict__ A, int ld, int nr, int nc,
+                                                          const PcholState* __restrict__ stt,
+                                                          const double* __restrict__ Rall, int ldr) {
+  if (stt->stop) return;                      // the factorisation ended with the last panel
+  const int nb = stt->nblk;
+  const double* __restrict__ Rb = Rall + (size_t)(stt->rank - nb) * ldr;
+  __shared__ double sa[32][64], sb[32][64];
+  const int i0 = blockIdx.y * 64, t0 = blockIdx.x * 64, tid = threadIdx.x;
+  for (int e = tid; e < 32 * 64; e += 256) {
+    const int j = e >> 6, x = e & 63;
+    sa[j][x] = (j < nb && i0 + x < nr) ? Rb[(size_t)j * ldr + i0 + x] : 0.0;
+    sb[j][x] = (j < nb && t0 + x < nc) ? Rb[(size_t)j * ldr + t0 + x] : 0.0;
+  }
+  __syncthreads();
+  const int ti = (tid >> 4) * 4, tj = (tid & 15) * 4;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int j = 0; j < nb; ++j) {
+    double av[4], bw[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) av[a] = sa[j][ti + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bw[b] = sb[j][tj + b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bw[b], acc[a][b]);
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ti + a, t = t0 + tj + b;
+      if (i < nr && t < nc) A[(size_t)i * ld + t] -= acc[a][b];
+    }
+}
+int pchol_block(int nc) { return nc <= 1024 ? 32 : nc <= 2048 ? 16 : nc <= 4096 ? 8 : 0; }
+void launch_pchol_panel(hipStream_t st, const double* A, int ld, int nr, int nc, double tol, int kmax,
+                        PcholState* stt, double* Rout, int ldr, int* done) {
+  if (nc <= 1024)
+    hipLaunchKernelGGL((pchol_panel_kernel<1, 32>), dim3(1), dim3(1024), 0, st, A, ld, nr, nc, tol, kmax, stt,
+                       Rout, ldr, done);
+  else if (nc <= 2048)
+    hipLaunchKernelGGL((pchol_panel_kernel<2, 16>), dim3(1), dim3(1024), 0, st, A, ld, nr, nc, tol, kmax, stt,
+                       Rout, ldr, done);
+  else
+    hipLaunchKernelGGL((pchol_panel_kernel<4, 8>), dim3(1), dim3(1024), 0, st, A, ld, nr, nc, tol, kmax, stt,
+                       Rout, ldr, done);
+}
+void launch_pchol_trail(hipStream_t st, double* A, int ld, int nr, int nc, const PcholState* stt,
+                        const double* Rall, int ldr) {
+  hipLaunchKernelGGL(pchol_trail_kernel, dim3((nc + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, A, ld, nr, nc,
+                     stt, Rall, ldr);
+}
+
 // coarse matrix combine: out = beta*E0 + alpha*EM + EJ  (dense k x k)
 __global__ void combine3_kernel(size_t n, const double* a0, const double* a1, const double* a2,
                                 double alpha, double beta, double* out) {

@@ -1806,11 +1806,15 @@ static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk,
 // changes Z Z^T by at most eps*||Z Z^T|| -- rounding level.
 static const double kInternalRelThresh = 3e-8;
 
+static Exec main_exec(ricadi_ctx* c);
+static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                           double* dOut);
+
 // Recompress the device factor in place (columns [0, zc) of c->Z).
 static void factor_recompress(ricadi_ctx* c) {
   if (c->zc == 0) return;
   TArr<double> tmp(c->pool, (size_t)c->nv * c->zc);
-  const int k = compress_dev(c, c->Z.p, c->zc, c->zld, kInternalRelThresh, 0, true, tmp.p, nullptr);
+  const int k = recompress_exec(c, main_exec(c), c->Z.p, c->zc, c->zld, kInternalRelThresh, tmp.p);
   if (k > 0) launch_copy_cols(c->st, c->nv, k, tmp.p, k, 0, c->Z.p, c->zld, 0, 1.0);
   HIPCHK(hipStreamSynchronize(c->st));
   c->zc = k;
@@ -1819,6 +1823,8 @@ static void factor_recompress(ricadi_ctx* c) {
 static int compress_gram_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz,
                               double thresh, int kmax, bool thresh_relative, double* dOut,
                               std::vector<double>* sv_host);
+static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                           double* dOut);
 
 // Auxiliary stream + handle for work that runs beside the main stream (created on first use).
 static Exec aux_exec(ricadi_ctx* c) {
@@ -1862,7 +1868,7 @@ struct AsyncRecompress {
     double* op = out.p;
     fut = std::async(std::launch::async, [cc, ex, Zp, ld, sn, dev, op]() {
       (void)hipSetDevice(dev);
-      return compress_gram_exec(cc, ex, Zp, sn, ld, kInternalRelThresh, 0, true, op, nullptr);
+      return recompress_exec(cc, ex, Zp, sn, ld, kInternalRelThresh, op);
     });
     active = true;
   }
@@ -2345,6 +2351,86 @@ static int compress_gram_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, i
   return k;
 }
 
+// Recompression without an eigensolver (round 3; the route of the INTERNAL recompressions, which need
+// no singular values -- only Zc Zc^T = Z Z^T to rounding):
+//   G = Z^T Z (MFMA);  pivoted Cholesky  G ~ R^T R,  R k x cz, stopped at rel^2 of the first pivot
+//   (the error of a stopped pivoted Cholesky is the remaining Schur complement, <= its trace);
+//   then the rows of R are orthonormalised: with H = R R^T = L L^T the matrix V^T = L^-1 R has orthonormal
+//   rows spanning the row space of R, and Zc = Z V, Zc Zc^T = Z (V V^T) Z^T is Z Z^T up to that Schur
+//   complement.  chol(H) and the triangular solve are ONE more pivoted Cholesky, of the augmented matrix
+//   [H | R] (its pivoting also drops what the first pass kept beyond the tolerance: the final column
+//   count equals the eigensolver route's, measured +-1).  Even where L is ill-conditioned the product
+//   V V^T is the projector to rounding (the CholQR argument: the error is that of H = L L^T, eps ||H||).
+// rocSOLVER's dsyevd on the same Gram matrix was ~4000 launches (12-16 ms) per call; this is ~60.
+// Returns k; dOut is NV x k (ld k); synchronises ex.st.  Returns -1 when the matrix is too wide for the
+// panel kernel (the caller then takes the eigensolver route).
+static int compress_pchol_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                               double* dOut) {
+  hipStream_t st = ex.st;
+  if (cz == 0) return 0;
+  const int kcap = std::min(cz, c->nv);
+  if (pchol_block(cz) == 0 || pchol_block(cz + kcap) == 0) return -1;
+  const double tol = rel * rel;
+  TArr<double> G(*ex.pool, (size_t)cz * cz), R(*ex.pool, (size_t)kcap * cz), stt(*ex.pool, 8);
+  TArr<int> done(*ex.pool, (size_t)cz + kcap);
+  PcholState* s1 = reinterpret_cast<PcholState*>(stt.p);
+  PcholState* s2 = s1 + 1;
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
+  HIPCHK(hipMemsetAsync(stt.p, 0, sizeof(double) * 8, st));
+  HIPCHK(hipMemsetAsync(done.p, 0, sizeof(int) * ((size_t)cz + kcap), st));
+  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
+  {
+    const int nb = pchol_block(cz);
+    for (int r0 = 0; r0 < kcap; r0 += nb) {
+      launch_pchol_panel(st, G.p, cz, cz, cz, tol, kcap, s1, R.p, cz, done.p);
+      launch_pchol_trail(st, G.p, cz, cz, cz, s1, R.p, cz);
+    }
+  }
+  PcholState h1;
+  HIPCHK(hipMemcpyAsync(&h1, s1, sizeof(PcholState), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int k1 = h1.rank;
+  if (k1 <= 0) return 0;
+  // [H | R] with H = R R^T  (gemm_tn wants the tall operand: R^T, cz x k1)
+  const int nc2 = k1 + cz;
+  TArr<double> Rt(*ex.pool, (size_t)cz * k1), A2(*ex.pool, (size_t)k1 * nc2), R2(*ex.pool, (size_t)k1 * nc2);
+  launch_transpose(st, k1, cz, R.p, cz, Rt.p, k1);
+  HIPCHK(hipMemsetAsync(A2.p, 0, sizeof(double) * (size_t)k1 * nc2, st));
+  launch_gemm_tn(st, cz, k1, k1, Rt.p, k1, Rt.p, k1, A2.p, nc2);
+  launch_copy_cols(st, k1, cz, R.p, cz, 0, A2.p, nc2, k1, 1.0);
+  {
+    const int nb = pchol_block(nc2);
+    int* done2 = done.p + cz;
+    for (int r0 = 0; r0 < k1; r0 += nb) {
+      launch_pchol_panel(st, A2.p, nc2, k1, nc2, tol, k1, s2, R2.p, nc2, done2);
+      launch_pchol_trail(st, A2.p, nc2, k1, nc2, s2, R2.p, nc2);
+    }
+  }
+  PcholState h2;
+  HIPCHK(hipMemcpyAsync(&h2, s2, sizeof(PcholState), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int k = h2.rank;
+  if (k <= 0) return 0;
+  // V = (rows 0..k of the carried part)^T: cz x k;  Zc = Z V
+  TArr<double> V(*ex.pool, (size_t)cz * k);
+  launch_transpose(st, k, cz, R2.p + k1, nc2, V.p, k);
+  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, V.p, k, dOut, k, 1.0, 0.0);
+  HIPCHK(hipStreamSynchronize(st));
+  return k;
+}
+
+// The internal recompressions: pivoted-Cholesky route unless RICADI_RECOMPRESS_EIG=1 (or the factor is too
+// wide for it), then the Gram + eigensolver route.
+static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                           double* dOut) {
+  static const bool eig = getenv("RICADI_RECOMPRESS_EIG") != nullptr;
+  if (!eig) {
+    const int k = compress_pchol_exec(c, ex, dZ, cz, ldz, rel, dOut);
+    if (k >= 0) return k;
+  }
+  return compress_gram_exec(c, ex, dZ, cz, ldz, rel, 0, true, dOut, nullptr);
+}
+
 static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
                         bool thresh_relative, double* dOut, std::vector<double>* sv_host,
                         bool use_qr) {
@@ -2574,7 +2660,7 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 300; }
+int ricadi_version(void) { return 301; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
@@ -3830,6 +3916,23 @@ int ricadi_compress(ricadi_ctx* c, const double* Z, int cz, double thresh, int k
     HIPCHK(hipStreamSynchronize(c->st));
   }
   if (sv_out) std::memcpy(sv_out, sv.data(), sizeof(double) * std::min<size_t>(sv.size(), (size_t)std::min(cz, c->nv)));
+  API_END
+}
+
+int ricadi_recompress(ricadi_ctx* c, const double* Z, int cz, double rel, double* Zc_out, int* k_out) {
+  REQUIRE(c && c->nv > 0, RICADI_ESTATE, "set the operator (or the dimensions) first");
+  REQUIRE(Z && Zc_out && k_out && cz > 0, RICADI_EINVAL, "NULL argument or bad column count");
+  API_BEGIN
+  DArr<double> tmp, out;
+  tmp.alloc((size_t)c->nv * cz);
+  out.alloc((size_t)c->nv * cz);
+  HIPCHK(hipMemcpyAsync(tmp.p, Z, sizeof(double) * c->nv * cz, hipMemcpyHostToDevice, c->st));
+  const int k = recompress_exec(c, main_exec(c), tmp.p, cz, cz, rel > 0.0 ? rel : kInternalRelThresh, out.p);
+  *k_out = k;
+  if (k > 0) {
+    HIPCHK(hipMemcpyAsync(Zc_out, out.p, sizeof(double) * c->nv * k, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+  }
   API_END
 }
 

@@ -153,3 +153,35 @@ def test_two_ranks_full_newton_step_through_the_library_exchange():
     assert d["config"]["K_rel_diff_vs_oracle"] < 1e-6
     assert d["config"]["shift_solves_per_step"] == 177
     assert "PARITY_VIOLATION" not in d["config"]
+
+
+def _graded_factor(nv, c, decades, seed):
+    """nv x c factor with singular values falling over `decades` orders of magnitude, mixed into every
+    column (the shape of a low-rank ADI factor: far more columns than numerical rank)."""
+    rng = np.random.default_rng(seed)
+    r = min(nv, c)
+    Q, _ = np.linalg.qr(rng.standard_normal((nv, r)))
+    V, _ = np.linalg.qr(rng.standard_normal((c, r)))
+    return (Q * np.logspace(0, -decades, r)) @ V.T
+
+
+@pytest.mark.parametrize("nv,c,decades", [(3000, 700, 14), (2500, 1500, 20), (900, 40, 3), (400, 600, 12)])
+def test_recompress_pivoted_cholesky_route(nv, c, decades):
+    """ricadi_recompress (the drivers' internal recompression since round 3: pivoted Cholesky of the Gram
+    matrix + orthonormalised factor rows, no eigensolver): Zc Zc^T = Z Z^T to rounding, the column count
+    that of the optimal truncation at the same level (sqrt(eps) sigma_1) up to a few columns, and
+    range(Zc) inside range(Z) (the reference's compression identity, tests/...compress.py:92-97)."""
+    from optconpy_amd import _lib
+    Z = _graded_factor(nv, c, decades, seed=c)
+    ctx = _lib.Context(0)
+    ctx.set_dims(nv)
+    Zc = ctx.recompress(Z)
+    ctx.close()
+    s = np.linalg.svd(Z, compute_uv=False)
+    k_opt = int((s > 3e-8 * s[0]).sum())
+    X = Z @ Z.T
+    assert np.linalg.norm(Zc @ Zc.T - X) <= 2e-14 * np.linalg.norm(X)
+    assert k_opt - 2 <= Zc.shape[1] <= k_opt + max(6, k_opt // 20), (Zc.shape[1], k_opt)
+    # range(Zc) in range(Z)
+    U = np.linalg.svd(Z, full_matrices=False)[0][:, :min(k_opt + 40, min(Z.shape))]
+    assert np.linalg.norm(Zc - U @ (U.T @ Zc)) <= 1e-7 * np.linalg.norm(Zc)
