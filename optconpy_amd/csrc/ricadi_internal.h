@@ -369,6 +369,7 @@ void launch_tsqr_apply(hipStream_t st, int nrows, int w, const double* Qloc, con
                        double* Qout, int ldq);
 void launch_cholqr_small(hipStream_t st, int w, const double* G, const double* Rprev, double* T,
                          double* R, int* flag);
+void launch_cholqr_wide(hipStream_t st, int w, const double* G, int ldg, double* T, double* R, int* flag);
 void launch_select_evecs(hipStream_t st, int c, int k, const double* evec, double* sel);
 void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
 // batched block Gauss-Jordan inverse of the coarse matrices (ricadi_kernels.hip); nb <= RICADI_MAX_GROUPS matrices

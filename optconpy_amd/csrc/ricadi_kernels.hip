@@ -3510,6 +3510,249 @@ void launch_cholqr_small(hipStream_t st, int w, const double* G, const double* R
   hipLaunchKernelGGL(cholqr_small_kernel, dim3(1), dim3(64), 0, st, w, G, Rprev, T, R, flag);
 }
 
+// ---------------------------------------------------------------------------
+// K5w: the same panel step for panels of up to 128 columns, one workgroup of 256 threads, the
+// 128 x 128 Gram matrix in LDS (132 KB): blocked right-looking Cholesky in 16-column blocks
+//   - the 16 x 16 diagonal block is factorised AND inverted by wave 0 alone, one lane per row, rows in
+//     registers, cross-lane operands by shuffles (no workgroup barrier inside);
+//   - panel  L21 = A21 L11^-T  one thread per row against the explicit 16 x 16 inverse;
+//   - trailing update, 7 x 7 entries per thread;
+// then R = L^T D^-1 goes out and L is overwritten, block row by block row, by its
+// inverse  X[I,J] = -X[I,I] sum_K L[I,K] X[K,J]  (the inverses of the diagonal blocks wait transposed in the
+// unused upper triangle of those blocks until L's diagonal blocks are no longer needed); T = D X^T.
+// Same conventions and breakdown flag as cholqr_small_kernel, except that the second round's
+// R_this * R_prev is left to the caller; G has leading dimension ldg, T and R are 128 x 128 (ld 128).
+// ---------------------------------------------------------------------------
+constexpr int CQW = 128, CQLD = 129;
+#ifdef RICADI_CQ_TIMING
+#define CQT(i) long long cqt##i = wall_clock64()
+#define CQA(i) do { long long t_ = wall_clock64(); if (i > 0) cqa[i - 1] += t_ - cql; cql = t_; } while (0)
+#define CQP() if (tid == 0) printf("cholqr_wide w=%d: load %lld chol %lld [diag %lld panel %lld trail %lld] Rout %lld move %lld inv %lld T %lld (x10ns)\n", w, cqt1-cqt0, cqt2-cqt1, cqa[0], cqa[1], cqa[2], cqt3-cqt2, cqt4-cqt3, cqt5-cqt4, cqt6-cqt5)
+#else
+#define CQT(i)
+#define CQA(i)
+#define CQP()
+#endif
+__global__ __launch_bounds__(256) void cholqr_wide_kernel(int w, const double* __restrict__ G, int ldg,
+                                                          double* __restrict__ T, double* __restrict__ R,
+                                                          int* __restrict__ flag) {
+  extern __shared__ double sm[];
+  double* A = sm;                          // CQW x CQLD
+  double* dsc = A + CQW * CQLD;            // 128: D
+  double* dinv = dsc + CQW;                // 128: D^-1
+  double* xd = dinv + CQW;                 // 128: diagonal of L^-1
+  double* tmp = xd + CQW;                  // 16 x 112: S of a block row
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int nbk = (w + 15) >> 4, wp = nbk * 16;      // blocks / padded width actually worked on
+  bool bad = false;
+#ifdef RICADI_CQ_TIMING
+  long long cqa[3] = {0, 0, 0}, cql = 0;
+#endif
+  CQT(0);
+  if (tid < CQW) {
+    const double gjj = tid < w ? G[(size_t)tid * ldg + tid] : 1.0;
+    if (tid < w && !(gjj > 0.0)) bad = true;
+    dsc[tid] = (tid < w && gjj > 0.0) ? 1.0 / sqrt(gjj) : 0.0;
+    dinv[tid] = (tid < w && gjj > 0.0) ? sqrt(gjj) : 0.0;
+  }
+  __syncthreads();
+  {
+    // thread = (row strip tid >> 5, column tid & 31 (+32 q)): raw loads first (8 rows in flight), then the scaling
+    const int jj = tid & 31, is = tid >> 5;
+    for (int j = jj; j < wp; j += 32)
+      for (int ib = is; ib < wp; ib += 64) {
+        double g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = ib + 8 * q;
+          g[q] = (i < w && j < w) ? G[(size_t)i * ldg + j] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = ib + 8 * q;
+          if (i < wp) {
+            double v;
+            if (i < w && j < w && dsc[i] > 0.0 && dsc[j] > 0.0)
+              v = dsc[i] * dsc[j] * g[q];
+            else
+              v = (i == j) ? 1.0 : 0.0;        // identity padding (columns beyond w, zero columns)
+            A[i * CQLD + j] = v;
+          }
+        }
+      }
+  }
+  __syncthreads();
+  CQT(1);
+  for (int kb = 0; kb < nbk; ++kb) {
+    const int k0 = kb * 16;
+    CQA(0);
+    if (tid < 64) {
+      // wave 0: lane i (< 16) owns row i of the diagonal block
+      const int i = lane & 15;
+      double r[16], x[16], rinv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r[j] = A[(k0 + i) * CQLD + k0 + j];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        double piv = __shfl(r[t], t, 64);
+        if (!(piv > 1e-12)) {
+          bad = true;
+          piv = 1.0;
+        }
+        // 1 / l_tt by the hardware estimate + two Newton steps (no sqrt / division in the dependent chain;
+        // the second CholQR round absorbs the last-bit differences)
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+        rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
+        rinv[t] = rs;
+        r[t] = (i == t) ? piv * rs : r[t] * rs;        // rows i < t hold upper entries nobody reads
+#pragma unroll
+        for (int j = t + 1; j < 16; ++j) r[j] = fma(-r[t], __shfl(r[t], j, 64), r[j]);
+      }
+      // inverse, lane j owns COLUMN j of X = L^-1:  x_jj = 1 / l_jj,  x_ij = -(sum_{k<i} l_ik x_kj) / l_ii
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < ii; ++k) {
+          if (k & 1) s1 = fma(__shfl(r[k], ii, 64), x[k], s1);
+          else s0 = fma(__shfl(r[k], ii, 64), x[k], s0);
+        }
+        x[ii] = (ii < i) ? 0.0 : (ii == i ? rinv[ii] : -(s0 + s1) * rinv[ii]);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (j <= i) A[(k0 + i) * CQLD + k0 + j] = r[j];               // L11 (lower incl. diagonal)
+        xd[k0 + i] = x[i];
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii)
+          if (ii > i) A[(k0 + i) * CQLD + k0 + ii] = x[ii];             // X[ii][i] at the transposed (upper) position
+      }
+    }
+    __syncthreads();
+    CQA(1);
+    // panel: L[i][k0 + j] = sum_{k <= j} A[i][k0 + k] X[j][k],  rows below the block
+    {
+      const int i = k0 + 16 + tid;
+      if (i < wp) {
+        double a[16], l[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = A[i * CQLD + k0 + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          double sacc = a[j] * xd[k0 + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) sacc = fma(a[k], A[(k0 + k) * CQLD + k0 + j], sacc);   // X[j][k], k < j
+          l[j] = sacc;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) A[i * CQLD + k0 + j] = l[j];
+      }
+    }
+    __syncthreads();
+    CQA(2);
+    // trailing update of the lower triangle behind the block: thread (ti, tj) owns the entries
+    // (r0 + ti + 16 a, r0 + tj + 16 b), b <= a, in registers; 14 LDS reads per 28 (49) products
+    {
+      const int ti = tid >> 4, tj = tid & 15, r0 = k0 + 16;
+      const int nt = (wp - r0) >> 4;                 // 16-row strips behind the block (wp is a multiple of 16)
+      if (nt > 0) {
+        double acc[7][7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a)
+#pragma unroll
+          for (int b = 0; b < 7; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+          double li[7], lj[7];
+#pragma unroll
+          for (int a = 0; a < 7; ++a) {
+            li[a] = a < nt ? A[(r0 + ti + 16 * a) * CQLD + k0 + t] : 0.0;
+            lj[a] = a < nt ? A[(r0 + tj + 16 * a) * CQLD + k0 + t] : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < 7; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) acc[a][b] = fma(li[a], lj[b], acc[a][b]);
+        }
+#pragma unroll
+        for (int a = 0; a < 7; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b)
+            if (a < nt && (b < a || tj <= ti)) A[(r0 + ti + 16 * a) * CQLD + r0 + tj + 16 * b] -= acc[a][b];
+      }
+    }
+    __syncthreads();
+    CQA(3);
+  }
+  CQT(2);
+  // Rcur = L^T D^-1 (upper); the second round's product with the first round's R is the caller's (one MFMA GEMM)
+  for (int e = tid; e < CQW * CQW; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    R[e] = (i <= j && i < w && j < w && dsc[j] > 0.0) ? A[j * CQLD + i] * dinv[j] : 0.0;
+  }
+  __syncthreads();
+  CQT(3);
+  // the inverses of the diagonal blocks move to their own (lower) positions: L's diagonal blocks are not needed
+  // any more, and X = L^-1 is then stored uniformly
+  for (int e = tid; e < nbk * 256; e += 256) {
+    const int kb = e >> 8, i = (e >> 4) & 15, j = e & 15, k0 = kb * 16;
+    double v = 0.0;
+    if (j < i) v = A[(k0 + j) * CQLD + k0 + i];
+    else if (j == i) v = xd[k0 + i];
+    tmp[e & 255] = v;                       // one diagonal block per pass: 256 threads, 256 entries
+    __syncthreads();
+    if (j <= i) A[(k0 + i) * CQLD + k0 + j] = tmp[e & 255];
+    __syncthreads();
+  }
+  CQT(4);
+  // X = L^-1 in place of the block-lower part, block row by block row:  X[I,J] = -X[I,I] sum_K L[I,K] X[K,J]
+  for (int I = 1; I < nbk; ++I) {
+    const int i0 = I * 16, ncol = i0;                 // columns 0 .. i0-1
+    for (int e = tid; e < 16 * ncol; e += 256) {
+      const int r = e / ncol, cc = e - r * ncol;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int k = cc;
+      for (; k + 3 < i0; k += 4) {
+        s0 = fma(A[(i0 + r) * CQLD + k], A[k * CQLD + cc], s0);
+        s1 = fma(A[(i0 + r) * CQLD + k + 1], A[(k + 1) * CQLD + cc], s1);
+        s2 = fma(A[(i0 + r) * CQLD + k + 2], A[(k + 2) * CQLD + cc], s2);
+        s3 = fma(A[(i0 + r) * CQLD + k + 3], A[(k + 3) * CQLD + cc], s3);
+      }
+      for (; k < i0; ++k) s0 = fma(A[(i0 + r) * CQLD + k], A[k * CQLD + cc], s0);
+      tmp[r * 112 + cc] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * ncol; e += 256) {
+      const int r = e / ncol, cc = e - r * ncol;
+      double sacc = 0.0;
+      for (int q = 0; q <= r; ++q) sacc = fma(A[(i0 + r) * CQLD + i0 + q], tmp[q * 112 + cc], sacc);   // X[I,I][r][q]
+      A[(i0 + r) * CQLD + cc] = -sacc;
+    }
+    __syncthreads();
+  }
+  CQT(5);
+  // T = D X^T (upper; zero for failed / padded columns)
+  for (int e = tid; e < CQW * CQW; e += 256) {
+    const int i = e >> 7, j = e & 127;
+    T[e] = (i <= j && j < w && dsc[j] > 0.0) ? dsc[i] * A[j * CQLD + i] : 0.0;
+  }
+  CQT(6);
+  CQP();
+  if (__syncthreads_or(bad ? 1 : 0) && tid == 0) atomicExch(flag, 1);
+}
+void launch_cholqr_wide(hipStream_t st, int w, const double* G, int ldg, double* T, double* R, int* flag) {
+  const size_t lds = (size_t)(CQW * CQLD + 3 * CQW + 16 * 112) * sizeof(double);
+  static bool attr_set = false;   // 147 KB of dynamic LDS: above the 64 KB default limit
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cholqr_wide_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cholqr_wide_kernel, dim3(1), dim3(256), lds, st, w, G, ldg, T, R, flag);
+}
+
 // sel[i, jj] = evec[(c - 1 - jj), i]   (c x k, row-major): the k eigenvectors of the largest
 // eigenvalues, as columns, from the row-major view of a column-major eigenvector matrix with
 // ascending eigenvalues (row j of the view = eigenvector j).

@@ -1799,7 +1799,7 @@ static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double
                         bool thresh_relative, double* dOut, std::vector<double>* sv_host,
                         bool use_qr = false);
 static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
-                         double* R);
+                         double* R, int split = 0);
 
 // Truncation level of the internal recompressions: the Gram-matrix route
 // resolves singular values down to sqrt(eps)*sigma_1; dropping what lies below
@@ -2539,37 +2539,70 @@ static void panel_cholqr2(ricadi_ctx* c, const double* P, int n, int w, double* 
   launch_copy_cols(st, w, w, R2.p, 32, 0, R, ldr, 0, 1.0);
 }
 
+// One panel of up to 128 columns by CholQR2 (round 3): both Gram matrices and both products Q = P T on the MFMA
+// GEMMs, Cholesky factor + triangular inverse of the 128 x 128 Gram matrix in one workgroup
+// (cholqr_wide_kernel).  P: n x w (ld ldp); Q1: scratch n x w (ld ldp); Q (ld ldq), R (ld ldr).
+static void panel_cholqr2_wide(ricadi_ctx* c, const double* P, int ldp, int n, int w, double* Q1, double* Q, int ldq,
+                               double* R, int ldr, double* G, double* T1, double* R1, double* T2, double* R2) {
+  hipStream_t st = c->st;
+  int* flag = c->flag.p + 1;
+  HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * 128 * 128, st));
+  launch_gemm_tn(st, n, w, w, P, ldp, P, ldp, G, 128);
+  launch_cholqr_wide(st, w, G, 128, T1, R1, flag);
+  launch_gemm_nn(st, n, w, w, P, ldp, T1, 128, Q1, ldp, 1.0, 0.0);
+  HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * 128 * 128, st));
+  launch_gemm_tn(st, n, w, w, Q1, ldp, Q1, ldp, G, 128);
+  launch_cholqr_wide(st, w, G, 128, T2, R2, flag);
+  launch_gemm_nn(st, n, w, w, Q1, ldp, T2, 128, Q, ldq, 1.0, 0.0);
+  launch_gemm_nn(st, w, w, w, R2, 128, R1, 128, R, ldr, 1.0, 0.0);        // R = R_2 R_1
+}
+
 // D = Q R for a tall n x kk matrix (ldd): block classical Gram-Schmidt with
-// re-orthogonalisation between 32-column panels (both passes on the FP64 MFMA
-// GEMMs).  Inside a panel: CholQR2 on the matrix cores (panel_cholqr2) when the panel
-// allows it -- checked once, after the last panel -- else the whole factorisation is
-// redone with the Householder TSQR tree (numerically rank-deficient panels, e.g. raw
+// re-orthogonalisation between panels (both passes on the FP64 MFMA GEMMs).  Inside a panel:
+// CholQR2 on the matrix cores -- panels of 128 columns (panel_cholqr2_wide; round 2: 32 columns,
+// ~20 dependent launches per panel, RICADI_QR_PANEL=32 restores it) when the panel allows it --
+// checked once, after the last panel -- else the whole factorisation is redone with 32-column panels
+// through the Householder TSQR tree (numerically rank-deficient panels, e.g. raw
 // ADI blocks; RICADI_TSQR_HOUSEHOLDER=1 forces it).  Q: n x kk (ld kk), R: kk x kk
-// row-major upper triangular.
+// row-major upper triangular.  No panel straddles column `split` (the update norm factorises [Z_new, Z_old]).
 static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
-                         double* R) {
+                         double* R, int split) {
   hipStream_t st = c->st;
   static const bool hh_only = getenv("RICADI_TSQR_HOUSEHOLDER") != nullptr;
-  TArr<double> P(c->pool, (size_t)n * 32), C1(c->pool, (size_t)kk * 32), C2(c->pool, (size_t)kk * 32);
+  static const int pw_env = getenv("RICADI_QR_PANEL") ? atoi(getenv("RICADI_QR_PANEL")) : 128;
+  const int PWF = pw_env <= 32 ? 32 : 128;          // panel width of the fast path
+  TArr<double> P(c->pool, (size_t)n * PWF), C1(c->pool, (size_t)kk * PWF), C2(c->pool, (size_t)kk * PWF);
+  TArr<double> Q1(c->pool), Gw(c->pool), Tw(c->pool);
+  if (PWF == 128) {
+    Q1.alloc((size_t)n * 128);
+    Gw.alloc(128 * 128);
+    Tw.alloc(4 * 128 * 128);
+  }
   for (int attempt = hh_only ? 1 : 0; attempt < 2; ++attempt) {
     const bool fast = attempt == 0;
+    const int PW = fast ? PWF : 32;
     if (fast) HIPCHK(hipMemsetAsync(c->flag.p + 1, 0, sizeof(int), st));
     HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * kk * kk, st));
-    for (int c0 = 0; c0 < kk; c0 += 32) {
-      const int w = std::min(32, kk - c0);
-      HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));
-      launch_copy_cols(st, n, w, D, ldd, c0, P.p, 32, 0, 1.0);
+    for (int c0 = 0, wnext = 0; c0 < kk; c0 += wnext) {
+      int w = std::min(PW, kk - c0);
+      if (c0 < split && c0 + w > split) w = split - c0;       // no panel straddles `split`
+      wnext = w;
+      if (PW == 32) HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));   // 32-wide kernels read all 32
+      launch_copy_cols(st, n, w, D, ldd, c0, P.p, PW, 0, 1.0);
       if (c0 > 0) {
         for (int pass = 0; pass < 2; ++pass) {
           double* C = pass == 0 ? C1.p : C2.p;
           HIPCHK(hipMemsetAsync(C, 0, sizeof(double) * c0 * w, st));
-          launch_gemm_tn(st, n, c0, w, Q, kk, P.p, 32, C, w);
-          launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, 32, -1.0, 1.0);
+          launch_gemm_tn(st, n, c0, w, Q, kk, P.p, PW, C, w);
+          launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, PW, -1.0, 1.0);
         }
         launch_axpby(st, (size_t)c0 * w, 1.0, C2.p, 1.0, C1.p);
         launch_copy_cols(st, c0, w, C1.p, w, 0, R, kk, c0, 1.0);
       }
-      if (fast)
+      if (fast && PW == 128)
+        panel_cholqr2_wide(c, P.p, PW, n, w, Q1.p, Q + c0, kk, R + (size_t)c0 * kk + c0, kk, Gw.p, Tw.p,
+                           Tw.p + 16384, Tw.p + 2 * 16384, Tw.p + 3 * 16384);
+      else if (fast)
         panel_cholqr2(c, P.p, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
       else
         tsqr_dev(c, P.p, 32, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
@@ -2596,7 +2629,9 @@ static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const dou
       Rt(c->pool, (size_t)kk * kk), Rts(c->pool, (size_t)kk * kk), T(c->pool, (size_t)kk * kk);
   launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
   if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
-  block_qr_dev(c, D.p, kk, nv, kk, Q.p, R.p);
+  // panels never hold columns of both factors: Z1 ~ Z0 at convergence, and near-duplicate columns inside one
+  // panel would send the factorisation to the Householder fallback
+  block_qr_dev(c, D.p, kk, nv, kk, Q.p, R.p, k1);
   std::vector<double> Th((size_t)kk * kk);
   auto fro_of = [&](double sneg) {
     // (S R^T)^T (R^T) = R S R^T  with the transposes formed explicitly (kk x kk)

@@ -1,7 +1,3 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/r3x1
-timeout -k 10 300 python -m pytest tests/test_gpu_round3.py -x -q -k recompress > gpurun_out/r3x1/t.log 2>&1; tail -5 gpurun_out/r3x1/t.log
-timeout -k 10 120 python tools/recompress_probe.py 26450 768 2>&1 | tail -2
-RICADI_RECOMPRESS_EIG=1 timeout -k 10 120 python tools/recompress_probe.py 26450 768 2>&1 | tail -2
-timeout -k 10 120 python tools/recompress_probe.py 26450 1200 2>&1 | tail -2
-RICADI_RECOMPRESS_EIG=1 timeout -k 10 120 python tools/recompress_probe.py 26450 1200 2>&1 | tail -2
-tools/ab.sh r3x1 "pchol:" "eig:RICADI_RECOMPRESS_EIG=1"
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r3x4; mkdir -p $O
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -4 $O/gputests.log
+RICADI_TIMING=1 timeout -k 10 300 python bench.py --no-large-roofline --no-cpu-baseline --no-extras > $O/b.json 2> $O/b.err; cut -c1-300 $O/b.json; grep -i "timing\|setup\|sweep" $O/b.err | tail -12
