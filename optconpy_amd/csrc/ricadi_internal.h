@@ -374,6 +374,7 @@ void launch_select_evecs(hipStream_t st, int c, int k, const double* evec, doubl
 void launch_transpose_sign(hipStream_t st, int k, int k1, double sneg, const double* in, double* out);
 // batched block Gauss-Jordan inverse of the coarse matrices (ricadi_kernels.hip); nb <= RICADI_MAX_GROUPS matrices
 int gj_block();
+int gj_max_batch();
 void launch_gj_prep(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, double* Cb, double* Rp,
                     double* D);
 void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag);
@@ -420,6 +421,12 @@ void launch_pchol_panel(hipStream_t st, const double* A, int ld, int nr, int nc,
 void launch_pchol_trail(hipStream_t st, double* A, int ld, int nr, int nc, const PcholState* stt,
                         const double* Rall, int ldr);
 void launch_transpose(hipStream_t st, int rows, int cols, const double* in, int ldi, double* out, int ldo);
+
+// K4s: all Z blocks of an ADI sweep + their squared column norms in two launches
+bool sweep_combine_ok(int m, int nslot, int G);
+size_t sweep_combine_partial_len(int nrows, int m, int G);
+void launch_sweep_combine(hipStream_t st, int nrows, int m, int nslot, int G, const double* U, size_t ustride,
+                          const double* coef, double* Z, int zld, int zc0, double* partial, double* norms2);
 
 void set_error(const std::string& msg);
 

@@ -2887,8 +2887,11 @@ void launch_to_f32_tiled(hipStream_t st, int k, const double* src, float* dst) {
 // matrix cores (rocSOLVER's getrf + getri spend a third of their time in one poorly parallel kernel).
 // ---------------------------------------------------------------------------
 constexpr int GJ_NB = 128;
+// up to GJ_MAX matrices per call: the 16 shifts of a sweep and the projection operator go through ONE batch
+// (a matrix inverted alone costs several times its share of a batch)
+constexpr int GJ_MAX = 24;
 struct GjPtrs {
-  double* a[RICADI_MAX_GROUPS];
+  double* a[GJ_MAX];
 };
 __global__ __launch_bounds__(256) void gj_prep_kernel(GjPtrs A, int k, int k0, int nbe, double* __restrict__ Cb,
                                                       double* __restrict__ Rp, double* __restrict__ D) {
@@ -3004,10 +3007,11 @@ __global__ __launch_bounds__(256) void gj_rows_kernel(GjPtrs A, int k, int k0, i
   for (size_t e = tid; e < (size_t)nbe * k; e += nth) a[(size_t)k0 * k + e] = rb[e];
 }
 int gj_block() { return GJ_NB; }
+int gj_max_batch() { return GJ_MAX; }
 void launch_gj_prep(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, double* Cb, double* Rp,
                     double* D) {
   GjPtrs P;
-  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
+  for (int i = 0; i < GJ_MAX; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
   const int grid = (int)std::min<size_t>(((size_t)nbe * k + 255) / 256, 1024);
   hipLaunchKernelGGL(gj_prep_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Cb, Rp, D);
   hipLaunchKernelGGL(gj_cols_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Cb);
@@ -3017,7 +3021,7 @@ void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag) {
 }
 void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb) {
   GjPtrs P;
-  for (int i = 0; i < RICADI_MAX_GROUPS; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
+  for (int i = 0; i < GJ_MAX; ++i) P.a[i] = i < nb ? mats[i] : nullptr;
   const int grid = (int)std::min<size_t>(((size_t)nbe * k + 255) / 256, 1024);
   hipLaunchKernelGGL(gj_rows_kernel, dim3(grid, 1, nb), dim3(256), 0, st, P, k, k0, nbe, Rb);
 }
@@ -4005,6 +4009,83 @@ void launch_pchol_trail(hipStream_t st, double* A, int ld, int nr, int nc, const
                         const double* Rall, int ldr) {
   hipLaunchKernelGGL(pchol_trail_kernel, dim3((nc + 63) / 64, (nr + 63) / 64), dim3(256), 0, st, A, ld, nr, nc,
                      stt, Rall, ldr);
+}
+
+// ---------------------------------------------------------------------------
+// K4s: the Z blocks of an ADI sweep in one launch.  Block j = sum_s coef[j][s] U_s  (U_s: the nslot solution
+// panels, n x m each, `ustride` doubles apart; only the first nrows rows are used) goes straight into the
+// factor (columns zc0 + j m ..), and the squared column norms of all blocks are accumulated per workgroup
+// (partial[wg][j m + c]; sweep_norms_kernel sums them).  Round 2 issued three launches per block.
+// coef is the host's replicated layout coef[(j nslot + s) m + c] (the same value for every c).
+// ---------------------------------------------------------------------------
+constexpr int SWC_ROWS = 64, SWC_MAXS = 16;
+__global__ __launch_bounds__(256) void sweep_combine_kernel(int nrows, int m, int nslot, int G,
+                                                            const double* __restrict__ U, size_t ustride,
+                                                            const double* __restrict__ coef,
+                                                            double* __restrict__ Z, int zld, int zc0,
+                                                            double* __restrict__ partial) {
+  __shared__ double cs[SWC_MAXS * SWC_MAXS];
+  __shared__ double nr[SWC_MAXS * RICADI_MAX_M];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < G * nslot; e += 256) cs[e] = coef[(size_t)e * m];
+  for (int e = tid; e < G * m; e += 256) nr[e] = 0.0;
+  __syncthreads();
+  const int r0 = blockIdx.x * SWC_ROWS;
+  const int cnt = min(SWC_ROWS, nrows - r0) * m;
+  const bool fixedc = (256 % m) == 0;         // the thread's column is the same for all of its elements
+  double racc[SWC_MAXS];
+#pragma unroll
+  for (int j = 0; j < SWC_MAXS; ++j) racc[j] = 0.0;
+  for (int e = tid; e < cnt; e += 256) {
+    const int r = r0 + e / m, cidx = e % m;
+    double u[SWC_MAXS];
+#pragma unroll
+    for (int sl = 0; sl < SWC_MAXS; ++sl)
+      u[sl] = sl < nslot ? U[(size_t)sl * ustride + (size_t)r * m + cidx] : 0.0;
+#pragma unroll
+    for (int j = 0; j < SWC_MAXS; ++j) {
+      if (j < G) {
+        double v = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SWC_MAXS; ++sl) v = fma(sl < nslot ? cs[j * nslot + sl] : 0.0, u[sl], v);
+        Z[(size_t)r * zld + zc0 + j * m + cidx] = v;
+        if (fixedc) racc[j] = fma(v, v, racc[j]);
+        else atomicAdd(&nr[j * m + cidx], v * v);
+      }
+    }
+  }
+  if (fixedc) {
+    const int cidx = tid % m;
+#pragma unroll
+    for (int j = 0; j < SWC_MAXS; ++j)
+      if (j < G) atomicAdd(&nr[j * m + cidx], racc[j]);
+  }
+  __syncthreads();
+  for (int e = tid; e < G * m; e += 256) partial[(size_t)blockIdx.x * G * m + e] = nr[e];
+}
+__global__ __launch_bounds__(256) void sweep_norms_kernel(int nwg, int gm, const double* __restrict__ partial,
+                                                          double* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= gm) return;
+  double s0 = 0.0, s1 = 0.0;
+  int w = 0;
+  for (; w + 1 < nwg; w += 2) {
+    s0 += partial[(size_t)w * gm + e];
+    s1 += partial[(size_t)(w + 1) * gm + e];
+  }
+  if (w < nwg) s0 += partial[(size_t)w * gm + e];
+  out[e] = s0 + s1;
+}
+bool sweep_combine_ok(int m, int nslot, int G) { return nslot <= SWC_MAXS && G <= SWC_MAXS && m <= RICADI_MAX_M; }
+size_t sweep_combine_partial_len(int nrows, int m, int G) {
+  return (size_t)((nrows + SWC_ROWS - 1) / SWC_ROWS) * G * m;
+}
+void launch_sweep_combine(hipStream_t st, int nrows, int m, int nslot, int G, const double* U, size_t ustride,
+                          const double* coef, double* Z, int zld, int zc0, double* partial, double* norms2) {
+  const int nwg = (nrows + SWC_ROWS - 1) / SWC_ROWS;
+  hipLaunchKernelGGL(sweep_combine_kernel, dim3(nwg), dim3(256), 0, st, nrows, m, nslot, G, U, ustride, coef, Z,
+                     zld, zc0, partial);
+  hipLaunchKernelGGL(sweep_norms_kernel, dim3((G * m + 255) / 256), dim3(256), 0, st, nwg, G * m, partial, norms2);
 }
 
 // coarse matrix combine: out = beta*E0 + alpha*EM + EJ  (dense k x k)

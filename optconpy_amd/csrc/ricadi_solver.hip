@@ -298,7 +298,7 @@ struct ricadi_ctx {
   long lr_epoch = 0;          // bumped whenever U / V change
   bool smw = true;            // RICADI_SMW=0: keep the low-rank term inside the Krylov operator
   DArr<double> smw_rhs, smw_x, smw_cap;
-  DArr<double> sweep_u, sweep_t, sweep_coef;   // ADI sweeps: the G solutions, a panel, coefficients
+  DArr<double> sweep_u, sweep_t, sweep_coef, sweep_part;   // ADI sweeps: the G solutions, a panel, coefficients, norm partials
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
   // workspaces
@@ -616,8 +616,8 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     bool done = false, done_gj = false;
     if (gj && npvt) {
       done = true;
-      for (int i0 = 0; i0 < nb && done; i0 += RICADI_MAX_GROUPS)
-        done = gj_invert_batched(c, hp.data() + i0, std::min(RICADI_MAX_GROUPS, nb - i0), k);
+      for (int i0 = 0; i0 < nb && done; i0 += gj_max_batch())
+        done = gj_invert_batched(c, hp.data() + i0, std::min(gj_max_batch(), nb - i0), k);
       done_gj = done;
       if (!done)
         for (ShiftData* sd : todo)   // a vanishing pivot: assemble again for the rocSOLVER routes
@@ -2126,11 +2126,19 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * (size_t)Gs * nslot * m,
                           hipMemcpyHostToDevice, st));
     // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
-    for (int j = 0; j < Gs; ++j) {
-      launch_cols_update(st, nv, m, nslot, ubase, nm, c->sweep_coef.p + (size_t)j * nslot * m, 1.0,
-                         nullptr, nullptr, c->sweep_t.p);
-      launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, c->Z.p, c->zld, c->zc + j * m, 1.0);
-      col_norms2(c, c->sweep_t.p, nv, m, c->nrm2.p + (size_t)j * m);
+    static const bool fused_blocks = getenv("RICADI_SWEEP_UNFUSED") == nullptr;
+    if (fused_blocks && sweep_combine_ok(m, nslot, Gs)) {
+      // all blocks and their norms in two launches (K4s)
+      c->sweep_part.ensure(sweep_combine_partial_len(nv, m, Gs));
+      launch_sweep_combine(st, nv, m, nslot, Gs, ubase, nm, c->sweep_coef.p, c->Z.p, c->zld, c->zc,
+                           c->sweep_part.p, c->nrm2.p);
+    } else {
+      for (int j = 0; j < Gs; ++j) {
+        launch_cols_update(st, nv, m, nslot, ubase, nm, c->sweep_coef.p + (size_t)j * nslot * m, 1.0,
+                           nullptr, nullptr, c->sweep_t.p);
+        launch_copy_cols(st, nv, m, c->sweep_t.p, m, 0, c->Z.p, c->zld, c->zc + j * m, 1.0);
+        col_norms2(c, c->sweep_t.p, nv, m, c->nrm2.p + (size_t)j * m);
+      }
     }
     hn.resize((size_t)Gs * m);
     HIPCHK(hipMemcpyAsync(hn.data(), c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
