@@ -235,6 +235,19 @@ int ricadi_lyap_res_norm(ricadi_ctx* ctx, const double* Z, int c,
 int ricadi_factor_cols(ricadi_ctx* ctx, int* c_out);
 int ricadi_factor_get(ricadi_ctx* ctx, double* Z_out, int c);
 int ricadi_factor_set(ricadi_ctx* ctx, const double* Z, int c);
+/* ... into a DEVICE buffer (NV x c row-major, ld = c; c = ricadi_factor_cols) */
+int ricadi_factor_get_dev(ricadi_ctx* ctx, double* dZ_out, int c);
+
+/* a1 with every panel ALREADY IN HBM (no PCIe traffic inside the call; the reference's callers hand numpy
+ * arrays over, /root/reference/solve_dae_ric.py:152-159 -- this is the same call for a host side that keeps
+ * its panels on the device between calls, e.g. one backward time step after the other): dB NV x nb, dW NV x mw,
+ * dZ0 NV x c0 (NULL with c0 = 0), dOldB NV x nb or NULL, all row-major with leading dimension = width.
+ * The new iterate stays in the context's factor (ricadi_factor_cols / _get / _get_dev).
+ * stats_out as ricadi_ric_newtonadi.                                                                        */
+int ricadi_ric_newtonadi_dev(ricadi_ctx* ctx, const double* shifts, int nshifts,
+                             const double* dB, int nb, const double* dW, int mw,
+                             const double* dZ0, int c0, const double* dOldB,
+                             const ricadi_adi_params* prm, int* c_out, double* stats_out);
 
 /* ---- device-pointer level (multi-GPU orchestration, benchmarks) --------
  * Same operations on buffers that already live in HBM (e.g. torch tensors'

@@ -20,7 +20,7 @@ RICADI_ENOCONV = -3
 MAX_M = 128
 # ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
 # are part of the ABI and are not covered by the struct handshake below
-ABI_VERSION = 301
+ABI_VERSION = 302
 
 
 class RicadiOpts(C.Structure):
@@ -77,6 +77,9 @@ SIGNATURES = {
     "ricadi_factor_cols": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "ricadi_factor_get": (C.c_int, [_vp, _dp, C.c_int]),
     "ricadi_factor_set": (C.c_int, [_vp, _dp, C.c_int]),
+    "ricadi_factor_get_dev": (C.c_int, [_vp, _vp, C.c_int]),
+    "ricadi_ric_newtonadi_dev": (C.c_int, [_vp, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp,
+                                           C.POINTER(RicadiAdiParams), C.POINTER(C.c_int), _dp]),
     "ricadi_spmm_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp]),
     "ricadi_shift_solve_dev": (C.c_int, [_vp, C.c_double, C.c_double, _vp, C.c_int, _vp,
                                          C.POINTER(C.c_int), _dp]),
@@ -471,6 +474,35 @@ class Context:
                     lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]))
         _warn_nonconverged(info)
         return Z, info
+
+    def ric_newtonadi_dev(self, shifts, B_t, W_t, prm, Z0_t=None, old_t=None):
+        """``ricadi_ric_newtonadi_dev``: every panel is a torch CUDA tensor (float64, contiguous, NV rows);
+        the new iterate comes back as a fresh NV x c CUDA tensor.  No PCIe traffic."""
+        import torch
+        sh = np.ascontiguousarray(shifts, dtype=np.float64)
+        for t in (B_t, W_t, Z0_t, old_t):
+            if t is not None and not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+                                      and t.dim() == 2 and t.shape[0] == self.nv):
+                raise ValueError("device panels must be contiguous float64 CUDA tensors with NV rows")
+        cc = C.c_int(0)
+        stats = np.zeros(12)
+        self._zdev = None
+        torch.cuda.current_stream().synchronize()          # the library runs on its own stream
+        _chk(self._lib.ricadi_ric_newtonadi_dev(
+            self._h, _d(sh), sh.size, B_t.data_ptr(), B_t.shape[1], W_t.data_ptr(), W_t.shape[1],
+            None if Z0_t is None else Z0_t.data_ptr(), 0 if Z0_t is None else Z0_t.shape[1],
+            None if old_t is None else old_t.data_ptr(), C.byref(prm), C.byref(cc), _d(stats)))
+        c = cc.value
+        Zt = torch.empty((self.nv, c), dtype=torch.float64, device=B_t.device)
+        if c > 0:
+            _chk(self._lib.ricadi_factor_get_dev(self._h, Zt.data_ptr(), c))
+        info = dict(nwtn_steps=int(stats[0]), upd_abs=stats[1], upd_rel=stats[2],
+                    adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
+                    shift_solves=int(stats[5]), cols=c,
+                    gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7],
+                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]))
+        _warn_nonconverged(info)
+        return Zt, info
 
     def compress(self, Z=None, thresh=None, k=None):
         """``Z=None`` compresses the factor left on the device."""

@@ -90,6 +90,13 @@ def context_for(calA, calE, J):
     return ctx
 
 
+def operator_has_cale(MT):
+    """Whether the resident operator's ``cal E`` is the matrix ``MT`` (by fingerprint): the device-level gain
+    (``ricadi_gain_dev``) multiplies by the context's ``cal E``."""
+    return (_ctx is not None and isinstance(_ctx_key, tuple) and len(_ctx_key) == 3 and _ctx_key[0] != "dims"
+            and _ctx_key[1] == _fingerprint(MT))
+
+
 def context_dims(nv):
     """Context that only knows NV (compression, explicit-matrix gain)."""
     global _ctx_key

@@ -520,6 +520,14 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     todo.push_back(sd);
   }
   if (todo.empty()) return;
+  Tick tks;
+  double tph[6] = {0, 0, 0, 0, 0, 0};
+  auto lapS = [&](int i) {
+    if (c->timing) {
+      (void)hipStreamSynchronize(st);
+      tph[i] += tks.lap();
+    }
+  };
   HIPCHK(hipMemsetAsync(c->flag.p, 0, sizeof(int), st));
   const size_t bsz = (size_t)c->bs * c->bs;
   const int k = c->kc;
@@ -534,6 +542,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     get_shifts(c->child.get(), al.data(), be.data(), (int)todo.size(), subs.data());
     for (size_t i = 0; i < todo.size(); ++i) todo[i]->sub = subs[i];
   }
+  lapS(0);
   for (ShiftData* sd : todo) {
     const double alpha = sd->alpha, beta = sd->beta;
     stable_alloc(sd->sval, c->snnz);
@@ -562,6 +571,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       }
     }
   }
+  lapS(1);
   // block inversions and Schur blocks: one launch each for all shifts (<= 16 per call)
   for (size_t t0 = 0; t0 < todo.size(); t0 += RICADI_MAX_GROUPS) {
     const int cnt = (int)std::min<size_t>(RICADI_MAX_GROUPS, todo.size() - t0);
@@ -592,6 +602,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
       launch_block_invert(st, cnt, c->nbp, c->bs, c->bp_ptr.p, pp, c->flag.p);
     }
   }
+  lapS(2);
   const int nb = (int)todo.size();
   std::vector<int> info(nb, 0);
   if (kd > 0) {
@@ -643,6 +654,7 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     if (!(gj && npvt && done_gj))
       HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
   }
+  lapS(3);
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -677,6 +689,10 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
     }
     HIPCHK(hipStreamSynchronize(st));
   }
+  lapS(4);
+  if (c->timing && !c->borrowed)
+    fprintf(stderr, "[ricadi timing] setup of %d shifts: child %.1f ms, per-shift assembly %.1f, block inverses + Schur blocks %.1f, coarse inverses %.1f, FP32 copies %.1f\n",
+            (int)todo.size(), 1e3 * tph[0], 1e3 * tph[1], 1e3 * tph[2], 1e3 * tph[3], 1e3 * tph[4]);
   for (ShiftData* sd : todo) sd->valid = true;
 }
 
@@ -2201,8 +2217,10 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
       if (dbg) {
         double wf = 0.0;
         DScalar::gram_norms(c, dW, c->nv, m, &wf, nullptr);
-        fprintf(stderr, "[ricadi rank %d] sweep %d: Gs %d kept %d per_rank %d nmine %d  ||W^T W|| %.6e  znorm2 %.6e\n", rank, sw + 1,
+        fprintf(stderr, "[ricadi rank %d] sweep %d: Gs %d kept %d per_rank %d nmine %d  ||W^T W|| %.6e  znorm2 %.6e  its", rank, sw + 1,
                 Gs, kept, per_rank, nmine, wf, znorm2);
+        for (int k = 0; k < nmine; ++k) fprintf(stderr, " %d", res[k].iters);
+        fprintf(stderr, "\n");
       }
       fprintf(stderr, "[ricadi] ADI sweep %3d (steps %d..%d): rel new Z %9.3e, gmres its <= %d%s\n",
               sw + 1, steps - kept + 1, steps, stt.rel, its, shard ? " (this rank)" : "");
@@ -2703,7 +2721,7 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 301; }
+int ricadi_version(void) { return 302; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
@@ -3769,16 +3787,15 @@ int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W
   API_END
 }
 
-int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const double* B, int nb,
-                         const double* W, int mw, const double* Z0, int c0, const double* oldB,
-                         const ricadi_adi_params* prm, double* Z_out, int zcap, int* c_out,
-                         double* stats_out) {
-  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
-  REQUIRE(shifts && ns > 0 && B && W && prm, RICADI_EINVAL, "bad argument");
-  REQUIRE(nb >= 1 && nb <= 64 && mw >= 1 && mw + nb <= RICADI_MAX_M, RICADI_EINVAL, "bad widths");
-  REQUIRE(c0 == 0 || Z0, RICADI_EINVAL, "Z0 is NULL");
-  for (int i = 0; i < ns; ++i) REQUIRE(shifts[i] < 0.0, RICADI_EINVAL, "ADI shifts must be negative");
-  API_BEGIN
+}  // extern "C"
+
+// Newton-Kleinman iteration on DEVICE operands (all panels row-major, their own width as leading dimension):
+// dB nv x nb, dW nv x mw, dZ0 nv x c0 (or c0 = 0), dOld nv x nb or NULL (`oldB`: whether it is given).  The new
+// iterate is left in the context's factor (c->Z, c->zc).
+static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const double* dB, int nb, const double* dW,
+                              int mw, const double* dZ0, int c0, const double* dOld, const ricadi_adi_params* prm,
+                              double* stats_out) {
+  const bool oldB = dOld != nullptr;
   hipStream_t st = c->st;
   const int nv = c->nv;
   const int mfull = mw + nb;
@@ -3793,21 +3810,12 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     }
   } lowrank_reset{c};
   ensure_work(c, mfull);
-  TArr<double> dB(c->pool, (size_t)nv * nb), dWm(c->pool, (size_t)nv * mw), dOld(c->pool),
-      dK(c->pool, (size_t)nv * nb), dKall(c->pool, (size_t)nv * nb), dRhs(c->pool, (size_t)nv * mfull),
-      Zk(c->pool), Znew(c->pool);
-  HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(dWm.p, W, sizeof(double) * nv * mw, hipMemcpyHostToDevice, st));
-  if (oldB) {
-    dOld.alloc((size_t)nv * nb);
-    HIPCHK(hipMemcpyAsync(dOld.p, oldB, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
-  }
-  int kk = 0;  // columns of the current (compressed) iterate Zk
-  if (c0 > 0) {
-    Zk.alloc((size_t)nv * c0);
-    HIPCHK(hipMemcpyAsync(Zk.p, Z0, sizeof(double) * nv * c0, hipMemcpyHostToDevice, st));
-    kk = c0;
-  }
+  TArr<double> dWm(c->pool, (size_t)nv * mw), dK(c->pool, (size_t)nv * nb), dKall(c->pool, (size_t)nv * nb),
+      dRhs(c->pool, (size_t)nv * mfull), Zown(c->pool), Znew(c->pool);
+  // W is projected in place below: private copy; B, the old gain and Z0 are only read
+  HIPCHK(hipMemcpyAsync(dWm.p, dW, sizeof(double) * nv * mw, hipMemcpyDeviceToDevice, st));
+  const double* zk = c0 > 0 ? dZ0 : nullptr;       // current (compressed) iterate Z_k, nv x kk (ld kk)
+  int kk = c0;
   // the rhs factor W is projected once here; the K_k part is in range(P^T) already
   ricadi_adi_params p2 = *prm;
   Tick tk0;
@@ -3836,7 +3844,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     Tick tkn;
     if (c->timing) c->t_setup = c->t_solve = c->t_recomb = c->t_compress = c->t_updnorm = c->t_proj = c->t_gain = 0;
     if (kk > 0) {
-      gain_dev(c, c->E, Zk.p, kk, kk, dB.p, nb, dK.p);
+      gain_dev(c, c->E, zk, kk, kk, dB, nb, dK.p);
       if (c->timing) c->t_gain += tkn.lap();
       m = mfull;
     } else {
@@ -3844,7 +3852,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     }
     // closed loop  cal A - (K_k - old) B^T
     HIPCHK(hipMemcpyAsync(dKall.p, dK.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
-    if (oldB) launch_axpby(st, (size_t)nv * nb, -1.0, dOld.p, 1.0, dKall.p);
+    if (oldB) launch_axpby(st, (size_t)nv * nb, -1.0, dOld, 1.0, dKall.p);
     const bool lr = (kk > 0) || oldB;
     c->q = lr ? nb : 0;
     ++c->lr_epoch;
@@ -3852,7 +3860,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
       c->U.ensure((size_t)nv * nb);
       c->V.ensure((size_t)nv * nb);
       HIPCHK(hipMemcpyAsync(c->U.p, dKall.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
-      HIPCHK(hipMemcpyAsync(c->V.p, dB.p, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(c->V.p, dB, sizeof(double) * nv * nb, hipMemcpyDeviceToDevice, st));
     }
     // rhs = [W, K_k]
     launch_copy_cols(st, nv, mw, dWm.p, mw, 0, dRhs.p, m, 0, 1.0);
@@ -3878,7 +3886,7 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     const int knew = c->zc;
     launch_copy_cols(st, nv, knew, c->Z.p, c->zld, 0, Znew.p, knew, 0, 1.0);
     double x1 = 0.0;
-    upd = diff_zzt_fnorm(c, Znew.p, knew, Zk.p, kk, &x1);
+    upd = diff_zzt_fnorm(c, Znew.p, knew, zk, kk, &x1);
     updrel = x1 > 0.0 ? upd / x1 : 0.0;
     {
       double dec[2] = {upd, updrel};       // the stopping decision is rank 0's
@@ -3896,18 +3904,12 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     if (prm->verbose)
       fprintf(stderr, "[ricadi] Newton step %2d: |upd| %9.3e rel %9.3e (%d ADI steps, %d -> %d columns)\n",
               steps, upd, updrel, s.steps, c->zc, knew);
-    Zk.swap(Znew);
+    Zown.swap(Znew);
+    zk = Zown.p;
     kk = knew;
     if (upd < prm->nwtn_upd_abstol || updrel < prm->nwtn_upd_reltol) break;
   }
   if (steps > prm->nwtn_max_steps) steps = prm->nwtn_max_steps;
-  if (c_out) *c_out = c->zc;
-  if (Z_out && c->zc > 0) {
-    if (c->zc > zcap) throw ricadi::HipError{"Z_out capacity too small"};
-    HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * c->zc, c->Z.p, sizeof(double) * c->zld,
-                            sizeof(double) * c->zc, nv, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-  }
   if (stats_out) {
     stats_out[0] = steps;
     stats_out[1] = upd;
@@ -3922,6 +3924,69 @@ int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const doub
     stats_out[10] = (double)(c->escalations - esc0);
     stats_out[11] = 0.0;
   }
+}
+
+extern "C" {
+
+int ricadi_ric_newtonadi(ricadi_ctx* c, const double* shifts, int ns, const double* B, int nb,
+                         const double* W, int mw, const double* Z0, int c0, const double* oldB,
+                         const ricadi_adi_params* prm, double* Z_out, int zcap, int* c_out,
+                         double* stats_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(shifts && ns > 0 && B && W && prm, RICADI_EINVAL, "bad argument");
+  REQUIRE(nb >= 1 && nb <= 64 && mw >= 1 && mw + nb <= RICADI_MAX_M, RICADI_EINVAL, "bad widths");
+  REQUIRE(c0 == 0 || Z0, RICADI_EINVAL, "Z0 is NULL");
+  for (int i = 0; i < ns; ++i) REQUIRE(shifts[i] < 0.0, RICADI_EINVAL, "ADI shifts must be negative");
+  API_BEGIN
+  hipStream_t st = c->st;
+  const int nv = c->nv;
+  TArr<double> dB(c->pool, (size_t)nv * nb), dWm(c->pool, (size_t)nv * mw), dOld(c->pool), dZ0(c->pool);
+  HIPCHK(hipMemcpyAsync(dB.p, B, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dWm.p, W, sizeof(double) * nv * mw, hipMemcpyHostToDevice, st));
+  if (oldB) {
+    dOld.alloc((size_t)nv * nb);
+    HIPCHK(hipMemcpyAsync(dOld.p, oldB, sizeof(double) * nv * nb, hipMemcpyHostToDevice, st));
+  }
+  if (c0 > 0) {
+    dZ0.alloc((size_t)nv * c0);
+    HIPCHK(hipMemcpyAsync(dZ0.p, Z0, sizeof(double) * nv * c0, hipMemcpyHostToDevice, st));
+  }
+  ric_newtonadi_run(c, shifts, ns, dB.p, nb, dWm.p, mw, dZ0.p, c0, oldB ? dOld.p : nullptr, prm, stats_out);
+  if (c_out) *c_out = c->zc;
+  if (Z_out && c->zc > 0) {
+    if (c->zc > zcap) throw ricadi::HipError{"Z_out capacity too small"};
+    HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * c->zc, c->Z.p, sizeof(double) * c->zld,
+                            sizeof(double) * c->zc, nv, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  API_END
+}
+
+// The same with every panel ALREADY ON THE DEVICE (no PCIe traffic inside the call): dB, dW, dZ0, dOldB are device
+// pointers (row-major, leading dimension = width; dZ0 / dOldB may be NULL with c0 = 0).  The new iterate stays in
+// the context's factor: ricadi_factor_cols, ricadi_factor_get (host) / ricadi_factor_get_dev (device).
+int ricadi_ric_newtonadi_dev(ricadi_ctx* c, const double* shifts, int ns, const double* dB, int nb,
+                             const double* dW, int mw, const double* dZ0, int c0, const double* dOldB,
+                             const ricadi_adi_params* prm, int* c_out, double* stats_out) {
+  REQUIRE(c && c->has_op, RICADI_ESTATE, "set the operator first");
+  REQUIRE(shifts && ns > 0 && dB && dW && prm, RICADI_EINVAL, "bad argument");
+  REQUIRE(nb >= 1 && nb <= 64 && mw >= 1 && mw + nb <= RICADI_MAX_M, RICADI_EINVAL, "bad widths");
+  REQUIRE(c0 == 0 || dZ0, RICADI_EINVAL, "Z0 is NULL");
+  for (int i = 0; i < ns; ++i) REQUIRE(shifts[i] < 0.0, RICADI_EINVAL, "ADI shifts must be negative");
+  API_BEGIN
+  ric_newtonadi_run(c, shifts, ns, dB, nb, dW, mw, dZ0, c0, dOldB, prm, stats_out);
+  if (c_out) *c_out = c->zc;
+  HIPCHK(hipStreamSynchronize(c->st));
+  API_END
+}
+
+// Copy of the device-resident factor into a DEVICE buffer (nv x cz row-major, ld cz; cz = ricadi_factor_cols)
+int ricadi_factor_get_dev(ricadi_ctx* c, double* dZ_out, int cz) {
+  REQUIRE(c && dZ_out, RICADI_EINVAL, "NULL argument");
+  REQUIRE(cz == c->zc && cz > 0, RICADI_EINVAL, "column count differs from the resident factor");
+  API_BEGIN
+  launch_copy_cols(c->st, c->nv, cz, c->Z.p, c->zld, 0, dZ_out, cz, 0, 1.0);
+  HIPCHK(hipStreamSynchronize(c->st));
   API_END
 }
 

@@ -18,8 +18,61 @@ from . import _lib, backend
 
 __all__ = [
     "solve_proj_lyap_stein", "proj_alg_ric_newtonadi", "compress_Zsvd",
-    "get_mTzzTtb", "comp_proj_lyap_res_norm", "DEFAULT_MS",
+    "get_mTzzTtb", "comp_proj_lyap_res_norm", "DEFAULT_MS", "DeviceFactor", "to_device",
 ]
+
+
+class DeviceFactor:
+    """A dense ``NV x c`` panel that lives in HBM (a contiguous float64 torch CUDA tensor ``.t``).
+
+    Extension of the mirror, not part of the reference's interface: ``proj_alg_ric_newtonadi`` returns its
+    ``'zfac'`` as one when it was GIVEN device panels (``bmat`` / ``wmat`` / ``z0`` as ``DeviceFactor`` or CUDA
+    tensors) or when ``nwtn_adi_dict['device_resident']`` is set, and accepts one as ``z0``;
+    ``get_mTzzTtb`` takes one as ``Z`` / ``tb``.  The factor then never crosses PCIe between the calls of a
+    time loop (``solve_dae_ric.py:147-189``: ``z0 = Zc`` of the previous step, gain from the new factor).
+    ``np.asarray(f)`` (or ``f.numpy()``) downloads it; everything that expects an ndarray still works that way."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    ndim = 2
+    dtype = np.dtype(np.float64)
+
+    def numpy(self):
+        return self.t.cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+
+def to_device(a):
+    """Upload a dense / sparse ``NV x q`` matrix once; the result can be passed wherever the mirror takes a
+    dense panel (``bmat``, ``wmat``, ``z0``, ``tb``)."""
+    import torch
+    if isinstance(a, DeviceFactor):
+        return a
+    if torch.is_tensor(a):
+        return DeviceFactor(a.to(device="cuda", dtype=torch.float64).contiguous())
+    t = torch.from_numpy(np.ascontiguousarray(_dense(a), dtype=np.float64)).to("cuda:%d" % backend.device_id())
+    torch.cuda.synchronize()
+    return DeviceFactor(t)
+
+
+def _on_device(a):
+    if isinstance(a, DeviceFactor):
+        return True
+    try:
+        import torch
+    except ImportError:
+        return False
+    return torch.is_tensor(a) and a.is_cuda
 
 # Built-in shift list for an ``adi_dict`` without ``'ms'``
 # (tests/test_units_compfacres_compress.py:54-64 relies on such a default; the
@@ -114,12 +167,22 @@ def proj_alg_ric_newtonadi(mmat=None, amat=None, jmat=None, bmat=None,
         # throughput of one shift-solve at a time on one GPU.  ``sweep_width=1`` in the
         # dict restores the step-by-step recurrence of the reference.
         prm.sweep_width = 16
-    B, W = _dense(bmat), _dense(wmat)
-    backend.ensure_exchange(ctx, B.shape[1] + W.shape[1], len(_shifts(d)))
-    Z, info = ctx.ric_newtonadi(_shifts(d), B, W, prm,
-                                Z0=None if z0 is None else _dense(z0),
-                                oldB=None if mtxoldb is None else _dense(mtxoldb))
-    out = dict(zfac=Z)
+    if d.get("device_resident", False) or any(_on_device(x) for x in (bmat, wmat, z0, mtxoldb)):
+        # every panel in HBM (uploaded here once if it came as an ndarray), the new factor returned as a
+        # DeviceFactor: no PCIe traffic in the call when the caller keeps its panels on the device
+        Bt, Wt = to_device(bmat).t, to_device(wmat).t
+        backend.ensure_exchange(ctx, Bt.shape[1] + Wt.shape[1], len(_shifts(d)))
+        Zt, info = ctx.ric_newtonadi_dev(_shifts(d), Bt, Wt, prm,
+                                         Z0_t=None if z0 is None else to_device(z0).t,
+                                         old_t=None if mtxoldb is None else to_device(mtxoldb).t)
+        out = dict(zfac=DeviceFactor(Zt))
+    else:
+        B, W = _dense(bmat), _dense(wmat)
+        backend.ensure_exchange(ctx, B.shape[1] + W.shape[1], len(_shifts(d)))
+        Z, info = ctx.ric_newtonadi(_shifts(d), B, W, prm,
+                                    Z0=None if z0 is None else _dense(z0),
+                                    oldB=None if mtxoldb is None else _dense(mtxoldb))
+        out = dict(zfac=Z)
     out.update(info)
     if d.get("check_lyap_res", False):
         # optcont_main.py:130: residual of the last Newton step's Lyapunov equation --
@@ -140,7 +203,7 @@ def compress_Zsvd(Z, thresh=None, k=None, shplot=False):
     (factors wider than 1024 columns, or ``backend.configure(compress_qr=0)``: Gram matrix +
     symmetric eigendecomposition).  ``shplot`` is accepted and ignored.
     """
-    Z = _dense(Z)
+    Z = _dense(np.asarray(Z))
     ctx = backend.context_dims(Z.shape[0])
     Zc, _ = ctx.compress(Z, thresh=thresh, k=k)
     return Zc
@@ -149,9 +212,19 @@ def compress_Zsvd(Z, thresh=None, k=None, shplot=False):
 def get_mTzzTtb(MT, Z, tb, output=None):
     """``MT * (Z * (Z^T * tb))``; the feedback gain is its negative
     (``optcont_main.py:505-506``; ``solve_dae_ric.py:101,183,189``)."""
-    Z = _dense(Z)
+    if _on_device(Z) and backend.operator_has_cale(MT):
+        # factor (and, if it was staged, tb) in HBM and MT = cal E of the resident operator: K on the device,
+        # only the NV x q result comes back
+        import torch
+        ctx = backend.context()
+        Zt, Bt = to_device(Z).t, to_device(tb).t
+        Kt = torch.empty_like(Bt)
+        torch.cuda.current_stream().synchronize()
+        ctx.gain_dev(1.0, Zt.data_ptr(), Zt.shape[1], Zt.shape[1], Bt.data_ptr(), Bt.shape[1], Kt.data_ptr())
+        return Kt.cpu().numpy()
+    Z = _dense(np.asarray(Z))
     ctx = backend.context_dims(Z.shape[0])
-    return ctx.gain(_dense(tb), Z=Z, MT=sps.csr_matrix(MT))
+    return ctx.gain(_dense(np.asarray(tb)), Z=Z, MT=sps.csr_matrix(MT))
 
 
 def comp_proj_lyap_res_norm(Z, amat=None, mmat=None, wmat=None, jmat=None,

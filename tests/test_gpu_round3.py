@@ -185,3 +185,38 @@ def test_recompress_pivoted_cholesky_route(nv, c, decades):
     # range(Zc) in range(Z)
     U = np.linalg.svd(Z, full_matrices=False)[0][:, :min(k_opt + 40, min(Z.shape))]
     assert np.linalg.norm(Zc - U @ (U.T @ Zc)) <= 1e-7 * np.linalg.norm(Zc)
+
+
+def test_device_resident_boundary_same_factor_and_gain():
+    """The mirror's device-resident form of the boundary calls (ricadi_ric_newtonadi_dev, DeviceFactor): panels
+    staged in HBM once, z0 and the new factor never cross PCIe.  Same Newton steps, same ADI steps, same K as the
+    ndarray form of the same calls and as the oracle (optcont_main.py:488-492,505; solve_dae_ric.py:152-159 with
+    z0 = the previous factor)."""
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    backend.reset()
+    pr, tb, trct, ms = _inputs(15, 0.1, nshifts=8)
+    F = (-pr.A - pr.Nc).tocsr()
+    MT = pr.M.T.tocsr()
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms, sweep_width=8)
+    host = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
+    K_h = -pru.get_mTzzTtb(MT, host["zfac"], tb)
+    tb_d, trct_d = pru.to_device(tb), pru.to_device(trct)
+    dev = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb_d, wmat=trct_d, nwtn_adi_dict=d)
+    assert isinstance(dev["zfac"], pru.DeviceFactor) and dev["zfac"].shape == host["zfac"].shape
+    assert dev["nwtn_steps"] == host["nwtn_steps"] and dev["adi_steps"] == host["adi_steps"]
+    K_d = -pru.get_mTzzTtb(MT, dev["zfac"], tb_d)
+    assert rel(K_d, K_h) < 1e-9
+    ref = opru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=dict(d))
+    assert rel(K_d, -opru.get_mTzzTtb(pr.M.T, ref["zfac"], tb)) < 1e-6
+    # one more step from the device-resident iterate (z0 a DeviceFactor) == from its host copy
+    d1 = dict(d, nwtn_max_steps=1)
+    nxt_d = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb_d, wmat=trct_d, z0=dev["zfac"],
+                                       nwtn_adi_dict=d1)
+    nxt_h = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=np.asarray(dev["zfac"]),
+                                       nwtn_adi_dict=d1)
+    assert nxt_d["adi_steps"] == nxt_h["adi_steps"]
+    assert rel(-pru.get_mTzzTtb(MT, nxt_d["zfac"], tb_d), -pru.get_mTzzTtb(MT, nxt_h["zfac"], tb)) < 1e-9
+    # a DeviceFactor is accepted wherever the mirror takes an ndarray (downloaded on demand)
+    Zc = pru.compress_Zsvd(dev["zfac"], thresh=1e-7)
+    assert Zc.shape[0] == pr.NV and Zc.shape[1] <= dev["zfac"].shape[1]
+    backend.reset()
