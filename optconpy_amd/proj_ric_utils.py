@@ -60,9 +60,19 @@ def to_device(a):
         return a
     if torch.is_tensor(a):
         return DeviceFactor(a.to(device="cuda", dtype=torch.float64).contiguous())
-    t = torch.from_numpy(np.ascontiguousarray(_dense(a), dtype=np.float64)).to("cuda:%d" % backend.device_id())
+    h = np.array(_dense(a), dtype=np.float64, order="C")           # private, writable copy for from_numpy
+    t = torch.from_numpy(h).to("cuda:%d" % backend.device_id())
     torch.cuda.synchronize()
     return DeviceFactor(t)
+
+
+def _host(a):
+    """ndarray / sparse matrix as is; a device panel downloaded."""
+    if isinstance(a, DeviceFactor):
+        return a.numpy()
+    if _on_device(a):
+        return a.cpu().numpy()
+    return a
 
 
 def _on_device(a):
@@ -203,7 +213,7 @@ def compress_Zsvd(Z, thresh=None, k=None, shplot=False):
     (factors wider than 1024 columns, or ``backend.configure(compress_qr=0)``: Gram matrix +
     symmetric eigendecomposition).  ``shplot`` is accepted and ignored.
     """
-    Z = _dense(np.asarray(Z))
+    Z = _dense(_host(Z))
     ctx = backend.context_dims(Z.shape[0])
     Zc, _ = ctx.compress(Z, thresh=thresh, k=k)
     return Zc
@@ -222,9 +232,9 @@ def get_mTzzTtb(MT, Z, tb, output=None):
         torch.cuda.current_stream().synchronize()
         ctx.gain_dev(1.0, Zt.data_ptr(), Zt.shape[1], Zt.shape[1], Bt.data_ptr(), Bt.shape[1], Kt.data_ptr())
         return Kt.cpu().numpy()
-    Z = _dense(np.asarray(Z))
+    Z = _dense(_host(Z))
     ctx = backend.context_dims(Z.shape[0])
-    return ctx.gain(_dense(np.asarray(tb)), Z=Z, MT=sps.csr_matrix(MT))
+    return ctx.gain(_dense(_host(tb)), Z=Z, MT=sps.csr_matrix(MT))
 
 
 def comp_proj_lyap_res_norm(Z, amat=None, mmat=None, wmat=None, jmat=None,
