@@ -48,7 +48,11 @@ struct DArr {
   DArr& operator=(const DArr&) = delete;
   ~DArr() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      static const bool dbg = getenv("RICADI_DEBUG_FREE") != nullptr;
+      if (dbg) fprintf(stderr, "[ricadi free] %zu bytes\n", n * sizeof(T));
+      (void)hipFree(p);
+    }
     p = nullptr;
     n = 0;
   }
