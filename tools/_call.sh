@@ -1,13 +1,11 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r3x8; mkdir -p $O
-RICADI_TIMING=1 RICADI_DEBUG_FREE=1 python bench.py --no-large-roofline --no-cpu-baseline --no-extras --steps 3 --warmup 1 2> $O/free.err > /dev/null
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r3x10; mkdir -p $O
+RICADI_OPTS="coarse_max=8192" timeout -k 10 900 python bench.py --workload cfg5 --steps 1 --warmup 1 > $O/cfg5_c8192.json 2> $O/cfg5_c8192.err; cut -c1-160 $O/cfg5_c8192.json; echo; tail -3 $O/cfg5_c8192.err
+RICADI_OPTS="coarse_max=8192" timeout -k 10 900 python bench.py --workload cfg4 --steps 1 --warmup 1 > $O/cfg4_c8192.json 2> $O/cfg4_c8192.err; cut -c1-160 $O/cfg4_c8192.json; echo
 python - <<'PY'
-import re,collections
-lines=open("gpurun_out/r3x8/free.err").read().splitlines()
-# indices of 'Newton step 1: total' lines
-idx=[i for i,l in enumerate(lines) if "Newton step" in l and "total" in l]
-print(len(idx), "newton lines")
-# frees between the last two Newton lines (one full timed step)
-a,b=idx[-2],idx[-1]
-c=collections.Counter(l.split()[2] for l in lines[a:b] if "ricadi free" in l)
-print(sum(c.values()), "frees in one step:", c.most_common(12))
+import json
+for w in ['cfg5_c8192','cfg4_c8192']:
+    try:
+        d=json.load(open('gpurun_out/r3x10/%s.json'%w)); c=d['config']
+        print(w, d['value'], d['ms_per_step'], {k:c[k] for k in c if 'iter' in k or 'level' in k or 'coarse' in k or 'nonconv' in k})
+    except Exception as e: print(w, e)
 PY
