@@ -8,6 +8,7 @@
 // Nothing here follows reference code: the reference solves these systems with
 // SuperLU.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -139,7 +140,7 @@ static HostCsr galerkin(const HostCsr& M, int nrow_c, const int* rows_ptr, const
 }
 
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
-                 HostSetup& hs, int max_levels) {
+                 HostSetup& hs, int max_levels, double sa_omega) {
   const int nv = A.nrows, np = J.nrows, n = nv + np;
   hs.nv = nv;
   hs.np = np;
@@ -416,6 +417,129 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   for (int i = 0; i < nv; ++i) hs.aggof[i] = va[i];
   for (int k = 0; k < np; ++k) hs.aggof[nv + k] = kv + pa[k];
   lists_from_blocks(n, hs.aggof.data(), kc, hs.agg_ptr, hs.agg_rows);
+  // ---- prolongation P (rows): plain aggregation, or smoothed on the velocity rows ----------------
+  hs.sa = sa_omega > 0.0 && !hs.multilevel && np > 0 && kv > 0;
+  if (hs.sa) {
+    // Only for a stiffness-like cal A -- constants nearly in the kernel of its symmetric part: row sums small against
+    // the diagonal (NSE operator 0.01-0.06, DRE operator at n = 3e4 0.03; a mass matrix 1.6).  Smoothing the
+    // aggregates with a mass-like matrix makes the cycle WORSE (numpy mirror, [[M, J^T],[J, 0]]: 54 -> 122
+    // iterations at omega = 0.5, no convergence at 0.67).
+    double srs = 0.0, sdg = 0.0;
+    std::vector<double> colsum(nv, 0.0);
+    for (int i = 0; i < nv; ++i)
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) colsum[A.ci[k]] += A.v[k];
+    for (int i = 0; i < nv; ++i) {
+      double rsum = 0.0, dg = 0.0;
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+        rsum += A.v[k];
+        if (A.ci[k] == i) dg += A.v[k];
+      }
+      srs += std::fabs(0.5 * (rsum + colsum[i]));
+      sdg += std::fabs(dg);
+    }
+    if (!(sdg > 0.0) || srs > 0.15 * sdg) hs.sa = false;
+    if (o.verbose)
+      fprintf(stderr, "[ricadi] smoothed aggregation %s: row sums / diagonal of sym(cal A) = %.3f\n", hs.sa ? "on" : "off",
+              sdg > 0.0 ? srs / sdg : -1.0);
+  }
+  hs.p_rp.clear(); hs.p_ci.clear(); hs.p_v.clear();
+  hs.pt_rp.clear(); hs.pt_ci.clear(); hs.pt_v.clear();
+  hs.pd_rp.clear(); hs.pd_ci.clear(); hs.pd_v.clear();
+  if (hs.sa) {
+    const HostCsr At = transpose(A);
+    // damping relative to the spectral radius of D^-1 K0 (power iteration): the prolongation smoother
+    // I - omega D^-1 K0 must not amplify -- a mass-like cal A (lau.app_prj_via_sadpnt hands the mass matrix over
+    // as the operator) has rho ~ 4 for P2 elements, and omega = 0.67 made GMRES fail there
+    {
+      std::vector<double> dg(nv, 0.0), x(nv), y(nv);
+      for (int i = 0; i < nv; ++i)
+        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+          if (A.ci[k] == i) dg[i] += A.v[k];
+      unsigned sd = 12345u;
+      for (int i = 0; i < nv; ++i) {
+        sd = sd * 1664525u + 1013904223u;
+        x[i] = (double)(sd >> 8) / 16777216.0 - 0.5;
+      }
+      double rho = 0.0;
+      for (int it = 0; it < 20; ++it) {
+        double nx = 0.0, ny = 0.0;
+        for (int i = 0; i < nv; ++i) {
+          double t = 0.0;
+          for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) t += A.v[k] * x[A.ci[k]];
+          for (int k = At.rp[i]; k < At.rp[i + 1]; ++k) t += At.v[k] * x[At.ci[k]];
+          y[i] = dg[i] != 0.0 ? 0.5 * t / dg[i] : 0.0;
+          nx += x[i] * x[i];
+          ny += y[i] * y[i];
+        }
+        rho = nx > 0.0 ? std::sqrt(ny / nx) : 0.0;
+        const double sc = ny > 0.0 ? 1.0 / std::sqrt(ny) : 0.0;
+        for (int i = 0; i < nv; ++i) x[i] = y[i] * sc;
+      }
+      if (rho > 2.0) sa_omega *= 2.0 / rho;
+      if (o.verbose) fprintf(stderr, "[ricadi] smoothed aggregation: rho(D^-1 K0) ~ %.2f, omega %.3f\n", rho, sa_omega);
+    }
+    hs.p_rp.assign(1, 0);
+    hs.pd_rp.assign(1, 0);
+    std::vector<int> where(kc, -1);
+    for (int i = 0; i < nv; ++i) {
+      const int r0 = (int)hs.p_ci.size();
+      auto add = [&](int a, double w) {
+        int at = where[a];
+        if (at < r0) {
+          at = (int)hs.p_ci.size();
+          where[a] = at;
+          hs.p_ci.push_back(a);
+          hs.p_v.push_back(0.0);
+        }
+        hs.p_v[at] += w;
+      };
+      add(va[i], 1.0);
+      double d = 0.0;
+      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k)
+        if (A.ci[k] == i) d += A.v[k];
+      if (d != 0.0) {
+        const double sc = -0.5 * sa_omega / d;         // K0 = (A + A^T) / 2
+        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) add(va[A.ci[k]], sc * A.v[k]);
+        for (int k = At.rp[i]; k < At.rp[i + 1]; ++k) add(va[At.ci[k]], sc * At.v[k]);
+      }
+      hs.p_rp.push_back((int)hs.p_ci.size());
+      for (int k = r0; k < (int)hs.p_ci.size(); ++k) {
+        hs.pd_ci.push_back(hs.p_ci[k]);
+        hs.pd_v.push_back(hs.p_v[k] - (hs.p_ci[k] == va[i] ? 1.0 : 0.0));
+      }
+      hs.pd_rp.push_back((int)hs.pd_ci.size());
+    }
+    for (int k = 0; k < np; ++k) {
+      hs.p_ci.push_back(kv + pa[k]);
+      hs.p_v.push_back(1.0);
+      hs.p_rp.push_back((int)hs.p_ci.size());
+    }
+    // P^T by rows
+    hs.pt_rp.assign(kc + 1, 0);
+    for (int c : hs.p_ci) hs.pt_rp[c + 1]++;
+    for (int a = 0; a < kc; ++a) hs.pt_rp[a + 1] += hs.pt_rp[a];
+    hs.pt_ci.resize(hs.p_ci.size());
+    hs.pt_v.resize(hs.p_ci.size());
+    std::vector<int> pos(hs.pt_rp.begin(), hs.pt_rp.end() - 1);
+    for (int i = 0; i < n; ++i)
+      for (int k = hs.p_rp[i]; k < hs.p_rp[i + 1]; ++k) {
+        const int at = pos[hs.p_ci[k]]++;
+        hs.pt_ci[at] = i;
+        hs.pt_v[at] = hs.p_v[k];
+      }
+  }
+  // the entries of row j of P (plain aggregation: the single (aggof[j], 1))
+  auto prow = [&](int j, const int*& ci, const double*& v) -> int {
+    static const double one = 1.0;
+    if (hs.sa) {
+      ci = hs.p_ci.data() + hs.p_rp[j];
+      v = hs.p_v.data() + hs.p_rp[j];
+      return hs.p_rp[j + 1] - hs.p_rp[j];
+    }
+    ci = hs.aggof.data() + j;
+    v = &one;
+    return 1;
+  };
   if (hs.multilevel) {
     hs.l1A = galerkin(A, kv, hs.agg_ptr.data(), hs.agg_rows.data(), 0, va.data(), kv);
     hs.l1E = galerkin(E, kv, hs.agg_ptr.data(), hs.agg_rows.data(), 0, va.data(), kv);
@@ -425,15 +549,30 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   hs.EM.assign((size_t)kc * kc, 0.0);
   hs.EJ.assign((size_t)kc * kc, 0.0);
   for (int i = 0; i < nv; ++i) {
-    const size_t ra = (size_t)va[i] * kc;
-    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) hs.E0[ra + va[A.ci[k]]] += A.v[k];
-    for (int k = E.rp[i]; k < E.rp[i + 1]; ++k) hs.EM[ra + va[E.ci[k]]] += E.v[k];
+    const int *ri, *cj;
+    const double *rw, *cw;
+    const int nri = prow(i, ri, rw);
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      const int ncj = prow(A.ci[k], cj, cw);
+      for (int a = 0; a < nri; ++a)
+        for (int b = 0; b < ncj; ++b) hs.E0[(size_t)ri[a] * kc + cj[b]] += rw[a] * A.v[k] * cw[b];
+    }
+    for (int k = E.rp[i]; k < E.rp[i + 1]; ++k) {
+      const int ncj = prow(E.ci[k], cj, cw);
+      for (int a = 0; a < nri; ++a)
+        for (int b = 0; b < ncj; ++b) hs.EM[(size_t)ri[a] * kc + cj[b]] += rw[a] * E.v[k] * cw[b];
+    }
   }
   for (int k = 0; k < np; ++k)
     for (int q = J.rp[k]; q < J.rp[k + 1]; ++q) {
-      const int cp = kv + pa[k], cv = va[J.ci[q]];
-      hs.EJ[(size_t)cp * kc + cv] += J.v[q];
-      hs.EJ[(size_t)cv * kc + cp] += J.v[q];
+      const int cp = kv + pa[k];
+      const int* cj;
+      const double* cw;
+      const int ncj = prow(J.ci[q], cj, cw);
+      for (int b = 0; b < ncj; ++b) {
+        hs.EJ[(size_t)cp * kc + cj[b]] += J.v[q] * cw[b];
+        hs.EJ[(size_t)cj[b] * kc + cp] += J.v[q] * cw[b];
+      }
     }
   }
   // ---- prolongated operator S*Y (n x kc, sparse) -----------------------------
@@ -451,19 +590,24 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
     for (int i = 0; i < n; ++i) {
       const int r0 = (int)hs.sy_ci.size();
       for (int k = hs.s_rp[i]; k < hs.s_rp[i + 1]; ++k) {
-        const int a = hs.aggof[hs.s_ci[k]];
-        int at = where[a];
-        if (at < r0) {              // not seen in this row yet
-          at = (int)hs.sy_ci.size();
-          where[a] = at;
-          hs.sy_ci.push_back(a);
-          hs.sy_A.push_back(0.0);
-          hs.sy_E.push_back(0.0);
-          hs.sy_J.push_back(0.0);
+        const int* cj;
+        const double* cw;
+        const int ncj = prow(hs.s_ci[k], cj, cw);
+        for (int b = 0; b < ncj; ++b) {
+          const int a = cj[b];
+          int at = where[a];
+          if (at < r0) {              // not seen in this row yet
+            at = (int)hs.sy_ci.size();
+            where[a] = at;
+            hs.sy_ci.push_back(a);
+            hs.sy_A.push_back(0.0);
+            hs.sy_E.push_back(0.0);
+            hs.sy_J.push_back(0.0);
+          }
+          hs.sy_A[at] += hs.s_srcA[k] * cw[b];
+          hs.sy_E[at] += hs.s_srcE[k] * cw[b];
+          hs.sy_J[at] += hs.s_srcJ[k] * cw[b];
         }
-        hs.sy_A[at] += hs.s_srcA[k];
-        hs.sy_E[at] += hs.s_srcE[k];
-        hs.sy_J[at] += hs.s_srcJ[k];
       }
       hs.sy_rp.push_back((int)hs.sy_ci.size());
     }

@@ -66,6 +66,15 @@ struct HostSetup {
   // aggregate sizes); its Galerkin matrices Yv^T A Yv, Yv^T E Yv, Yp^T J Yv go to a child level.
   bool multilevel = false;
   HostCsr l1A, l1E, l1J;
+  // Smoothed aggregation (round 3; two-level setups only): the velocity part of the prolongation is
+  //   P_v = (I - omega D^-1 K0) Y_v,  K0 = sym(cal A), D = diag(K0)
+  // -- shift independent, so that P^T S(p) P and S(p) P stay linear in (alpha, beta).  p_*: P by rows (all n rows;
+  // pressure rows are the piecewise-constant ones), pt_*: P^T by rows (the restriction), pd_*: P - Y on the
+  // velocity rows (its action on the coarse vector is folded into the first velocity sweep).  With sa == false
+  // P = Y and these arrays are empty.
+  bool sa = false;
+  std::vector<int> p_rp, p_ci, pt_rp, pt_ci, pd_rp, pd_ci;
+  std::vector<double> p_v, pt_v, pd_v;
   // S * Y: CSR over (row, aggregate) with the three value sources of the saddle pattern
   std::vector<int> sy_rp, sy_ci;
   std::vector<double> sy_A, sy_E, sy_J;
@@ -75,7 +84,7 @@ struct HostSetup {
   std::vector<uint16_t> syb_lidx;
 };
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
-                 HostSetup& hs, int max_levels = 2);
+                 HostSetup& hs, int max_levels = 2, double sa_omega = 0.0);
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
 int deal_shifts(const double* shifts, int ns, int world, int32_t* owner);
 int gram_lstsq(int h, int m, const double* Ghh, const double* Ghb, double rtol, double* Y);
@@ -317,8 +326,8 @@ void launch_block_apply2_b(hipStream_t st, const GroupTab& gt, int bs, int nbloc
                            const Seg2& s2, double* out, int ldo, size_t gso, int m, const ProlongArgs& pa);
 // per shift:  out[b] = Ainv[b] * (alpha dE[b] + beta dA[b] + dJ[b])   (dense slices of S*Y, bs x ks)
 void launch_ady_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* dA,
-                       const double* dE, const double* dJ, const double* alphas, const double* betas,
-                       const GroupPtrs& ainv, const GroupPtrs& out);
+                       const double* dE, const double* dJ, const double* dT, const double* alphas,
+                       const double* betas, const GroupPtrs& ainv, const GroupPtrs& out);
 void launch_gt_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* jtd,
                       const GroupPtrs& ainv, const GroupPtrs& out);
 void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int lds_, float* dst,

@@ -2458,7 +2458,8 @@ struct ShiftCoefs {
 };
 __global__ __launch_bounds__(256) void ady_blocks_kernel(int bs, int ks, const double* __restrict__ dA,
                                                          const double* __restrict__ dE,
-                                                         const double* __restrict__ dJ, ShiftCoefs cf,
+                                                         const double* __restrict__ dJ,
+                                                         const double* __restrict__ dT, ShiftCoefs cf,
                                                          GroupPtrs ainvs, GroupPtrs outs) {
   extern __shared__ double sm[];            // Ai (bs x bs), D (bs x ks)
   double* Ai = sm;
@@ -2474,12 +2475,13 @@ __global__ __launch_bounds__(256) void ady_blocks_kernel(int bs, int ks, const d
     const int i = e / ks, j = e - i * ks;
     double sacc = 0.0;
     for (int t = 0; t < bs; ++t) sacc = fma(Ai[i * bs + t], D[t * ks + j], sacc);
-    out[e] = sacc;
+    // smoothed aggregation: the sweep subtracts (out e); (P - Y) e is ADDED to the sweep's result there
+    out[e] = dT ? sacc - dT[off + e] : sacc;
   }
 }
 void launch_ady_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, const double* dA,
-                       const double* dE, const double* dJ, const double* alphas, const double* betas,
-                       const GroupPtrs& ainv, const GroupPtrs& out) {
+                       const double* dE, const double* dJ, const double* dT, const double* alphas,
+                       const double* betas, const GroupPtrs& ainv, const GroupPtrs& out) {
   if (nblocks <= 0 || nshift <= 0) return;
   ShiftCoefs cf;
   for (int i = 0; i < RICADI_MAX_GROUPS; ++i) {
@@ -2487,7 +2489,7 @@ void launch_ady_blocks(hipStream_t st, int nshift, int nblocks, int bs, int ks, 
     cf.beta[i] = i < nshift ? betas[i] : 0.0;
   }
   hipLaunchKernelGGL(ady_blocks_kernel, dim3(nblocks, nshift), dim3(256),
-                     (size_t)(bs * bs + bs * ks) * sizeof(double), st, bs, ks, dA, dE, dJ, cf, ainv, out);
+                     (size_t)(bs * bs + bs * ks) * sizeof(double), st, bs, ks, dA, dE, dJ, dT, cf, ainv, out);
 }
 
 // G[b] = Ainv[b] (bs x bs) * JTd[b] (bs x ks)  for every velocity block b and every shift of the

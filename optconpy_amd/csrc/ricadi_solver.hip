@@ -266,7 +266,11 @@ struct ricadi_ctx {
   bool ady_ok = false;
   int ady_ks = 0;
   DArr<int> cy_ptr, cy_cols;
-  DArr<double> cy_dA, cy_dE, cy_dJ;
+  DArr<double> cy_dA, cy_dE, cy_dJ, cy_dT;
+  // smoothed aggregation (HostSetup::sa): P^T by rows for the restriction; cy_dT = dense slices of P - Y
+  bool sa = false;
+  DArr<int> pt_rp, pt_ci;
+  DArr<double> pt_v;
   bool gt_ok = false;
   int gt_ks = 0;
   DArr<int> gt_ptr, gt_cols;
@@ -599,7 +603,8 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         al[i] = todo[t0 + i]->alpha;
         be[i] = todo[t0 + i]->beta;
       }
-      launch_ady_blocks(st, cnt, c->nbv, c->bs, c->ady_ks, c->cy_dA.p, c->cy_dE.p, c->cy_dJ.p, al, be, pv, pa_);
+      launch_ady_blocks(st, cnt, c->nbv, c->bs, c->ady_ks, c->cy_dA.p, c->cy_dE.p, c->cy_dJ.p,
+                        c->sa ? c->cy_dT.p : nullptr, al, be, pv, pa_);
     }
     if (c->nbp > 0) {
       launch_schur_blocks_bj(st, cnt, c->nbp, c->bs, c->bp_ptr.p, c->jd_ptr.p, c->jd_vblk.p,
@@ -904,12 +909,17 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
     if (!folded || m > 16) r16 = nullptr;
+    // (smoothed aggregation: P^T r with the rows of P^T)
+    const int* rrp = c->sa ? c->pt_rp.p : c->agg_ptr.p;
+    const int* rci = c->sa ? c->pt_ci.p : c->agg_rows.p;
+    const GroupPtrs rvals = c->sa ? same_ptr((const double*)c->pt_v.p) : ones;
+    if (c->sa && !folded) throw HipError{"smoothed aggregation needs the folded preconditioner cycle"};
     if (!on(0)) {
     } else if (r16)
-      launch_spmm_h(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, nullptr, r16, m, gsr, c->rc.p, m, bt.gsc,
+      launch_spmm_h(st, gt, c->kc, rrp, rci, rvals, nullptr, r16, m, gsr, c->rc.p, m, bt.gsc,
                     nullptr, 0, 0, 1.0, 0.0, m, 16);
     else
-      launch_spmm_b(st, gt, c->kc, c->agg_ptr.p, c->agg_rows.p, ones, r, m, gsr, nullptr, c->rc.p, m,
+      launch_spmm_b(st, gt, c->kc, rrp, rci, rvals, r, m, gsr, nullptr, c->rc.p, m,
                     bt.gsc, nullptr, 0, 0, 1.0, 0.0, m);
     if (!on(1)) {
     } else if (c->child) {
@@ -2848,7 +2858,30 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   HostSetup hs;
   if (!c->borrowed)
     c->levels = getenv("RICADI_LEVELS") ? std::max(2, atoi(getenv("RICADI_LEVELS"))) : std::max(2, c->opts.max_levels);
-  build_setup(A, E, J, c->opts, hs, c->levels);
+  // smoothed aggregation of the velocity prolongation (two-level setups, folded preconditioner cycle only);
+  // RICADI_SA=0 switches it off, RICADI_SA=<omega> sets the damping
+  double sa_omega = getenv("RICADI_SA") ? atof(getenv("RICADI_SA")) : 0.5;
+  if (c->borrowed || np == 0 || getenv("RICADI_NO_FOLD") || c->opts.bj_block != 32) sa_omega = 0.0;
+  build_setup(A, E, J, c->opts, hs, c->levels, sa_omega);
+  if (hs.sa) {
+    // the folded first sweep takes per-block dense slices of S*P of at most 64 columns
+    int kmax = 0;
+    std::vector<int> tmp;
+    for (int b = 0; b < hs.nbv; ++b) {
+      tmp.clear();
+      for (int q = hs.bv_ptr[b]; q < hs.bv_ptr[b + 1]; ++q)
+        for (int kk = hs.sy_rp[hs.bv_rows[q]]; kk < hs.sy_rp[hs.bv_rows[q] + 1]; ++kk) tmp.push_back(hs.sy_ci[kk]);
+      std::sort(tmp.begin(), tmp.end());
+      kmax = std::max(kmax, (int)(std::unique(tmp.begin(), tmp.end()) - tmp.begin()));
+    }
+    if (kmax > 64 || !block_apply2_ok(hs.bs, 64)) {
+      if (c->opts.verbose)
+        fprintf(stderr, "[ricadi] smoothed aggregation off: a velocity block touches %d coarse columns\n", kmax);
+      hs = HostSetup();
+      build_setup(A, E, J, c->opts, hs, c->levels, 0.0);
+    }
+  }
+  c->sa = hs.sa;
   c->cache.clear();
   c->child.reset();
   if (hs.multilevel) {
@@ -2948,6 +2981,11 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->agg_ptr.upload(hs.agg_ptr, st);
   c->agg_rows.upload(hs.agg_rows, st);
   c->aggof.upload(hs.aggof, st);
+  if (hs.sa) {
+    c->pt_rp.upload(hs.pt_rp, st);
+    c->pt_ci.upload(hs.pt_ci, st);
+    c->pt_v.upload(hs.pt_v, st);
+  }
   c->synnz = hs.sy_ci.size();
   c->sy_chunk = (c->synnz <= (size_t)10 * std::max(c->n, 1)) ? 8 : 16;
   if (c->opts.verbose)
@@ -2979,7 +3017,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
       const int ks = kmax <= 32 ? 32 : (kmax <= 64 ? 64 : 0);
       if (ks > 0 && block_apply2_ok(hs.bs, ks)) {
         const size_t tot = (size_t)hs.nbv * hs.bs * ks;
-        std::vector<double> dA(tot, 0.0), dE(tot, 0.0), dJ(tot, 0.0);
+        std::vector<double> dA(tot, 0.0), dE(tot, 0.0), dJ(tot, 0.0), dT(hs.sa ? tot : 0, 0.0);
         for (int b = 0; b < hs.nbv; ++b) {
           const int* cb = ccols.data() + cptr[b];
           const int nc = cptr[b + 1] - cptr[b];
@@ -2992,8 +3030,15 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
               dE[at] += hs.sy_E[kk];
               dJ[at] += hs.sy_J[kk];
             }
+            if (hs.sa)       // (P - Y)[row, :]: its columns are among those of (S P)[row, :] (S has a diagonal)
+              for (int kk = hs.pd_rp[row]; kk < hs.pd_rp[row + 1]; ++kk) {
+                const int* f = std::lower_bound(cb, cb + nc, hs.pd_ci[kk]);
+                if (f == cb + nc || *f != hs.pd_ci[kk]) throw ricadi::HipError{"smoothed prolongation: column outside the block's list"};
+                dT[((size_t)b * hs.bs + il) * ks + (int)(f - cb)] += hs.pd_v[kk];
+              }
           }
         }
+        if (hs.sa) c->cy_dT.upload(dT, st);
         c->cy_ptr.upload(cptr, st);
         c->cy_cols.upload(ccols, st);
         c->cy_dA.upload(dA, st);

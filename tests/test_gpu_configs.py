@@ -151,10 +151,12 @@ def test_cfg4_dre_operator_wide_panel_properties():
     print("cfg4: tau %.4f iterations per shift" % tau, its, "worst true residual %.2e" % worst)
 
 
-def test_third_level_forced_small_problem():
+def test_third_level_forced_small_problem(monkeypatch):
     """The child-level path (coarse problem handed to a second context instead of a dense inverse) on a
     problem small enough for the quick suite: N = 30 with coarse_max = 300 takes three levels, and the
-    same solve with max_levels = 2 (aggregates grown instead) must not need fewer iterations."""
+    same solve with max_levels = 2 (aggregates grown instead) must not need fewer iterations -- like for like:
+    plain aggregation on both (the two-level setup would otherwise smooth its aggregates, round 3)."""
+    monkeypatch.setenv("RICADI_SA", "0")
     pr = pb.ricc_problem(30, 0.05)
     calA = (-pr.A - pr.Nc).T.tocsr()
     ms = [float(p) for p in pb.logshifts(1.0, 1e3, 8)]
