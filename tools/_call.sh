@@ -1,2 +1,4 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r3x13; mkdir -p $O
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; tail -6 $O/gputests.log
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+timeout 600 python tools/robustness_probe.py 2>&1 | grep "^N="
+timeout 600 python tools/ml_probe.py 58 2>&1 | tail -4
+tools/ab.sh r3x16 "sa05:"
