@@ -3059,7 +3059,7 @@ void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int 
 // added with FP64 atomics (C must be zeroed by the caller).
 // ---------------------------------------------------------------------------
 template <int TI, int TJ>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GroupTab gt, int ptiles, int n, int p, int q,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_tn_kernel(GroupTab gt, int ptiles, int n, int p, int q,
                                                       const double* __restrict__ A, int lda,
                                                       const double* __restrict__ B, int ldb,
                                                       size_t gsB, double* __restrict__ C, int ldc,
@@ -3086,25 +3086,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GroupTab gt, int ptiles, i
   for (int a = 0; a < TI; ++a)
 #pragma unroll
     for (int b = 0; b < TJ; ++b) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-  for (int r = rbeg; r < rend; r += 4) {
+  // operands of the NEXT 4-row step are loaded before the MFMAs of the current one (a wide product runs about one
+  // wave per SIMD: without the prefetch every step waited a full memory round trip for its 8 loads)
+  double af[TI], bf[TJ], afn[TI], bfn[TJ];
+  auto load4 = [&](int r, double (&fa)[TI], double (&fb)[TJ]) {
     const int rr = r + lk;
     const bool rok = rr < rend;
-    double af[TI], bf[TJ];
 #pragma unroll
     for (int a = 0; a < TI; ++a) {
       const int col = i0 + 16 * a + lc;
-      af[a] = (rok && col < p) ? A[(size_t)rr * lda + col] : 0.0;
+      fa[a] = (rok && col < p) ? A[(size_t)rr * lda + col] : 0.0;
     }
 #pragma unroll
     for (int b = 0; b < TJ; ++b) {
       const int col = j0 + 16 * b + lc;
-      bf[b] = (rok && col < q) ? B[(size_t)rr * ldb + col] : 0.0;
+      fb[b] = (rok && col < q) ? B[(size_t)rr * ldb + col] : 0.0;
     }
+  };
+  if (rbeg < rend) load4(rbeg, af, bf);
+  for (int r = rbeg; r < rend; r += 4) {
+    load4(r + 4, afn, bfn);                  // rows >= rend read as zeros
 #pragma unroll
     for (int a = 0; a < TI; ++a)
 #pragma unroll
       for (int b = 0; b < TJ; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < TI; ++a) af[a] = afn[a];
+#pragma unroll
+    for (int b = 0; b < TJ; ++b) bf[b] = bfn[b];
   }
   if (TI * TJ > 4) {
     // wide products: the atomics are spread over many outputs; every wave adds
