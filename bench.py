@@ -200,7 +200,11 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     fl = "float" if pb_ == 4 else "double"
     few = nb * G <= 8192
     stages = {
-        "pc_restrict": ("ricadi::spmm_kernel_v2 (unit values, aggregate lists)", G * (vin * n * m + 8.0 * kc0 * m) + 4.0 * n),
+        "pc_restrict": ("ricadi::spmm_kernel_v2 (rows of P^T: smoothed aggregation, %.1f entries per dof)"
+                        % (info.get("nnz_restriction", n) / max(n, 1)) if info.get("nnz_restriction", n) > n
+                        else "ricadi::spmm_kernel_v2 (unit values, aggregate lists)",
+                        G * (vin * n * m + 8.0 * kc0 * m) + (12.0 if info.get("nnz_restriction", n) > n else 4.0)
+                        * info.get("nnz_restriction", n)),
         "pc_coarse": (models["coarse"][0] if info["levels"] <= 2 else "child level: one full cycle of its own stages",
                       models["coarse"][1] if info["levels"] <= 2 else None),
         "pc_sy_prows": ("ricadi::spmm_kernel_v2 (pressure rows of S*Y)", None),

@@ -617,11 +617,11 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 16)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 16))
+        a = (C.c_int * 17)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 17))
         return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
                          "dense_coarse", "fp16_vector_input", "rect_ks", "two_term_ks", "np_", "nnz_j",
-                         "nnz_sy"), list(a)))
+                         "nnz_sy", "nnz_restriction"), list(a)))
 
     def time_qr_dev(self, z_ptr, c, reps):
         ms = C.c_double(0.0)

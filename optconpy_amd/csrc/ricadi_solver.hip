@@ -3756,6 +3756,8 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   if (nout > 13) out[13] = c->np;
   if (nout > 14) out[14] = (int)c->J.ci.n;
   if (nout > 15) out[15] = c->kc > 0 && c->np > 0 ? (int)(c->synnz) : 0;
+  // [16]: entries of the restriction (rows of P^T with smoothed aggregation; else one per dof)
+  if (nout > 16) out[16] = c->kc > 0 ? (c->sa ? (int)c->pt_ci.n : c->n) : 0;
   return RICADI_OK;
 }
 

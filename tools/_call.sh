@@ -1,2 +1,12 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tools/ab.sh r3x17 "base:" "rec3:RICADI_RECYCLE=3" "rec8:RICADI_RECYCLE=8" "cyc8:RICADI_CYC0=8" "cyc12:RICADI_CYC0=12" "cyc15:RICADI_CYC0=15" "ap20:RICADI_OPTS=agg_p=20" "ap32x:RICADI_OPTS=agg_p=36" "av12:RICADI_OPTS=agg_v=12" "av20:RICADI_OPTS=agg_v=20" "base2:"
+timeout -k 10 120 python tools/qr_probe.py 26450 456 2>&1 | grep -v amdgpu.ids
+timeout -k 10 120 python tools/recompress_probe.py 26450 768 2>&1 | tail -1
+python - <<'PY'
+import sys; sys.path.insert(0,'.')
+import bench, torch
+from optconpy_amd import _lib
+ctx=_lib.Context(0); ctx.set_dims(26450)
+print(bench.gram_mfma(ctx, 26450, 512)); print(bench.gram_mfma(ctx, 26450, 128))
+PY
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -x -q -k "tsqr or compress or gain or update" 2>&1 | tail -2
+tools/ab.sh r3x18 "pref:" "pref2:"
