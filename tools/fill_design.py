@@ -11,9 +11,10 @@ vals = {"VALUE": "%.1f" % d["value"], "MS": "%.1f" % d["ms_per_step"], "ITS": "%
         "CFG3": "%.1f" % c3["value"], "CFG4": "%.1f" % c4["value"], "CFG5": "%.2f" % c5["value"], "CFG5S": "%.1f" % (c5["ms_per_step"] / 1e3),
         "DRE_S": "%.0f" % (dre["ms_per_step"] / 1e3), "DRE_V": "%.1f" % dre["value"],
         "CPU": "%.1f" % d["cpu_baseline"]["value"], "CPU1": "%.1f" % d["cpu_baseline"]["single_core"]["value"], "R2": "%.0f" % r2["value"]}
-s = open("DESIGN.md").read()
-for k, v in vals.items():
-    s = s.replace("@@%s@@" % k, v)
-left = re.findall(r"@@[A-Z0-9_]+@@", s)
-open("DESIGN.md", "w").write(s)
-print("filled", len(vals), "left:", left)
+for f in ("DESIGN.md", "README.md"):
+    s = open(f).read()
+    for k, v in vals.items():
+        s = s.replace("@@%s@@" % k, v)
+    left = re.findall(r"@@[A-Z0-9_]+@@", s)
+    open(f, "w").write(s)
+    print(f, "filled", len(vals), "left:", left)
