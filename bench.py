@@ -754,6 +754,8 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    step_ms = []
+
     def timed(step, nsteps, nwarm):
         for _ in range(nwarm):
             step()
@@ -761,11 +763,14 @@ def main():
         t0 = time.perf_counter()
         units = iters = solves = 0
         K = None
+        step_ms.clear()
         for _ in range(nsteps):
+            ts = time.perf_counter()
             u, it, K, ls = step()
             units += u
             iters += it
             solves += ls
+            step_ms.append(round(1e3 * (time.perf_counter() - ts), 1))
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
@@ -775,6 +780,7 @@ def main():
         return units, iters, solves, K, el
 
     units, iters, local_solves, K, elapsed = timed(one_step, args.steps, args.warmup)
+    main_step_ms = list(step_ms)
     k_conv = float(np.linalg.norm(K - K_conv) / np.linalg.norm(K_conv))
     k_orc = None if K_oracle is None else float(np.linalg.norm(K - K_oracle) / np.linalg.norm(K_oracle))
 
@@ -804,6 +810,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+            "ms_of_each_step": main_step_ms,
             "higher_is_better": True,
             "scaling": "strong",          # the same problem at every N
             "vs_baseline": None,
