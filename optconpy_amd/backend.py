@@ -44,6 +44,9 @@ def device_id():
 def _fingerprint(m):
     if m is None:
         return None
+    fp = getattr(m, "_ricadi_fp", None)        # the mirror's own converted operands carry theirs (proj_ric_utils._orient)
+    if fp is not None:
+        return fp
     m = sps.csr_matrix(m)
     d = m.data
     return (m.shape, m.nnz, float(d.sum()) if d.size else 0.0,

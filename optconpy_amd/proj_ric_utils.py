@@ -97,12 +97,42 @@ def _dense(a):
     return a.reshape(-1, 1) if a.ndim == 1 else a
 
 
+_orient_memo = {}
+
+
+def _content_sig(m):
+    """Cheap content signature of a scipy sparse matrix as handed over (no format conversion)."""
+    d = m.data
+    idx = getattr(m, "indices", None)
+    return (type(m).__name__, m.shape, int(m.nnz), float(d.sum()) if d.size else 0.0,
+            float(np.abs(d).sum()) if d.size else 0.0,
+            int(idx[::97].sum()) if idx is not None and idx.size else 0)
+
+
 def _orient(amat, mmat, transposed):
-    amat = sps.csr_matrix(amat)
-    mmat = sps.csr_matrix(mmat)
-    if transposed:
-        return amat, mmat
-    return amat.T.tocsr(), mmat.T.tocsr()
+    """(cal A, cal E) in CSR.  The reference re-passes the same matrices with every call
+    (``optcont_main.py:488-492``): the conversion (two CSR transposes, ~5 ms at n = 3e4) is remembered for the last
+    operands -- keyed by object identity AND a content signature, so an operand changed in place is converted anew."""
+    key = (id(amat), id(mmat), bool(transposed))
+    if sps.issparse(amat) and sps.issparse(mmat):
+        sig = (_content_sig(amat), _content_sig(mmat))
+        hit = _orient_memo.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1], hit[2]
+    else:
+        sig = None
+    a = sps.csr_matrix(amat)
+    e = sps.csr_matrix(mmat)
+    if not transposed:
+        a, e = a.T.tocsr(), e.T.tocsr()
+    if sig is not None:
+        if a is amat or e is mmat:            # never tag or keep the caller's own objects
+            a, e = a.copy(), e.copy()
+        a._ricadi_fp = backend._fingerprint(a)
+        e._ricadi_fp = backend._fingerprint(e)
+        _orient_memo.clear()
+        _orient_memo[key] = (sig, a, e)
+    return a, e
 
 
 def _shifts(d):
