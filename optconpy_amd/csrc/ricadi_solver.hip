@@ -364,6 +364,7 @@ struct ricadi_ctx {
   // drained at the section ends only in that mode)
   bool timing = false;
   double t_setup = 0, t_solve = 0, t_recomb = 0, t_compress = 0, t_updnorm = 0, t_proj = 0, t_gain = 0;
+  double t_cyc = 0, t_iter = 0, t_guess = 0, t_smw = 0;   // inside t_solve: restart-cycle bookkeeping, Arnoldi iterations, recycling, SMW + checks
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
@@ -1207,7 +1208,15 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   static const int cyc0 = getenv("RICADI_CYC0") ? std::max(2, atoi(getenv("RICADI_CYC0"))) : 10;
   int cyc = std::min(restart, cyc0);
   std::vector<double> rstart(GM, 0.0);
+  Tick tkc;
+  auto lapc = [&](double& acc) {
+    if (c->timing) {
+      (void)hipStreamSynchronize(st);
+      acc += tkc.lap();
+    }
+  };
   while (!act.empty()) {
+    lapc(c->t_iter);
     bt.set(act);
     // residual of the current iterates
     if (first) {
@@ -1271,6 +1280,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       launch_colscale_b(st, bt.tab, n, m, c->scale.p, c->wv.p, nm, 0.0, V, nm);
     live = act;
     for (int g : act) kk[g] = 0;
+    lapc(c->t_cyc);
     if (adots) {
       HIPCHK(hipMemsetAsync(c->h1.p, 0, sizeof(double) * gsh * G, st));
       HIPCHK(hipMemsetAsync(c->h2.p, 0, sizeof(double) * gsh * G, st));
@@ -1350,6 +1360,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       }
       live.swap(still);
     }
+    lapc(c->t_iter);
     // corrections: x_g += P^-1 (V_g y_g) with the k_g basis vectors group g built
     // (one launch each for all groups of the cycle, k_g per group by value)
     bt.set(act);
@@ -1372,7 +1383,9 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       precond_apply(c, bt, c->wv.p, nm, c->zv.p);
       launch_axpby_b(st, bt.tab, nm, 1.0, c->zv.p, nm, 1.0, x, nm);
     }
+    lapc(c->t_cyc);
   }
+  lapc(c->t_cyc);
 }
 
 // ---- recycled right-hand sides (ricadi_set_recycle) ---------------------------------------------
@@ -1524,7 +1537,12 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
   hipStream_t st = c->st;
   const bool plain = !(lowrank && c->q > 0);
   const bool shared = (gsb == 0 || G == 1) && plain && c->rec_depth > 0;
+  Tick tkg;
   const bool guess = shared && recycle_guess(c, sds, G, b, m, x);
+  if (c->timing) {
+    (void)hipStreamSynchronize(st);
+    c->t_guess += tkg.lap();
+  }
   const int lvl0 = storage_level(c);
   gmres_core(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, !no_net && lvl0 < 2);
   std::vector<int> bad;
@@ -3894,7 +3912,7 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
   for (steps = 1; steps <= prm->nwtn_max_steps; ++steps) {
     int m = mw;
     Tick tkn;
-    if (c->timing) c->t_setup = c->t_solve = c->t_recomb = c->t_compress = c->t_updnorm = c->t_proj = c->t_gain = 0;
+    if (c->timing) c->t_setup = c->t_solve = c->t_recomb = c->t_compress = c->t_updnorm = c->t_proj = c->t_gain = c->t_cyc = c->t_iter = c->t_guess = 0;
     if (kk > 0) {
       gain_dev(c, c->E, zk, kk, kk, dB, nb, dK.p);
       if (c->timing) c->t_gain += tkn.lap();
@@ -3948,6 +3966,8 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
     }
     if (c->timing) {
       c->t_updnorm += tkc.lap();
+      fprintf(stderr, "[ricadi timing] inside the solves: Arnoldi iterations %.1f ms, restart-cycle bookkeeping %.1f, recycled guesses %.1f\n",
+              1e3 * c->t_iter, 1e3 * c->t_cyc, 1e3 * c->t_guess);
       fprintf(stderr, "[ricadi timing] Newton step %d: total %.1f ms = setup %.1f + projection %.1f + solves %.1f + "
               "recombination %.1f + recompression %.1f + update norm %.1f + gain %.1f (+ rest); %d raw columns at the end\n",
               steps, 1e3 * tkn.lap(), 1e3 * c->t_setup, 1e3 * c->t_proj, 1e3 * c->t_solve, 1e3 * c->t_recomb,
