@@ -415,6 +415,12 @@ int ricadi_set_exchange(ricadi_ctx* ctx, int rank, int world, ricadi_allgather_f
  * predicted iteration counts it(p) that fall with |p| (the small shifts are the slow solves).
  * Deterministic in (shifts, world): every rank computes the same table.  Returns 0 or <0.   */
 int ricadi_host_deal(const double* shifts, int nshifts, int world, int32_t* owner_out);
+/* Whether the setup smooths the velocity aggregates of the two-level preconditioner for the operator cal A (CSR,
+ * NV x NV):  *on_out = 1 iff the row sums of sym(cal A) stay below 0.15 of its diagonal (stiffness-like, not
+ * mass-like) and sum |skew part| / sum |off-diagonal symmetric part| <= 0.7 (not convection dominated).  The two
+ * ratios are returned (skew ratio -1 when the first test failed).  Host only; no GPU needed.                       */
+int ricadi_host_sa_criterion(int nv, const int32_t* a_rowptr, const int32_t* a_col, const double* a_val,
+                             double* rowsum_ratio_out, double* skew_ratio_out, int* on_out);
 /* Greedy BFS aggregation of the graph of a CSR pattern into blocks of at
  * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */
 int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col,

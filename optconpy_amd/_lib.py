@@ -20,7 +20,7 @@ RICADI_ENOCONV = -3
 MAX_M = 128
 # ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
 # are part of the ABI and are not covered by the struct handshake below
-ABI_VERSION = 302
+ABI_VERSION = 303
 
 
 class RicadiOpts(C.Structure):
@@ -106,6 +106,8 @@ SIGNATURES = {
     "ricadi_set_recycle": (C.c_int, [_vp, C.c_int]),
     "ricadi_set_exchange": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int64]),
     "ricadi_host_deal": (C.c_int, [_dp, C.c_int, C.c_int, _ip]),
+    "ricadi_host_sa_criterion": (C.c_int, [C.c_int, _ip, _ip, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int)]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
 }
@@ -721,3 +723,12 @@ def host_cauchy(shifts):
     c1 = np.empty(g)
     _chk(load().ricadi_host_cauchy(_d(sh), g, _d(rinv), _d(c1)))
     return rinv, c1
+
+
+def host_sa_criterion(calA):
+    """``(on, rowsum_ratio, skew_ratio)``: whether the setup would smooth the velocity aggregates for ``calA``
+    (``ricadi_host_sa_criterion``; host only)."""
+    rp, ci, v, sh = as_csr(calA)
+    rs, sk, on = C.c_double(0.0), C.c_double(0.0), C.c_int(0)
+    _chk(load().ricadi_host_sa_criterion(sh[0], _i(rp), _i(ci), _d(v), C.byref(rs), C.byref(sk), C.byref(on)))
+    return bool(on.value), rs.value, sk.value

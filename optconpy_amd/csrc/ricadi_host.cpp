@@ -139,6 +139,53 @@ static HostCsr galerkin(const HostCsr& M, int nrow_c, const int* rows_ptr, const
   return out;
 }
 
+// Is smoothing the velocity aggregates with a Jacobi step on sym(A) appropriate for this operator?
+//  - only for a stiffness-like A -- constants nearly in the kernel of its symmetric part: row sums small against
+//    the diagonal (NSE operator 0.01-0.06, DRE operator at n = 3e4 0.03; a mass matrix 1.6).  Smoothing the
+//    aggregates with a mass-like matrix makes the cycle WORSE (numpy mirror, [[M, J^T],[J, 0]]: 54 -> 122
+//    iterations at omega = 0.5, no convergence at 0.67);
+//  - and only while the symmetric part dominates: the smoother says nothing about a convection-dominated operator.
+//    gamma = sum |skew part| / sum |off-diagonal symmetric part| (~ 1.2 x the cell Peclet number): measured
+//    slowest-shift iterations with / without smoothing at gamma = 0.10: 73 / 100, 0.23: 59 / 67, 0.52: 82 / 106 and
+//    93 / 106, but 1.07: 120 / 107, 2.0: 262 / 217 and 291 / 226.
+// rs / gamma return the two ratios (gamma = -1 when the first test already failed).
+bool sa_criterion(const HostCsr& A, double& rs_out, double& gamma_out) {
+  const int nv = A.nrows;
+  double srs = 0.0, sdg = 0.0;
+  std::vector<double> colsum(nv, 0.0);
+  for (int i = 0; i < nv; ++i)
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) colsum[A.ci[k]] += A.v[k];
+  for (int i = 0; i < nv; ++i) {
+    double rsum = 0.0, dg = 0.0;
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
+      rsum += A.v[k];
+      if (A.ci[k] == i) dg += A.v[k];
+    }
+    srs += std::fabs(0.5 * (rsum + colsum[i]));
+    sdg += std::fabs(dg);
+  }
+  rs_out = sdg > 0.0 ? srs / sdg : -1.0;
+  gamma_out = -1.0;
+  if (!(sdg > 0.0) || srs > 0.15 * sdg) return false;
+  const HostCsr At0 = transpose(A);
+  std::vector<double> w1(nv, 0.0), w2(nv, 0.0);
+  double sk = 0.0, sy = 0.0;
+  for (int i = 0; i < nv; ++i) {
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) w1[A.ci[k]] += 0.5 * A.v[k];
+    for (int k = At0.rp[i]; k < At0.rp[i + 1]; ++k) w2[At0.ci[k]] += 0.5 * At0.v[k];
+    auto visit = [&](int j) {
+      if (w1[j] == 0.0 && w2[j] == 0.0) return;
+      sk += std::fabs(w1[j] - w2[j]);
+      if (j != i) sy += std::fabs(w1[j] + w2[j]);
+      w1[j] = w2[j] = 0.0;
+    };
+    for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) visit(A.ci[k]);
+    for (int k = At0.rp[i]; k < At0.rp[i + 1]; ++k) visit(At0.ci[k]);
+  }
+  gamma_out = sy > 0.0 ? sk / sy : 1e30;
+  return gamma_out <= 0.7;
+}
+
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
                  HostSetup& hs, int max_levels, double sa_omega) {
   const int nv = A.nrows, np = J.nrows, n = nv + np;
@@ -420,51 +467,11 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   // ---- prolongation P (rows): plain aggregation, or smoothed on the velocity rows ----------------
   hs.sa = sa_omega > 0.0 && !hs.multilevel && np > 0 && kv > 0;
   if (hs.sa) {
-    // Only for a stiffness-like cal A -- constants nearly in the kernel of its symmetric part: row sums small against
-    // the diagonal (NSE operator 0.01-0.06, DRE operator at n = 3e4 0.03; a mass matrix 1.6).  Smoothing the
-    // aggregates with a mass-like matrix makes the cycle WORSE (numpy mirror, [[M, J^T],[J, 0]]: 54 -> 122
-    // iterations at omega = 0.5, no convergence at 0.67).
-    double srs = 0.0, sdg = 0.0;
-    std::vector<double> colsum(nv, 0.0);
-    for (int i = 0; i < nv; ++i)
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) colsum[A.ci[k]] += A.v[k];
-    for (int i = 0; i < nv; ++i) {
-      double rsum = 0.0, dg = 0.0;
-      for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) {
-        rsum += A.v[k];
-        if (A.ci[k] == i) dg += A.v[k];
-      }
-      srs += std::fabs(0.5 * (rsum + colsum[i]));
-      sdg += std::fabs(dg);
-    }
-    if (!(sdg > 0.0) || srs > 0.15 * sdg) hs.sa = false;
-    // ... and only while the symmetric part dominates: the smoother is a Jacobi step on sym(cal A), which says
-    // nothing about a convection-dominated operator.  gamma = sum |skew part| / sum |off-diagonal symmetric part|
-    // (~ 1.2 x the cell Peclet number): measured slowest-shift iterations with / without smoothing at gamma =
-    // 0.10: 73 / 100, 0.23: 59 / 67, 0.52: 82 / 106 and 93 / 106, but 1.07: 120 / 107, 2.0: 262 / 217 and 291 / 226.
-    double gamma = -1.0;
-    if (hs.sa) {
-      const HostCsr At0 = transpose(A);
-      std::vector<double> w1(nv, 0.0), w2(nv, 0.0);
-      double sk = 0.0, sy = 0.0;
-      for (int i = 0; i < nv; ++i) {
-        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) w1[A.ci[k]] += 0.5 * A.v[k];
-        for (int k = At0.rp[i]; k < At0.rp[i + 1]; ++k) w2[At0.ci[k]] += 0.5 * At0.v[k];
-        auto visit = [&](int j) {
-          if (w1[j] == 0.0 && w2[j] == 0.0) return;
-          sk += std::fabs(w1[j] - w2[j]);
-          if (j != i) sy += std::fabs(w1[j] + w2[j]);
-          w1[j] = w2[j] = 0.0;
-        };
-        for (int k = A.rp[i]; k < A.rp[i + 1]; ++k) visit(A.ci[k]);
-        for (int k = At0.rp[i]; k < At0.rp[i + 1]; ++k) visit(At0.ci[k]);
-      }
-      gamma = sy > 0.0 ? sk / sy : 1e30;
-      if (gamma > 0.7) hs.sa = false;
-    }
+    double rs = -1.0, gamma = -1.0;
+    hs.sa = sa_criterion(A, rs, gamma);
     if (o.verbose)
       fprintf(stderr, "[ricadi] smoothed aggregation %s: row sums / diagonal of sym(cal A) = %.3f, skew / symmetric "
-              "off-diagonal mass %.3f\n", hs.sa ? "on" : "off", sdg > 0.0 ? srs / sdg : -1.0, gamma);
+              "off-diagonal mass %.3f\n", hs.sa ? "on" : "off", rs, gamma);
   }
   hs.p_rp.clear(); hs.p_ci.clear(); hs.p_v.clear();
   hs.pt_rp.clear(); hs.pt_ci.clear(); hs.pt_v.clear();
@@ -843,6 +850,25 @@ int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col, int 
     return RICADI_EINVAL;
   }
   return ricadi::aggregate(n, rowptr, col, bsize, blk_out);
+}
+
+int ricadi_host_sa_criterion(int nv, const int32_t* a_rp, const int32_t* a_ci, const double* a_v, double* rowsum_ratio_out,
+                             double* skew_ratio_out, int* on_out) {
+  if (nv < 1 || !a_rp || !a_ci || !a_v || !on_out) {
+    ricadi::set_error("ricadi_host_sa_criterion: bad argument");
+    return RICADI_EINVAL;
+  }
+  try {
+    const ricadi::HostCsr A = ricadi::make_csr(nv, nv, a_rp, a_ci, a_v);
+    double rs = -1.0, g = -1.0;
+    *on_out = ricadi::sa_criterion(A, rs, g) ? 1 : 0;
+    if (rowsum_ratio_out) *rowsum_ratio_out = rs;
+    if (skew_ratio_out) *skew_ratio_out = g;
+  } catch (...) {
+    ricadi::set_error("ricadi_host_sa_criterion: exception");
+    return RICADI_EINVAL;
+  }
+  return RICADI_OK;
 }
 
 int ricadi_host_deal(const double* shifts, int ns, int world, int32_t* owner_out) {

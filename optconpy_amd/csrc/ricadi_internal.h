@@ -85,6 +85,7 @@ struct HostSetup {
 };
 void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ricadi_opts& o,
                  HostSetup& hs, int max_levels = 2, double sa_omega = 0.0);
+bool sa_criterion(const HostCsr& A, double& rs_out, double& gamma_out);
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1);
 int deal_shifts(const double* shifts, int ns, int world, int32_t* owner);
 int gram_lstsq(int h, int m, const double* Ghh, const double* Ghb, double rtol, double* Y);

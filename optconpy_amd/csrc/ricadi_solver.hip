@@ -2754,7 +2754,7 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 302; }
+int ricadi_version(void) { return 303; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h

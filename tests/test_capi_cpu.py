@@ -189,3 +189,27 @@ def test_host_deal_shift_owners():
     assert groups(a, ms) == groups(b, ms[perm])
     with pytest.raises(ValueError):
         _lib.host_deal([1.0, -1.0], 2)           # positive shift
+
+
+def test_host_sa_criterion_on_the_operator_kinds():
+    """ricadi_host_sa_criterion (host logic of the round-3 smoothed aggregation): on for the diffusion-dominated NSE
+    operator and the DRE operator of solve_dae_ric.py:147, off for a mass matrix (lau.app_prj_via_sadpnt hands one over
+    as the operator, optcont_main.py:405-408) and for a convection-dominated operator."""
+    from optconpy_amd import _lib, problems as pb
+    pr = pb.ricc_problem(12, 0.1)
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    on, rs, sk = _lib.host_sa_criterion(calA)
+    assert on and 0.0 <= rs < 0.15 and 0.0 <= sk < 0.7, (on, rs, sk)
+    dre = (-(0.5 * pr.M.T + 0.1 * (pr.A + pr.Nc).T)).tocsr()
+    assert _lib.host_sa_criterion(dre)[0]
+    on_m, rs_m, sk_m = _lib.host_sa_criterion(pr.M.T.tocsr())
+    assert not on_m and rs_m > 1.0 and sk_m == -1.0
+    pc = pb.ricc_problem(16, 0.01)                       # cell Peclet number ~ 1.6: the second test decides
+    on_c, rs_c, sk_c = _lib.host_sa_criterion((-pc.A - pc.Nc).T.tocsr())
+    assert not on_c and rs_c < 0.15 and sk_c > 0.7, (on_c, rs_c, sk_c)
+    # the skew ratio is that of the matrix: recomputed with scipy
+    K = (0.5 * (calA + calA.T)).tocsr()
+    S = (0.5 * (calA - calA.T)).tocsr()
+    import scipy.sparse as sps
+    off = K - sps.diags(K.diagonal())
+    assert abs(sk - np.abs(S.data).sum() / np.abs(off.data).sum()) < 1e-12
