@@ -3063,7 +3063,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                                                       const double* __restrict__ A, int lda,
                                                       const double* __restrict__ B, int ldb,
                                                       size_t gsB, double* __restrict__ C, int ldc,
-                                                      size_t gsC, int rows_per_wave, int symmetric) {
+                                                      size_t gsC, int rows_per_wave, int symmetric, int combine) {
   // batched form: blockIdx.y = (active group) * ptiles + (tile row); A is shared
   const int by = blockIdx.y % ptiles;
   {
@@ -3117,8 +3117,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
     for (int b = 0; b < TJ; ++b) bf[b] = bfn[b];
   }
   if (TI * TJ > 4) {
-    // wide products: the atomics are spread over many outputs; every wave adds
-    // its own tiles (an LDS combine buffer would need 131 KB)
+    // wide products: the atomics are spread over many outputs; every wave adds its own tiles -- unless the
+    // product has FEW tiles and is therefore cut into many short row slices (combine != 0): then the four waves
+    // of the workgroup (four consecutive slices of the same tiles) are summed first, one after the other through
+    // one 32-KB LDS buffer, and wave 0 alone issues the atomics (4x fewer)
+    if (combine) {
+      __shared__ double comb[(TI * TJ > 4) ? TI * TJ * 4 * 64 : 1];
+      for (int wsrc = 1; wsrc < 4; ++wsrc) {
+        if (wave_in_blk == wsrc) {
+#pragma unroll
+          for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) comb[((a * TJ + b) * 4 + e) * 64 + lane] = acc[a][b][e];
+        }
+        __syncthreads();
+        if (wave_in_blk == 0) {
+#pragma unroll
+          for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int b = 0; b < TJ; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[a][b][e] += comb[((a * TJ + b) * 4 + e) * 64 + lane];
+        }
+        __syncthreads();
+      }
+      if (wave_in_blk != 0) return;
+    }
 #pragma unroll
     for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -3127,7 +3153,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
         for (int e = 0; e < 4; ++e) {
           const int row = i0 + 16 * a + lk + 4 * e;
           const int col = j0 + 16 * b + lc;
-          if (rbeg < n && row < p && col < q) {
+          if ((rbeg < n || combine) && row < p && col < q) {
             atomicAdd(&C[(size_t)row * ldc + col], acc[a][b][e]);
             if (symmetric && blockIdx.z > by)
               atomicAdd(&C[(size_t)col * ldc + row], acc[a][b][e]);
@@ -3181,8 +3207,11 @@ void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, c
   // Row slices: every slice adds its partial tiles with atomics, so wide products
   // (many output elements) take few, long slices -- about 1.5 waves per SIMD in
   // total -- while thin ones take many short slices to fill the chip.
-  const int min_rows = wide ? 256 : 64;
-  const int target_waves = wide ? 1536 : 8192;
+  // wide products with few tiles (a 128-column QR panel against itself or against the earlier columns): short
+  // slices fill the chip, the workgroup's four partial tile sets are combined in LDS before the atomics
+  const int combine = (wide && tiles * gt.ng <= 16) ? 1 : 0;
+  const int min_rows = wide ? (combine ? 64 : 256) : 64;
+  const int target_waves = wide ? (combine ? 3072 : 1536) : 8192;
   int slices = std::max(1, std::min((n + min_rows - 1) / min_rows,
                                     std::max(1, target_waves / std::max(1, tiles * gt.ng))));
   int rows_per_wave = (n + slices - 1) / slices;
@@ -3191,10 +3220,10 @@ void launch_gemm_tn_b(hipStream_t st, const GroupTab& gt, int n, int p, int q, c
   dim3 grid((slices + 3) / 4, tp_ * gt.ng, tq_), block(256);
   if (wide)
     hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, block, 0, st, gt, tp_, n, p, q, A, lda, B, ldb,
-                       gsB, C, ldc, gsC, rows_per_wave, symmetric);
+                       gsB, C, ldc, gsC, rows_per_wave, symmetric, combine);
   else
     hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, block, 0, st, gt, tp_, n, p, q, A, lda, B, ldb,
-                       gsB, C, ldc, gsC, rows_per_wave, symmetric);
+                       gsB, C, ldc, gsC, rows_per_wave, symmetric, 0);
 }
 
 // gemm_nn:  Y (n x q) = alpha * A (n x p) * C (p x q) + beta * Y.
