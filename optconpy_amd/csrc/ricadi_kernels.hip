@@ -3602,18 +3602,18 @@ __global__ __launch_bounds__(256) void cholqr_wide_kernel(int w, const double* _
   }
   __syncthreads();
   {
-    // thread = (row strip tid >> 5, column tid & 31 (+32 q)): raw loads first (8 rows in flight), then the scaling
+    // thread = (row strip tid >> 5, column tid & 31 (+32 q)): raw loads first (16 rows in flight), then the scaling
     const int jj = tid & 31, is = tid >> 5;
     for (int j = jj; j < wp; j += 32)
-      for (int ib = is; ib < wp; ib += 64) {
-        double g[8];
+      for (int ib = is; ib < wp; ib += 128) {
+        double g[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 16; ++q) {
           const int i = ib + 8 * q;
           g[q] = (i < w && j < w) ? G[(size_t)i * ldg + j] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 16; ++q) {
           const int i = ib + 8 * q;
           if (i < wp) {
             double v;
@@ -3632,11 +3632,13 @@ __global__ __launch_bounds__(256) void cholqr_wide_kernel(int w, const double* _
     const int k0 = kb * 16;
     CQA(0);
     if (tid < 64) {
-      // wave 0: lane i (< 16) owns row i of the diagonal block
+      // wave 0: lane i (< 16) owns row i of the diagonal block; only the factor here -- the block's inverse is
+      // formed after the factorisation, all blocks at once (cholqr_diag_inverse)
       const int i = lane & 15;
-      double r[16], x[16], rinv[16];
+      double r[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) r[j] = A[(k0 + i) * CQLD + k0 + j];
+      double myinv = 0.0;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         double piv = __shfl(r[t], t, 64);
@@ -3649,47 +3651,31 @@ __global__ __launch_bounds__(256) void cholqr_wide_kernel(int w, const double* _
         double rs = __builtin_amdgcn_rsq(piv);
         rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
         rs = rs * fma(-0.5 * piv * rs, rs, 1.5);
-        rinv[t] = rs;
+        if (i == t) myinv = rs;
         r[t] = (i == t) ? piv * rs : r[t] * rs;        // rows i < t hold upper entries nobody reads
 #pragma unroll
         for (int j = t + 1; j < 16; ++j) r[j] = fma(-r[t], __shfl(r[t], j, 64), r[j]);
-      }
-      // inverse, lane j owns COLUMN j of X = L^-1:  x_jj = 1 / l_jj,  x_ij = -(sum_{k<i} l_ik x_kj) / l_ii
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < ii; ++k) {
-          if (k & 1) s1 = fma(__shfl(r[k], ii, 64), x[k], s1);
-          else s0 = fma(__shfl(r[k], ii, 64), x[k], s0);
-        }
-        x[ii] = (ii < i) ? 0.0 : (ii == i ? rinv[ii] : -(s0 + s1) * rinv[ii]);
       }
       if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
           if (j <= i) A[(k0 + i) * CQLD + k0 + j] = r[j];               // L11 (lower incl. diagonal)
-        xd[k0 + i] = x[i];
-#pragma unroll
-        for (int ii = 0; ii < 16; ++ii)
-          if (ii > i) A[(k0 + i) * CQLD + k0 + ii] = x[ii];             // X[ii][i] at the transposed (upper) position
+        xd[k0 + i] = myinv;
       }
     }
     __syncthreads();
     CQA(1);
-    // panel: L[i][k0 + j] = sum_{k <= j} A[i][k0 + k] X[j][k],  rows below the block
+    // panel: L21 = A21 L11^-T by forward substitution, one thread per row below the block
     {
       const int i = k0 + 16 + tid;
       if (i < wp) {
-        double a[16], l[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = A[i * CQLD + k0 + k];
+        double l[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          double sacc = a[j] * xd[k0 + j];
+          double sacc = A[i * CQLD + k0 + j];
 #pragma unroll
-          for (int k = 0; k < j; ++k) sacc = fma(a[k], A[(k0 + k) * CQLD + k0 + j], sacc);   // X[j][k], k < j
-          l[j] = sacc;
+          for (int k = 0; k < j; ++k) sacc = fma(-l[k], A[(k0 + j) * CQLD + k0 + k], sacc);   // L11[j][k]
+          l[j] = sacc * xd[k0 + j];
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) A[i * CQLD + k0 + j] = l[j];
@@ -3739,41 +3725,97 @@ __global__ __launch_bounds__(256) void cholqr_wide_kernel(int w, const double* _
   }
   __syncthreads();
   CQT(3);
-  // the inverses of the diagonal blocks move to their own (lower) positions: L's diagonal blocks are not needed
-  // any more, and X = L^-1 is then stored uniformly
-  for (int e = tid; e < nbk * 256; e += 256) {
-    const int kb = e >> 8, i = (e >> 4) & 15, j = e & 15, k0 = kb * 16;
-    double v = 0.0;
-    if (j < i) v = A[(k0 + j) * CQLD + k0 + i];
-    else if (j == i) v = xd[k0 + i];
-    tmp[e & 255] = v;                       // one diagonal block per pass: 256 threads, 256 entries
-    __syncthreads();
-    if (j <= i) A[(k0 + i) * CQLD + k0 + j] = tmp[e & 255];
-    __syncthreads();
-  }
-  CQT(4);
-  // X = L^-1 in place of the block-lower part, block row by block row:  X[I,J] = -X[I,I] sum_K L[I,K] X[K,J]
-  for (int I = 1; I < nbk; ++I) {
-    const int i0 = I * 16, ncol = i0;                 // columns 0 .. i0-1
-    for (int e = tid; e < 16 * ncol; e += 256) {
-      const int r = e / ncol, cc = e - r * ncol;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-      int k = cc;
-      for (; k + 3 < i0; k += 4) {
-        s0 = fma(A[(i0 + r) * CQLD + k], A[k * CQLD + cc], s0);
-        s1 = fma(A[(i0 + r) * CQLD + k + 1], A[(k + 1) * CQLD + cc], s1);
-        s2 = fma(A[(i0 + r) * CQLD + k + 2], A[(k + 2) * CQLD + cc], s2);
-        s3 = fma(A[(i0 + r) * CQLD + k + 3], A[(k + 3) * CQLD + cc], s3);
-      }
-      for (; k < i0; ++k) s0 = fma(A[(i0 + r) * CQLD + k], A[k * CQLD + cc], s0);
-      tmp[r * 112 + cc] = (s0 + s1) + (s2 + s3);
+  // inverses of the 16 x 16 diagonal blocks, in place, two blocks per wave: lane i (< 16) holds row i of L11 and
+  // forms COLUMN i of X11 = L11^-1:  x_ii = 1 / l_ii,  x_ri = -(sum_{k<r} l_rk x_ki) / l_rr  (operands of the other
+  // rows by shuffles); every lane has read its row before any lane writes
+  for (int kb = tid >> 6; kb < nbk; kb += 4) {
+    const int k0 = kb * 16, i = lane & 15;
+    double r[16], x[16], rinv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      r[j] = A[(k0 + i) * CQLD + k0 + j];
+      rinv[j] = xd[k0 + j];
     }
+#pragma unroll
+    for (int ii = 0; ii < 16; ++ii) {
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < ii; ++k) {
+        if (k & 1) s1 = fma(__shfl(r[k], ii, 64), x[k], s1);
+        else s0 = fma(__shfl(r[k], ii, 64), x[k], s0);
+      }
+      x[ii] = (ii < i) ? 0.0 : (ii == i ? rinv[ii] : -(s0 + s1) * rinv[ii]);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii)
+        if (ii >= i) A[(k0 + ii) * CQLD + k0 + i] = x[ii];               // X11[ii][i], lower incl. diagonal
+    }
+  }
+  __syncthreads();
+  CQT(4);
+  // X = L^-1 in place of the block-lower part, right-looking over the block columns J:  once X[J, 0 .. j0+16) is
+  // final, every block row I > J takes  W[I, :] -= L[I, J] X[J, :]  (W: the running right-hand side of L X = I,
+  // kept where L's consumed blocks were; L[., J] is saved in `tmp` first), in 7 x 8 register tiles
+  for (int J = 0; J < nbk; ++J) {
+    const int j0 = J * 16;
+    if (J > 0) {
+      // X[J, c] = X[J,J] W[J, c], c < j0
+      // thread (r, cg) forms X[J][r][cg + 16 b], b < J: one entry of X[J,J] and J entries of W per step
+      const int r = tid >> 4, cg = tid & 15;
+      double xv[7];
+#pragma unroll
+      for (int b = 0; b < 7; ++b) xv[b] = 0.0;
+#pragma unroll 4
+      for (int t = 0; t < 16; ++t) {
+        const double xdv = t <= r ? A[(j0 + r) * CQLD + j0 + t] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 7; ++b)
+          if (b < J) xv[b] = fma(xdv, A[(j0 + t) * CQLD + cg + 16 * b], xv[b]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 7; ++b)
+        if (b < J) A[(j0 + r) * CQLD + cg + 16 * b] = xv[b];
+    }
+    const int r0 = j0 + 16, nt = (wp - r0) >> 4;      // block rows below
+    if (nt <= 0) break;                               // uniform
+    for (int e = tid; e < nt * 256; e += 256) tmp[e] = A[(r0 + (e >> 4)) * CQLD + j0 + (e & 15)];
     __syncthreads();
-    for (int e = tid; e < 16 * ncol; e += 256) {
-      const int r = e / ncol, cc = e - r * ncol;
-      double sacc = 0.0;
-      for (int q = 0; q <= r; ++q) sacc = fma(A[(i0 + r) * CQLD + i0 + q], tmp[q * 112 + cc], sacc);   // X[I,I][r][q]
-      A[(i0 + r) * CQLD + cc] = -sacc;
+    {
+      const int ti = tid >> 4, tj = tid & 15;
+      double acc[7][8];
+#pragma unroll
+      for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = 0.0;
+#pragma unroll 2
+      for (int t = 0; t < 16; ++t) {
+        // all 15 operands are loaded unconditionally (every address is inside the buffers; a guarded LDS load
+        // becomes a masked block with its own wait) and masked afterwards
+        double li[7], xj[8];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) li[a] = tmp[(ti + 16 * a) * 16 + t];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) xj[b] = A[(j0 + t) * CQLD + tj + 16 * b];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          // X[J][t][c], c = tj + 16 b: columns of block J itself only up to the diagonal (c - j0 <= t); columns
+          // behind block J are not written below
+          if (b == J && tj > t) xj[b] = 0.0;
+#pragma unroll
+        for (int a = 0; a < 7; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b) acc[a][b] = fma(li[a], xj[b], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (a < nt && b <= J) {
+            double* dst = &A[(r0 + ti + 16 * a) * CQLD + tj + 16 * b];
+            *dst = (b == J ? 0.0 : *dst) - acc[a][b];      // block J of these rows held L[., J] (now in tmp)
+          }
     }
     __syncthreads();
   }
