@@ -4148,16 +4148,25 @@ __global__ __launch_bounds__(256) void sweep_combine_kernel(int nrows, int m, in
 }
 __global__ __launch_bounds__(256) void sweep_norms_kernel(int nwg, int gm, const double* __restrict__ partial,
                                                           double* __restrict__ out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= gm) return;
+  // 32 outputs per workgroup, the partial rows dealt to 8 row slices (a single thread per output walked all
+  // ~400 rows one dependent load after the other: 55 us)
+  __shared__ double red[8][32];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + col;
   double s0 = 0.0, s1 = 0.0;
-  int w = 0;
-  for (; w + 1 < nwg; w += 2) {
-    s0 += partial[(size_t)w * gm + e];
-    s1 += partial[(size_t)(w + 1) * gm + e];
+  if (e < gm) {
+    int w = sl;
+    for (; w + 8 < nwg; w += 16) {
+      s0 += partial[(size_t)w * gm + e];
+      s1 += partial[(size_t)(w + 8) * gm + e];
+    }
+    if (w < nwg) s0 += partial[(size_t)w * gm + e];
   }
-  if (w < nwg) s0 += partial[(size_t)w * gm + e];
-  out[e] = s0 + s1;
+  red[sl][col] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && e < gm)
+    out[e] = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) +
+             ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
 }
 bool sweep_combine_ok(int m, int nslot, int G) { return nslot <= SWC_MAXS && G <= SWC_MAXS && m <= RICADI_MAX_M; }
 size_t sweep_combine_partial_len(int nrows, int m, int G) {
@@ -4168,7 +4177,7 @@ void launch_sweep_combine(hipStream_t st, int nrows, int m, int nslot, int G, co
   const int nwg = (nrows + SWC_ROWS - 1) / SWC_ROWS;
   hipLaunchKernelGGL(sweep_combine_kernel, dim3(nwg), dim3(256), 0, st, nrows, m, nslot, G, U, ustride, coef, Z,
                      zld, zc0, partial);
-  hipLaunchKernelGGL(sweep_norms_kernel, dim3((G * m + 255) / 256), dim3(256), 0, st, nwg, G * m, partial, norms2);
+  hipLaunchKernelGGL(sweep_norms_kernel, dim3((G * m + 31) / 32), dim3(256), 0, st, nwg, G * m, partial, norms2);
 }
 
 // coarse matrix combine: out = beta*E0 + alpha*EM + EJ  (dense k x k)
