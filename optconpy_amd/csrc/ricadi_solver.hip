@@ -342,6 +342,10 @@ struct ricadi_ctx {
     DArr<double> b;
   };
   std::vector<std::unique_ptr<RecB>> rec_ring;
+  // the same panels side by side (nv x 8 w_pan, slot i of the ring in columns [i w_pan, (i+1) w_pan)): the normal
+  // equations of a recycled guess are then two GEMM launches instead of one per pair of stored panels
+  DArr<double> rec_pan;
+  int rec_pan_w = 0;
   long rec_serial = 0;
   int rec_depth = 0;          // depth in force for the next solves (the ADI drivers set it for their sweeps)
   int rec_user_depth = 0;     // ricadi_set_recycle: depth for direct solve calls
@@ -1411,26 +1415,55 @@ static bool recycle_guess(ricadi_ctx* c, ShiftData* const* sds, int G, const dou
   for (auto* e : ent) h += e->w;
   hipStream_t st = c->st;
   const int nv = c->nv, n = c->n, hw = h + m;
-  TArr<double> Gd(c->pool, (size_t)h * hw), Yd(c->pool, (size_t)h * m);
-  HIPCHK(hipMemsetAsync(Gd.p, 0, sizeof(double) * h * hw, st));
-  int r0 = 0;
-  for (size_t i = 0; i < ent.size(); ++i) {
-    int c0 = r0;
-    for (size_t j = i; j < ent.size(); ++j) {
-      launch_gemm_tn(st, nv, ent[i]->w, ent[j]->w, ent[i]->b.p, ent[i]->w, ent[j]->b.p, ent[j]->w,
-                     Gd.p + (size_t)r0 * hw + c0, hw);
-      c0 += ent[j]->w;
-    }
-    launch_gemm_tn(st, nv, ent[i]->w, m, ent[i]->b.p, ent[i]->w, b, m, Gd.p + (size_t)r0 * hw + h, hw);
-    r0 += ent[i]->w;
-  }
-  std::vector<double> Gh((size_t)h * hw);
-  HIPCHK(hipMemcpyAsync(Gh.data(), Gd.p, sizeof(double) * Gh.size(), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  TArr<double> Gd(c->pool), Yd(c->pool, (size_t)h * m);
   std::vector<double> Ghh((size_t)h * h), Ghb((size_t)h * m), Y;
-  for (int i = 0; i < h; ++i) {
-    for (int j = 0; j < h; ++j) Ghh[(size_t)i * h + j] = j >= i ? Gh[(size_t)i * hw + j] : Gh[(size_t)j * hw + i];
-    for (int j = 0; j < m; ++j) Ghb[(size_t)i * m + j] = Gh[(size_t)i * hw + h + j];
+  int r0 = 0;
+  // slot of every entry in the side-by-side panel (all of the panel's width, ring of at most 8 slots)
+  std::vector<int> slot_of(ent.size(), -1);
+  bool pan = c->rec_pan_w == m && c->rec_pan.p && c->rec_ring.size() <= 8;
+  for (size_t i = 0; i < ent.size() && pan; ++i) {
+    for (size_t si = 0; si < c->rec_ring.size(); ++si)
+      if (c->rec_ring[si].get() == ent[i]) slot_of[i] = (int)si;
+    pan = slot_of[i] >= 0 && ent[i]->w == m;
+  }
+  if (pan) {
+    // Gram matrix of ALL slots and their products with b in two launches; the live entries are picked on the host
+    const int H = 8 * m, Hw = H + m;
+    Gd.alloc((size_t)H * Hw);
+    HIPCHK(hipMemsetAsync(Gd.p, 0, sizeof(double) * H * Hw, st));
+    launch_gemm_tn(st, nv, H, H, c->rec_pan.p, H, c->rec_pan.p, H, Gd.p, Hw);
+    launch_gemm_tn(st, nv, H, m, c->rec_pan.p, H, b, m, Gd.p + H, Hw);
+    std::vector<double> Gh((size_t)H * Hw);
+    HIPCHK(hipMemcpyAsync(Gh.data(), Gd.p, sizeof(double) * Gh.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t ei = 0; ei < ent.size(); ++ei)
+      for (int a = 0; a < m; ++a) {
+        const int i = (int)ei * m + a, gi = slot_of[ei] * m + a;
+        for (size_t ej = 0; ej < ent.size(); ++ej)
+          for (int bcol = 0; bcol < m; ++bcol)
+            Ghh[(size_t)i * h + ej * m + bcol] = Gh[(size_t)gi * Hw + slot_of[ej] * m + bcol];
+        for (int j = 0; j < m; ++j) Ghb[(size_t)i * m + j] = Gh[(size_t)gi * Hw + H + j];
+      }
+  } else {
+    Gd.alloc((size_t)h * hw);
+    HIPCHK(hipMemsetAsync(Gd.p, 0, sizeof(double) * h * hw, st));
+    for (size_t i = 0; i < ent.size(); ++i) {
+      int c0 = r0;
+      for (size_t j = i; j < ent.size(); ++j) {
+        launch_gemm_tn(st, nv, ent[i]->w, ent[j]->w, ent[i]->b.p, ent[i]->w, ent[j]->b.p, ent[j]->w,
+                       Gd.p + (size_t)r0 * hw + c0, hw);
+        c0 += ent[j]->w;
+      }
+      launch_gemm_tn(st, nv, ent[i]->w, m, ent[i]->b.p, ent[i]->w, b, m, Gd.p + (size_t)r0 * hw + h, hw);
+      r0 += ent[i]->w;
+    }
+    std::vector<double> Gh((size_t)h * hw);
+    HIPCHK(hipMemcpyAsync(Gh.data(), Gd.p, sizeof(double) * Gh.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < h; ++i) {
+      for (int j = 0; j < h; ++j) Ghh[(size_t)i * h + j] = j >= i ? Gh[(size_t)i * hw + j] : Gh[(size_t)j * hw + i];
+      for (int j = 0; j < m; ++j) Ghb[(size_t)i * m + j] = Gh[(size_t)i * hw + h + j];
+    }
   }
   // the diagonal blocks come from a symmetric kernel, the off-diagonal ones were computed above the
   // diagonal only: the mirror image is exact
@@ -1470,6 +1503,21 @@ static void recycle_store(ricadi_ctx* c, ShiftData* const* sds, int G, const dou
   slot->w = m;
   slot->b.ensure((size_t)c->nv * m);
   HIPCHK(hipMemcpyAsync(slot->b.p, b, sizeof(double) * c->nv * m, hipMemcpyDeviceToDevice, st));
+  {
+    // side-by-side copy (slots of another width invalidate the panel: recycle_guess then takes the pairwise path)
+    int si = 0;
+    for (; si < (int)c->rec_ring.size(); ++si)
+      if (c->rec_ring[si].get() == slot) break;
+    if (c->rec_pan_w != m || c->rec_pan.n < (size_t)c->nv * 8 * m) {
+      c->rec_pan.ensure((size_t)c->nv * 8 * m);
+      HIPCHK(hipMemsetAsync(c->rec_pan.p, 0, sizeof(double) * (size_t)c->nv * 8 * m, st));
+      c->rec_pan_w = m;
+      for (auto& e : c->rec_ring)
+        if (e.get() != slot && e->serial >= 0 && e->w == m)
+          launch_copy_cols(st, c->nv, m, e->b.p, m, 0, c->rec_pan.p, 8 * m, (int)(&e - &c->rec_ring[0]) * m, 1.0);
+    }
+    if (si < 8) launch_copy_cols(st, c->nv, m, b, m, 0, c->rec_pan.p, 8 * m, si * m, 1.0);
+  }
   auto live = [&](long serial) {
     for (auto& e : c->rec_ring)
       if (e->serial == serial) return true;
