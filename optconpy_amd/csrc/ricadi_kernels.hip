@@ -1865,10 +1865,44 @@ void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int r
                      scale, resid, bnorm, tol, host_resid, zero_h1, zero_h2, hsum);
 }
 
-// y[i*m + c] solves R y = g for the k x k triangle of column c.
-__global__ void gmres_backsolve_kernel(GroupTab gt, int m, GroupInts ks, int restart,
-                                       const double* __restrict__ H, const double* __restrict__ g,
-                                       double* __restrict__ y) {
+// y[i*m + c] solves R y = g for the k x k triangle of column c.  One wave per (column, group): lane l first
+// fetches column-entries R[i][l] = Hc[l][i] of all rows i <= l (independent loads, all in flight), then the k steps of
+// the back substitution run out of LDS with a wave reduction each (one thread per column walking the triangle with
+// dependent global loads took 31 us per call).
+__global__ __launch_bounds__(64) void gmres_backsolve_kernel(GroupTab gt, int m, GroupInts ks, int restart,
+                                                             const double* __restrict__ H,
+                                                             const double* __restrict__ g,
+                                                             double* __restrict__ y) {
+  extern __shared__ double sm[];          // k rows of 64: sm[i * 64 + l] = R[i][l];  then ys[64]
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const int k = ks.v[gt.gid[blockIdx.z]];
+  if (k <= 0) return;
+  {
+    const size_t grp = (size_t)gt.gid[blockIdx.z];
+    H += grp * m * (restart + 1) * restart;
+    g += grp * m * (restart + 1);
+    y += grp * restart * m;
+  }
+  const double* Hc = H + (size_t)c * (restart + 1) * restart;
+  const double* gc = g + (size_t)c * (restart + 1);
+  double* ys = sm + (size_t)k * 64;
+  for (int i = 0; i < k; ++i)
+    sm[i * 64 + lane] = (lane < k && lane >= i) ? Hc[(size_t)lane * (restart + 1) + i] : 0.0;
+  ys[lane] = 0.0;
+  __syncthreads();
+  for (int i = k - 1; i >= 0; --i) {
+    double part = (lane > i && lane < k) ? sm[i * 64 + lane] * ys[lane] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == i) ys[i] = (gc[i] - part) / sm[i * 64 + i];
+    __syncthreads();
+  }
+  if (lane < k) y[lane * m + c] = ys[lane];
+}
+// the same, one thread per column (cycles longer than a wave: gmres_restart > 63)
+__global__ void gmres_backsolve_seq_kernel(GroupTab gt, int m, GroupInts ks, int restart,
+                                           const double* __restrict__ H, const double* __restrict__ g,
+                                           double* __restrict__ y) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
   const int k = ks.v[gt.gid[blockIdx.z]];
@@ -1889,8 +1923,13 @@ __global__ void gmres_backsolve_kernel(GroupTab gt, int m, GroupInts ks, int res
 void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
                               int restart, const double* H, const double* g, double* y) {
   if (gt.ng <= 0) return;
-  hipLaunchKernelGGL(gmres_backsolve_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m,
-                     k, restart, H, g, y);
+  if (restart > 63) {   // (the wave form holds one row per lane)
+    hipLaunchKernelGGL(gmres_backsolve_seq_kernel, dim3((m + 63) / 64, 1, gt.ng), dim3(64), 0, st, gt, m, k, restart,
+                       H, g, y);
+    return;
+  }
+  hipLaunchKernelGGL(gmres_backsolve_kernel, dim3(m, 1, gt.ng), dim3(64), (size_t)(restart + 1) * 64 * sizeof(double),
+                     st, gt, m, k, restart, H, g, y);
 }
 
 // start of a cycle: beta[c] = sqrt(nrm2[c]); g = [beta, 0...]; scale = 1/beta
