@@ -306,6 +306,7 @@ struct ricadi_ctx {
   long lr_epoch = 0;          // bumped whenever U / V change
   bool smw = true;            // RICADI_SMW=0: keep the low-rank term inside the Krylov operator
   DArr<double> smw_rhs, smw_x, smw_cap;
+  DArr<double> split_b, split_x;   // wide panels as sixteen-column groups (gmres_core_any)
   DArr<double> sweep_u, sweep_t, sweep_coef, sweep_part;   // ADI sweeps: the G solutions, a panel, coefficients, norm partials
   // per-shift data
   std::map<std::pair<double, double>, std::unique_ptr<ShiftData>> cache;
@@ -385,6 +386,13 @@ struct ricadi_ctx {
 
 namespace ricadi {
 
+// Width of the column groups a wide panel is solved in (0: the panel stays whole); see gmres_core_any.
+static int wide_split_width(const ricadi_ctx* c, int m) {
+  static const int off = getenv("RICADI_WIDE_SPLIT") && atoi(getenv("RICADI_WIDE_SPLIT")) == 0 ? 1 : 0;
+  (void)c;
+  return (!off && m > 32) ? 16 : 0;
+}
+
 // Workspace for batches of up to `groups` panels of width m (group-major: every
 // buffer holds one slab per group; basis is vector-major, i.e. Krylov vector j of
 // all groups is contiguous).
@@ -399,7 +407,10 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
     ensure_work(c->child.get(), m, groups, extra);
   }
   // every buffer scales with the total number of columns (m + extra) * groups
-  const int want = (m + extra) * groups;
+  int want = (m + extra) * groups;
+  // a wide panel is solved as chunks of up to RICADI_MAX_GROUPS sixteen-column groups: the buffers must hold a
+  // full chunk already NOW -- the caller's right-hand side lives in them (c->bvec) when the solve starts
+  if (wide_split_width(c, m + extra)) want = std::max(want, 16 * RICADI_MAX_GROUPS);
   if (want <= c->wcols && restart == c->wrestart) return;
   const size_t gm = (size_t)std::max(want, c->wcols);
   const size_t nm = (size_t)c->n * gm;
@@ -1392,6 +1403,88 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   lapc(c->t_cyc);
 }
 
+// ---- wide panels as sixteen-column groups -------------------------------------------------------
+// The columns of a panel are independent Arnoldi processes (per-column Givens), so an n x m panel with
+// m > 32 -- the time-varying Riccati loop's [M^T Z_c, sqrt(tau) C~^T, K_k] of up to comprz_maxc + NY' + NU
+// columns, /root/reference/solve_dae_ric.py:149 -- is solved as groups of 16 columns of the SAME shift in
+// the lockstep batch: every kernel tuned for the 16-column case (LDS-tiled SpMM, 16-byte Arnoldi kernels,
+// fused pressure step, FP16 vector input) then carries the iteration instead of the generic-width ones.
+// The shifts of the call are walked in chunks of floor(RICADI_MAX_GROUPS / groups per shift); the column
+// groups are scattered into / gathered from group-major panels (pad columns are zero: a zero column is
+// inert in every kernel of the iteration).  RICADI_WIDE_SPLIT=0 keeps the wide panels whole.
+static void gmres_core_any(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b, size_t gsb, double* x,
+                           int m, bool lowrank, GmresResult* res, bool have_x0, const std::vector<int>* only,
+                           bool allow_stall) {
+  const int W0 = wide_split_width(c, m);
+  if (!W0) {
+    gmres_core(c, sds, G, b, gsb, x, m, lowrank, res, have_x0, only, allow_stall);
+    return;
+  }
+  hipStream_t st = c->st;
+  const int n = c->n;
+  const size_t nm = (size_t)n * m;
+  std::vector<int> todo;
+  if (only) todo = *only;
+  else
+    for (int g = 0; g < G; ++g) todo.push_back(g);
+  for (int g = 0; g < G; ++g) res[g] = GmresResult();
+  for (int s : todo) res[s].converged = true;
+  // (ensure_work of the caller reserved a full chunk; growing the workspace here would free the buffer b lives in)
+  if (c->wcols < W0 * RICADI_MAX_GROUPS) throw HipError{"workspace not sized for the column groups of a wide panel"};
+  c->split_b.ensure((size_t)n * W0 * RICADI_MAX_GROUPS);
+  c->split_x.ensure((size_t)n * W0 * RICADI_MAX_GROUPS);
+  // columns [col0, col0 + ncols) of every panel as groups of W columns
+  auto run_pass = [&](int col0, int ncols, int W) {
+    const int ncg = (ncols + W - 1) / W;
+    const int per = std::max(1, RICADI_MAX_GROUPS / ncg);
+    const size_t nmw = (size_t)n * W;
+    // chunks of equal size (16 shifts, 3 per chunk: 3 3 3 3 2 2 rather than 3 3 3 3 3 1); the caller's order is
+    // kept: neighbouring shifts of a sorted list need similar iteration counts, which is what a lockstep batch wants
+    const int nchunk = ((int)todo.size() + per - 1) / per;
+    size_t at = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int cnt = ((int)todo.size() - (int)at + (nchunk - ch) - 1) / (nchunk - ch);
+      const int Gv = cnt * ncg;
+      std::vector<ShiftData*> vsds(Gv);
+      if (ncg * W != ncols) {
+        HIPCHK(hipMemsetAsync(c->split_b.p, 0, sizeof(double) * nmw * Gv, st));
+        if (have_x0) HIPCHK(hipMemsetAsync(c->split_x.p, 0, sizeof(double) * nmw * Gv, st));
+      }
+      for (int k = 0; k < cnt; ++k) {
+        const int s = todo[at + k];
+        for (int cg = 0; cg < ncg; ++cg) {
+          const int v = k * ncg + cg, w = std::min(W, ncols - cg * W), sc = col0 + cg * W;
+          vsds[v] = sds[s];
+          launch_copy_cols(st, n, w, b + (size_t)s * gsb, m, sc, c->split_b.p + (size_t)v * nmw, W, 0, 1.0);
+          if (have_x0)
+            launch_copy_cols(st, n, w, x + (size_t)s * nm, m, sc, c->split_x.p + (size_t)v * nmw, W, 0, 1.0);
+        }
+      }
+      std::vector<GmresResult> vres(Gv);
+      gmres_core(c, vsds.data(), Gv, c->split_b.p, nmw, c->split_x.p, W, lowrank, vres.data(), have_x0, nullptr,
+                 allow_stall);
+      for (int k = 0; k < cnt; ++k) {
+        const int s = todo[at + k];
+        GmresResult& r = res[s];
+        for (int cg = 0; cg < ncg; ++cg) {
+          const int v = k * ncg + cg, w = std::min(W, ncols - cg * W);
+          launch_copy_cols(st, n, w, c->split_x.p + (size_t)v * nmw, W, 0, x + (size_t)s * nm, m, col0 + cg * W, 1.0);
+          r.iters = std::max(r.iters, vres[v].iters);
+          r.converged = r.converged && vres[v].converged;
+          r.stalled = r.stalled || vres[v].stalled;
+          r.max_relres = std::max(r.max_relres, vres[v].max_relres);
+        }
+      }
+      at += cnt;
+    }
+  };
+  // (a remainder of up to 8 columns -- m = 66 = 4 x 16 + 2 -- as one more batch of 8-column groups over all
+  // shifts instead of a fifth sixteen-column group per shift was measured at n = 1e5: 2172 vs 2176 ms per pass
+  // over 64 shifts; the sweeps of an 8-column batch cost what those of a 16-column one do -- the block inverses
+  // they read are as many bytes as the panels)
+  run_pass(0, m, W0);
+}
+
 // ---- recycled right-hand sides (ricadi_set_recycle) ---------------------------------------------
 // Initial guesses  x_g = sum_e Y_{g,e} C_e  from the stored pairs (B_e, Y_{g,e}),  S_g Y_{g,e} = B_e, with
 // C = argmin || b - [B_e] C ||_F  (normal equations on the matrix cores, rank-revealing Cholesky on the
@@ -1592,14 +1685,14 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     c->t_guess += tkg.lap();
   }
   const int lvl0 = storage_level(c);
-  gmres_core(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, !no_net && lvl0 < 2);
+  gmres_core_any(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, !no_net && lvl0 < 2);
   std::vector<int> bad;
   for (int g = 0; g < G; ++g)
     if (!res[g].converged) bad.push_back(g);
   for (int level = lvl0 + 1; level <= 2 && !bad.empty() && !no_net; ++level) {
     StorageScope wide(c, level);
     std::vector<GmresResult> r2(G);
-    gmres_core(c, sds, G, b, gsb, x, m, lowrank, r2.data(), true, &bad, level < 2);
+    gmres_core_any(c, sds, G, b, gsb, x, m, lowrank, r2.data(), true, &bad, level < 2);
     c->escalations += (long)bad.size();
     std::vector<int> still;
     for (int g : bad) {

@@ -20,6 +20,9 @@ from oracle import lin_alg_utils as lau, proj_ric_utils as pru  # noqa: E402
 CFG1 = dict(N=15, nu=0.1, alphau=1e-2, NU=4, NY=4, nshifts=8, pmin=1.0, pmax=1e3)
 # BASELINE cfg2 = the benchmark's workload (bench.py:build_inputs): N = 58 -> n = 29 930
 CFG2 = dict(N=58, nu=0.05, alphau=1e-2, NU=4, NY=4, nshifts=16, pmin=1.0, pmax=3e3)
+# BASELINE cfg3 surrogate (bench.py --workload cfg3): N = 75 -> n = 50 177, nu = 0.15 / 40, 32 shifts --
+# the steady-state Riccati run of cyl_wake_cont.py:34-50 / optcont_main.py:488-506
+CFG3 = dict(N=75, nu=0.15 / 40.0, alphau=1e-2, NU=4, NY=4, nshifts=32, pmin=1.0, pmax=3e3)
 
 
 def cfg1_inputs(cfg=CFG1):
@@ -68,15 +71,17 @@ def main():
           "newton steps", ro["nwtn_steps"], "k", Zc.shape[1])
 
 
-def main_cfg2():
+def main_cfg2(CFG=CFG2, name="cfg2_golden.npz"):
     """Newton-ADI of the oracle at the benchmark size (about 5 min, 16 sparse LUs per Newton
     step).  Stored: the converged feedback gain K (the bench / GPU-test target), the Newton
-    history, and the gain after the FIRST Newton step (Z_0 = 0: open-loop Lyapunov solve)."""
+    history, and the gain after the FIRST Newton step (Z_0 = 0: open-loop Lyapunov solve).
+    `--cfg3`: the same at the cylinder-wake surrogate's size (N = 75, 32 shifts)."""
     import time
     t0 = time.time()
+    CFG2 = CFG
     pr, tb, trct, ms = cfg1_inputs(CFG2)
     F = (-pr.A - pr.Nc).tocsr()
-    d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+    d = dict(pb.default_nwtn_adi_dict(), ms=ms, verbose=bool(os.environ.get("GOLDEN_VERBOSE")))
     stats = {}
     ro = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct,
                                     nwtn_adi_dict=d, stats=stats)
@@ -95,7 +100,7 @@ def main_cfg2():
         oracle_seconds=np.array([time.time() - t0, stats.get("lu_time", 0.0), stats.get("solve_time", 0.0),
                                  stats.get("n_lu", 0), stats.get("n_shift_solves", 0)]),
     )
-    path = os.path.join(HERE, "cfg2_golden.npz")
+    path = os.path.join(HERE, name)
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; |K_ric| =", np.linalg.norm(K_ric), "newton steps",
           ro["nwtn_steps"], "upd_hist", out["upd_hist"].tolist(), "seconds", out["oracle_seconds"].tolist())
@@ -128,5 +133,7 @@ if __name__ == "__main__":
         main_dre30()
     elif "--cfg2" in sys.argv:
         main_cfg2()
+    elif "--cfg3" in sys.argv:
+        main_cfg2(CFG3, "cfg3_golden.npz")
     else:
         main()
