@@ -190,7 +190,7 @@ int ricadi_lyap_adi(ricadi_ctx* ctx, const double* shifts, int nshifts,
  * the GMRES tolerance, their worst relative residual, ||W_end^T W_end||_F of the
  * last Lyapunov solve (its projected residual norm: `check_lyap_res`,
  * /root/reference/optcont_main.py:130), ||W_0^T W_0||_F of its right-hand side,
- * 0, 0].                                                                       */
+ * solves repeated with wider storage, batched ADI sweeps run (sweep form)].     */
 int ricadi_ric_newtonadi(ricadi_ctx* ctx, const double* shifts, int nshifts,
                          const double* B, int nb, const double* W, int mw,
                          const double* Z0, int c0, const double* oldB,
@@ -358,8 +358,20 @@ int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_
  *        1 if the GMRES iteration hands the preconditioner the FP16-stored vector,
  *        padded width of the dense rectangles of the last velocity sweep (0: not in that form),
  *        the same for the first (two-term) velocity sweep, NP, nnz(J), nnz(S*Y)];
+ *        entries of the restriction,
+ *        route the last batch of dense coarse inverses took (0 block Gauss-Jordan without pivoting, 1 rocSOLVER
+ *        with partial pivoting; -1 none yet),
+ *        kernel of the last saddle SpMM launch (0 CSR, 1 LDS-tiled per group, 2 LDS-tiled multi-shift; +4 with
+ *        FP32 x input; -1 none yet)];
  * nout >= 8; entries beyond nout are not written.                                   */
 int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
+
+/* In-place inverses of nb dense k x k matrices (row major, back to back in A, host memory) by the routine the
+ * setup uses for the coarse matrices of a batch of shifts: block Gauss-Jordan without pivoting, and -- when a
+ * pivot vanishes relative to the scale of its diagonal block -- rocSOLVER's getrf / getri with partial
+ * pivoting for the whole batch.  *route_out: the route that finished (as in ricadi_setup_info).  Exported for
+ * tests (the production operators never leave route 0).  No reference counterpart (its LU is SuperLU's). */
+int ricadi_dense_inverse_batch(ricadi_ctx* ctx, int k, int nb, double* A, int* route_out);
 
 /* Average duration (ms) of the thin QR of a device-resident NV x c factor (the device
  * part of ricadi_qr: Householder TSQR panels inside a block Gram-Schmidt on the MFMA
@@ -390,10 +402,13 @@ int ricadi_set_recycle(ricadi_ctx* ctx, int depth);
  * The ADI sweeps of ricadi_lyap_adi / ricadi_ric_newtonadi (sweep_width > 1) shard by shift:
  * every rank owns a fixed subset of the shift list (ricadi_host_deal), sets up and solves only
  * its own shifts of a sweep in one batched solve, and the solution panels are exchanged by ONE
- * all-gather per sweep; recombination, recompression, update norm and gain are replicated, the
- * stopping decisions are rank 0's (a second, tiny all-gather per sweep).  The library does not
- * link a communication library: the host supplies the collective as a callback on two device
- * buffers it owns (torch.distributed.all_gather_into_tensor over RCCL in the Python binding):
+ * all-gather per sweep; recombination, recompression, update norm and gain are replicated.  The
+ * stopping decisions inside a sweep are taken by every rank on its own from the gathered panels (the
+ * block norms are summed in a fixed order, so the ranks see the same bits); a rank whose own setup or
+ * solves fail still takes part in the all-gather with a status word set, and all ranks return the error
+ * together.  Two transports: RCCL inside the library (ricadi_set_exchange_rccl, below), or -- this call --
+ * a collective the host supplies as a callback on two device buffers it owns (the Python binding uses it
+ * for gloo groups: CPU tests and the one-GPU rehearsal):
  *   fn(user, send_dev, recv_dev, bytes_per_rank) must place rank r's first bytes_per_rank bytes
  *   of send_dev at recv_dev + r * bytes_per_rank on EVERY rank and return 0 once the data are
  *   visible to work enqueued afterwards on any stream (the library has synchronised its own
@@ -407,6 +422,28 @@ typedef int (*ricadi_allgather_fn)(void* user, const void* send_dev, void* recv_
                                    int64_t bytes_per_rank);
 int ricadi_set_exchange(ricadi_ctx* ctx, int rank, int world, ricadi_allgather_fn fn, void* user,
                         void* send_dev, void* recv_dev, int64_t send_capacity);
+
+/* The same sharding with the collective INSIDE the library: RCCL's ncclAllGather (double, count = n * m per
+ * solution panel and rank) enqueued on the context's stream between the solves and the recombination -- no host
+ * synchronisation, no callback (section 5: the blocks exchanged are the V_i of
+ * /root/reference/solve_dae_ric.py:152-159, the reference itself has nothing distributed).
+ *   ricadi_rccl_unique_id: 128 bytes from ncclGetUniqueId; rank 0 calls it and hands the bytes to the other
+ *     ranks by whatever means the host has (the Python binding: torch.distributed.broadcast_object_list).
+ *   ricadi_set_exchange_rccl: joins the communicator of `world` ranks identified by unique_id
+ *     (ncclCommInitRank, collective over the ranks; destroyed with the context) -- or, with comm != NULL, uses an
+ *     ncclComm_t the caller created (not destroyed by the library).  The library allocates its own send buffer
+ *     of send_capacity bytes and receive buffer of world * send_capacity bytes (capacity needed:
+ *     max panels per rank and sweep * n * m * 8 + 4096).  world = 1 is allowed and still runs the exchange
+ *     path (one rank: the transport test).  unique_id = comm = NULL on a context that already holds a
+ *     communicator of the same rank / world keeps it and only re-sizes the buffers.
+ *     Replaces a callback set by ricadi_set_exchange and vice versa;
+ *     ricadi_set_exchange(ctx, 0, 1, NULL, ...) removes either.
+ *   ricadi_exchange_count: collectives the context has issued so far, control messages included (a sweep
+ *     costs exactly one; a Newton step one more for the update-norm decision, an ADI call one for statistics). */
+int ricadi_rccl_unique_id(void* id_out, int bytes);
+int ricadi_set_exchange_rccl(ricadi_ctx* ctx, int rank, int world, const void* unique_id, void* comm,
+                             int64_t send_capacity);
+int ricadi_exchange_count(ricadi_ctx* ctx, int64_t* count_out);
 
 /* ---- host-side logic exported for CPU tests ---------------------------- */
 /* Owner rank of every entry of an ADI shift list under `world` ranks: longest-processing-time

@@ -20,7 +20,7 @@ RICADI_ENOCONV = -3
 MAX_M = 128
 # ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
 # are part of the ABI and are not covered by the struct handshake below
-ABI_VERSION = 303
+ABI_VERSION = 400
 
 
 class RicadiOpts(C.Structure):
@@ -105,6 +105,10 @@ SIGNATURES = {
     "ricadi_time_gram_dev": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _dp]),
     "ricadi_set_recycle": (C.c_int, [_vp, C.c_int]),
     "ricadi_set_exchange": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int64]),
+    "ricadi_rccl_unique_id": (C.c_int, [_vp, C.c_int]),
+    "ricadi_set_exchange_rccl": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, C.c_int64]),
+    "ricadi_exchange_count": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "ricadi_dense_inverse_batch": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.POINTER(C.c_int)]),
     "ricadi_host_deal": (C.c_int, [_dp, C.c_int, C.c_int, _ip]),
     "ricadi_host_sa_criterion": (C.c_int, [C.c_int, _ip, _ip, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int)]),
@@ -337,13 +341,21 @@ class Context:
     def set_recycle(self, depth):
         """Depth of the recycling ring for DIRECT solve calls (the ADI drivers use their own, 3)."""
         _chk(self._lib.ricadi_set_recycle(self._h, int(depth)))
+        self.recycle_depth = int(depth)
 
-    def set_exchange(self, group=None, panel_cols=MAX_M, per_rank=2):
+    def set_exchange(self, group=None, panel_cols=MAX_M, per_rank=2, transport=None):
         """Shard the ADI sweeps of this context over the ranks of a ``torch.distributed`` process group
-        (SURVEY.md 8e): the library calls back for ONE all-gather per sweep
-        (``all_gather_into_tensor`` -- RCCL over xGMI with the nccl backend) on two device buffers
-        allocated here: ``per_rank`` solution panels of ``n x panel_cols`` per rank.  ``group=False``
-        removes the exchange."""
+        (SURVEY.md 8e): ONE all-gather of the solution panels per sweep, ``per_rank`` panels of
+        ``n x panel_cols`` per rank.  ``transport``:
+
+        * ``"rccl"`` (default for groups of the nccl backend): the library joins an RCCL communicator of its
+          own -- rank 0's ``ncclGetUniqueId`` bytes go round through the group -- and enqueues
+          ``ncclAllGather`` on its stream between the solves and the recombination (``ricadi_set_exchange_rccl``):
+          no host synchronisation, no Python in the sweep;
+        * ``"callback"`` (gloo groups: CPU tests, several ranks on one GPU): the library calls back for
+          ``all_gather_into_tensor`` on two device buffers allocated here.
+
+        ``group=False`` removes the exchange."""
         import torch
         import torch.distributed as dist
         if group is False or not (dist.is_available() and dist.is_initialized()):
@@ -351,11 +363,32 @@ class Context:
             self._xchg = None
             return
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        if world == 1:
+        if transport is None:
+            transport = "rccl" if dist.get_backend(group) == "nccl" else "callback"
+        if world == 1 and transport != "rccl":
             _chk(self._lib.ricadi_set_exchange(self._h, 0, 1, None, None, None, None, 0))
             self._xchg = None
             return
         count = int(per_rank) * self.n * int(panel_cols) + 512        # + 4096 bytes of control messages
+        if transport == "rccl":
+            cur = getattr(self, "_xchg", None)
+            if cur is not None and cur[0] == "rccl" and cur[3] is group:
+                # same communicator, larger buffers (wider panels)
+                _chk(self._lib.ricadi_set_exchange_rccl(self._h, rank, world, None, None, count * 8))
+                self._xchg = ("rccl", None, None, group, count)
+                return
+            ident = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                _chk(self._lib.ricadi_rccl_unique_id(buf, 128))
+                ident[0] = buf.raw
+            if world > 1:
+                dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                           group=group)
+            torch.cuda.synchronize()
+            _chk(self._lib.ricadi_set_exchange_rccl(self._h, rank, world, ident[0], None, count * 8))
+            self._xchg = ("rccl", None, None, group, count)
+            return
         dev = torch.device("cuda", torch.cuda.current_device())
         send = torch.zeros(count, dtype=torch.float64, device=dev)
         recv = torch.zeros(count * world, dtype=torch.float64, device=dev)
@@ -378,6 +411,12 @@ class Context:
         _chk(self._lib.ricadi_set_exchange(self._h, rank, world, C.cast(cb, _vp), None, send.data_ptr(),
                                            recv.data_ptr(), count * 8))
         self._xchg = (cb, send, recv, group, count)          # keep the callback and the buffers alive
+
+    def exchange_count(self):
+        """Collectives this context has issued so far (one per sharded ADI sweep + control messages)."""
+        k = C.c_int64(0)
+        _chk(self._lib.ricadi_exchange_count(self._h, C.byref(k)))
+        return int(k.value)
 
     # -- kernels ----------------------------------------------------------
     def _need_op(self):
@@ -473,7 +512,8 @@ class Context:
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
                     shift_solves=int(stats[5]), cols=c,
                     gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7],
-                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]))
+                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]),
+                    adi_sweeps=int(stats[11]))
         _warn_nonconverged(info)
         return Z, info
 
@@ -502,7 +542,8 @@ class Context:
                     adi_steps=int(stats[3]), gmres_iters=int(stats[4]),
                     shift_solves=int(stats[5]), cols=c,
                     gmres_nonconverged=int(stats[6]), gmres_worst_relres=stats[7],
-                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]))
+                    lyap_res_fro=stats[8], lyap_rhs_fro=stats[9], storage_escalations=int(stats[10]),
+                    adi_sweeps=int(stats[11]))
         _warn_nonconverged(info)
         return Zt, info
 
@@ -619,11 +660,21 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 17)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 17))
+        a = (C.c_int * 19)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 19))
         return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
                          "dense_coarse", "fp16_vector_input", "rect_ks", "two_term_ks", "np_", "nnz_j",
-                         "nnz_sy", "nnz_restriction"), list(a)))
+                         "nnz_sy", "nnz_restriction", "coarse_route", "k1_variant"), list(a)))
+
+    def dense_inverse_batch(self, mats):
+        """In-place inverses of a batch of dense matrices by the setup's coarse-matrix routine; returns
+        (inverses, route) -- route 0 block Gauss-Jordan, 1 rocSOLVER with partial pivoting."""
+        A = np.ascontiguousarray(mats, dtype=np.float64).copy()
+        if A.ndim != 3 or A.shape[1] != A.shape[2]:
+            raise ValueError("mats must be nb x k x k")
+        route = C.c_int(-1)
+        _chk(self._lib.ricadi_dense_inverse_batch(self._h, A.shape[1], A.shape[0], _d(A), C.byref(route)))
+        return A, int(route.value)
 
     def time_qr_dev(self, z_ptr, c, reps):
         ms = C.c_double(0.0)

@@ -4141,49 +4141,52 @@ void launch_pchol_trail(hipStream_t st, double* A, int ld, int nr, int nc, const
 // coef is the host's replicated layout coef[(j nslot + s) m + c] (the same value for every c).
 // ---------------------------------------------------------------------------
 constexpr int SWC_ROWS = 64, SWC_MAXS = 16;
+// The norms steer the ADI's stopping decisions, and with rank-sharded sweeps every rank takes them on its own from
+// the same gathered panels: all sums below run in a FIXED order (no atomics), so that the ranks get the same bits.
 __global__ __launch_bounds__(256) void sweep_combine_kernel(int nrows, int m, int nslot, int G,
                                                             const double* __restrict__ U, size_t ustride,
                                                             const double* __restrict__ coef,
                                                             double* __restrict__ Z, int zld, int zc0,
                                                             double* __restrict__ partial) {
   __shared__ double cs[SWC_MAXS * SWC_MAXS];
-  __shared__ double nr[SWC_MAXS * RICADI_MAX_M];
+  __shared__ double acc[SWC_MAXS][256];
   const int tid = threadIdx.x;
   for (int e = tid; e < G * nslot; e += 256) cs[e] = coef[(size_t)e * m];
-  for (int e = tid; e < G * m; e += 256) nr[e] = 0.0;
   __syncthreads();
   const int r0 = blockIdx.x * SWC_ROWS;
   const int cnt = min(SWC_ROWS, nrows - r0) * m;
-  const bool fixedc = (256 % m) == 0;         // the thread's column is the same for all of its elements
+  const int nthr = (256 / m) * m;             // working threads: a thread's column is the same for all of its elements
   double racc[SWC_MAXS];
 #pragma unroll
   for (int j = 0; j < SWC_MAXS; ++j) racc[j] = 0.0;
-  for (int e = tid; e < cnt; e += 256) {
-    const int r = r0 + e / m, cidx = e % m;
-    double u[SWC_MAXS];
+  if (tid < nthr)
+    for (int e = tid; e < cnt; e += nthr) {
+      const int r = r0 + e / m, cidx = e % m;
+      double u[SWC_MAXS];
 #pragma unroll
-    for (int sl = 0; sl < SWC_MAXS; ++sl)
-      u[sl] = sl < nslot ? U[(size_t)sl * ustride + (size_t)r * m + cidx] : 0.0;
+      for (int sl = 0; sl < SWC_MAXS; ++sl)
+        u[sl] = sl < nslot ? U[(size_t)sl * ustride + (size_t)r * m + cidx] : 0.0;
 #pragma unroll
-    for (int j = 0; j < SWC_MAXS; ++j) {
-      if (j < G) {
-        double v = 0.0;
+      for (int j = 0; j < SWC_MAXS; ++j) {
+        if (j < G) {
+          double v = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < SWC_MAXS; ++sl) v = fma(sl < nslot ? cs[j * nslot + sl] : 0.0, u[sl], v);
-        Z[(size_t)r * zld + zc0 + j * m + cidx] = v;
-        if (fixedc) racc[j] = fma(v, v, racc[j]);
-        else atomicAdd(&nr[j * m + cidx], v * v);
+          for (int sl = 0; sl < SWC_MAXS; ++sl) v = fma(sl < nslot ? cs[j * nslot + sl] : 0.0, u[sl], v);
+          Z[(size_t)r * zld + zc0 + j * m + cidx] = v;
+          racc[j] = fma(v, v, racc[j]);
+        }
       }
     }
-  }
-  if (fixedc) {
-    const int cidx = tid % m;
 #pragma unroll
-    for (int j = 0; j < SWC_MAXS; ++j)
-      if (j < G) atomicAdd(&nr[j * m + cidx], racc[j]);
-  }
+  for (int j = 0; j < SWC_MAXS; ++j)
+    if (j < G) acc[j][tid] = racc[j];
   __syncthreads();
-  for (int e = tid; e < G * m; e += 256) partial[(size_t)blockIdx.x * G * m + e] = nr[e];
+  for (int e = tid; e < G * m; e += 256) {
+    const int j = e / m, cidx = e % m;
+    double s = 0.0;
+    for (int k = cidx; k < nthr; k += m) s += acc[j][k];
+    partial[(size_t)blockIdx.x * G * m + e] = s;
+  }
 }
 __global__ __launch_bounds__(256) void sweep_norms_kernel(int nwg, int gm, const double* __restrict__ partial,
                                                           double* __restrict__ out) {

@@ -4,6 +4,7 @@
 // New code (the reference has no native source).  The
 // algorithms restate what the reference *calls* -- see include/ricadi.h for the
 // reference call site behind each entry point.
+#include <rccl/rccl.h>
 #include <rocsolver/rocsolver.h>
 
 #include <chrono>
@@ -361,6 +362,15 @@ struct ricadi_ctx {
   double* xsend = nullptr;
   double* xrecv = nullptr;
   size_t xcap = 0;            // capacity of xsend in bytes
+  // RCCL transport (ricadi_set_exchange_rccl): the all-gather is enqueued on the context's stream -- no host
+  // round trip, no callback; the buffers are the library's own
+  ncclComm_t xcomm = nullptr;
+  bool xcomm_owned = false;
+  bool xforce = false;        // a communicator of ONE rank still runs the exchange path (transport test)
+  DArr<double> xsend_own, xrecv_own;
+  long xcount = 0;            // collectives issued so far (ricadi_exchange_count)
+  int coarse_route = -1;      // route the last batch of coarse inverses took (invert_dense_batch); -1: none yet
+  int k1_variant = -1;        // saddle SpMM kernel of the last batched launch (saddle_spmm): 0 CSR, 1 tiled, 2 tiled multi-shift; +4: FP32 x
   // stats
   long total_iters = 0, total_solves = 0;
   long escalations = 0;       // solves repeated with wider storage of basis / preconditioner (safety net)
@@ -373,6 +383,7 @@ struct ricadi_ctx {
 
   ~ricadi_ctx() {
     if (h_resid) (void)hipHostFree(h_resid);
+    if (xcomm && xcomm_owned) (void)ncclCommDestroy(xcomm);
     for (int i = 0; i < 2; ++i)
       if (ev_res[i]) (void)hipEventDestroy(ev_res[i]);
     child.reset();
@@ -522,6 +533,41 @@ static bool gj_invert_batched(ricadi_ctx* c, double* const* hmats, int nb, int k
   return flag == 0;
 }
 
+// In-place inverses of nb dense k x k matrices (row major, device pointers in hp): the coarse matrices of a setup.
+// Route 0: block Gauss-Jordan WITHOUT pivoting on batched GEMMs (gj_invert_batched) -- with the velocity
+// aggregates ordered before the pressure aggregates that is block elimination of the coarse saddle matrix: the
+// velocity block has a definite symmetric part for ADI shifts (and is s.p.d. for the projection), the Schur
+// complement -B Av^-1 B^T inherits it.  A pivot that vanishes relative to its block's scale sends ALL matrices of
+// the call through route 1: rocSOLVER's getrf / getri with partial pivoting (its unpivoted routines, the step in
+// between until round 3, only notice an EXACTLY zero pivot -- a pivot of 1e-14 of the block's scale passed and left
+// a garbage inverse).  `reassemble` restores the matrices the first route has overwritten.  info (nb entries):
+// rocSOLVER's status.  Returns the route.
+template <class F>
+static int invert_dense_batch(ricadi_ctx* c, const std::vector<double*>& hp, int k, std::vector<int>& info,
+                              F&& reassemble) {
+  hipStream_t st = c->st;
+  const int nb = (int)hp.size();
+  bool done = true;
+  for (int i0 = 0; i0 < nb && done; i0 += gj_max_batch())
+    done = gj_invert_batched(c, hp.data() + i0, std::min(gj_max_batch(), nb - i0), k);
+  if (done) {
+    std::fill(info.begin(), info.end(), 0);
+    return 0;
+  }
+  reassemble();
+  // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
+  c->ipiv.ensure((size_t)k * nb);
+  c->info.ensure(nb);
+  c->eptrs.ensure(nb);
+  HIPCHK(hipMemcpyAsync(c->eptrs.p, hp.data(), sizeof(double*) * nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // hp may be a stack object of the caller
+  RBCHK(rocsolver_dgetrf_batched(c->rb, k, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
+  RBCHK(rocsolver_dgetri_batched(c->rb, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
+  HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return 1;
+}
+
 // Per-shift data for the given (alpha, beta) pairs; whatever is missing is built for
 // all of them together: the element-wise / block kernels per shift, the dense coarse
 // inverses in ONE batched rocSOLVER factorisation + inversion (its many small
@@ -632,53 +678,12 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
   const int nb = (int)todo.size();
   std::vector<int> info(nb, 0);
   if (kd > 0) {
-    // row-major E == column-major E^T; inv(E^T) column-major == inv(E) row-major
-    c->ipiv.ensure((size_t)k * nb);
-    c->info.ensure(nb);
     std::vector<double*> hp(nb);
     for (int i = 0; i < nb; ++i) hp[i] = todo[i]->einv.p;
-    c->eptrs.ensure(nb);
-    HIPCHK(hipMemcpyAsync(c->eptrs.p, hp.data(), sizeof(double*) * nb, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));   // hp is a stack object
-    // LU WITHOUT pivoting first: with the velocity aggregates ordered before the pressure
-    // aggregates it is block elimination of the coarse saddle matrix -- the velocity
-    // block has a definite symmetric part for ADI shifts (and is s.p.d. for the
-    // projection), the Schur complement -B Av^-1 B^T inherits it -- and it spares
-    // rocSOLVER's pivot search / row swap kernels, most of the small launches of the
-    // factorisation.  A zero pivot (info != 0) sends all matrices of the call through
-    // the pivoted routines.
-    static const bool npvt = getenv("RICADI_COARSE_PIVOT") == nullptr;
-    // default: block Gauss-Jordan on batched GEMMs (RICADI_COARSE_GJ=0: rocSOLVER getrf + getri)
-    static const bool gj = !(getenv("RICADI_COARSE_GJ") && atoi(getenv("RICADI_COARSE_GJ")) == 0);
-    bool done = false, done_gj = false;
-    if (gj && npvt) {
-      done = true;
-      for (int i0 = 0; i0 < nb && done; i0 += gj_max_batch())
-        done = gj_invert_batched(c, hp.data() + i0, std::min(gj_max_batch(), nb - i0), k);
-      done_gj = done;
-      if (!done)
-        for (ShiftData* sd : todo)   // a vanishing pivot: assemble again for the rocSOLVER routes
-          launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, sd->alpha, sd->beta, sd->einv.p);
-    }
-    if (!done && npvt) {
-      RBCHK(rocsolver_dgetrf_npvt_batched(c->rb, k, k, c->eptrs.p, k, c->info.p, nb));
-      HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-      done = true;
-      for (int i = 0; i < nb; ++i) done = done && info[i] == 0;
-      if (done) {
-        RBCHK(rocsolver_dgetri_npvt_batched(c->rb, k, c->eptrs.p, k, c->info.p, nb));
-      } else {
-        for (ShiftData* sd : todo)   // the factorisation overwrote the matrices: assemble again
-          launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, sd->alpha, sd->beta, sd->einv.p);
-      }
-    }
-    if (!done) {
-      RBCHK(rocsolver_dgetrf_batched(c->rb, k, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
-      RBCHK(rocsolver_dgetri_batched(c->rb, k, c->eptrs.p, k, c->ipiv.p, k, c->info.p, nb));
-    }
-    if (!(gj && npvt && done_gj))
-      HIPCHK(hipMemcpyAsync(info.data(), c->info.p, sizeof(int) * nb, hipMemcpyDeviceToHost, st));
+    c->coarse_route = invert_dense_batch(c, hp, k, info, [&] {
+      for (ShiftData* sd : todo)
+        launch_combine3(st, (size_t)k * k, c->E0.p, c->EM.p, c->EJ.p, sd->alpha, sd->beta, sd->einv.p);
+    });
   }
   lapS(3);
   int flag = 0;
@@ -833,7 +838,9 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
   const bool fits = saddle_tiled(c, m);
   const bool has_lr = lr.q > 0 && lr.nrows > 0;
   if (x32 && fits && !r && !xmap && !has_lr) {
-    if (ms_pays(c, bt.tab.ng, c->snnz) && spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n))
+    const bool ms = ms_pays(c, bt.tab.ng, c->snnz) && spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n);
+    c->k1_variant = (ms ? 2 : 1) + 4;
+    if (ms)
       launch_spmm_blocked_ms_x32(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
                                  c->sb_cols2.p, c->sb_lidx_ms.p, c->sbAJ.p, c->sbE.p, x32, m, gsx, y, m, gsy, alpha,
                                  m, c->sb_max_cols);
@@ -842,8 +849,10 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
                               bt.svalb, x32, m, gsx, y, m, gsy, alpha, m, c->sb_max_cols);
     return;
   }
-  if (fits && ms_pays(c, bt.tab.ng, c->snnz) && !xmap && !has_lr &&
-      spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n))
+  const bool ms = fits && ms_pays(c, bt.tab.ng, c->snnz) && !xmap && !has_lr &&
+                  spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n);
+  if (!xmap) c->k1_variant = ms ? 2 : fits ? 1 : 0;
+  if (ms)
     launch_spmm_blocked_ms(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
                            c->sb_cols2.p, c->sb_lidx_ms.p, c->sbAJ.p, c->sbE.p, x, m, gsx, y, m, gsy,
                            r, m, gsr, alpha, beta_r, m, c->sb_max_cols);
@@ -2088,6 +2097,7 @@ struct AdiStats {
   double res_fro = 0.0;
   long nonconverged = 0;      // shift-solves that hit gmres_maxit above the tolerance
   double worst_relres = 0.0;
+  int sweeps = 0;             // sweep form: batched sweeps run (= all-gathers when sharded)
 };
 
 // dW: NV x m device panel (overwritten by the final residual factor).
@@ -2108,6 +2118,13 @@ struct AdiStats {
 #define RICADI_XCTL 4096
 static size_t exchange_panel_capacity(const ricadi_ctx* c) { return c->xcap > RICADI_XCTL ? c->xcap - RICADI_XCTL : 0; }
 static void exchange_at(ricadi_ctx* c, double* send, double* recv, size_t count) {
+  ++c->xcount;
+  if (c->xcomm) {
+    // RCCL: stream ordered behind the solves that filled `send`, ahead of the recombination that reads `recv`
+    const ncclResult_t r = ncclAllGather(send, recv, count, ncclDouble, c->xcomm, c->st);
+    if (r != ncclSuccess) throw HipError{std::string("ncclAllGather: ") + ncclGetErrorString(r)};
+    return;
+  }
   HIPCHK(hipStreamSynchronize(c->st));
   const int rc = c->xfn(c->xuser, send, recv, (int64_t)(count * sizeof(double)));
   if (rc != 0) throw HipError{"the all-gather callback of ricadi_set_exchange failed (" + std::to_string(rc) + ")"};
@@ -2122,7 +2139,7 @@ static double* ctl_send(ricadi_ctx* c) { return c->xsend + exchange_panel_capaci
 static double* ctl_recv(ricadi_ctx* c) {
   return c->xrecv + (size_t)c->xworld * exchange_panel_capacity(c) / sizeof(double);
 }
-static bool sharded(const ricadi_ctx* c) { return c->xworld > 1 && c->xfn != nullptr; }
+static bool sharded(const ricadi_ctx* c) { return (c->xworld > 1 || c->xforce) && (c->xfn != nullptr || c->xcomm != nullptr); }
 // v[0..n) <- rank 0's values (decisions must not differ between the ranks: the norms they rest on come
 // from kernels with atomic accumulation).  One tiny all-gather.
 static void values_of_rank0(ricadi_ctx* c, double* v, int n) {
@@ -2133,9 +2150,10 @@ static void values_of_rank0(ricadi_ctx* c, double* v, int n) {
   HIPCHK(hipMemcpyAsync(v, ctl_recv(c), sizeof(double) * n, hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
 }
-// v[0..n) <- sum over the ranks (statistics)
-static void sum_over_ranks(ricadi_ctx* c, double* v, int n) {
+// v[0..nsum) <- sum over the ranks, v[nsum..nsum+nmax) <- maximum over the ranks (statistics)
+static void reduce_over_ranks(ricadi_ctx* c, double* v, int nsum, int nmax) {
   if (!sharded(c)) return;
+  const int n = nsum + nmax;
   if ((size_t)n * sizeof(double) > RICADI_XCTL) throw HipError{"control message too long"};
   HIPCHK(hipMemcpyAsync(ctl_send(c), v, sizeof(double) * n, hipMemcpyHostToDevice, c->st));
   exchange_at(c, ctl_send(c), ctl_recv(c), (size_t)n);
@@ -2143,8 +2161,11 @@ static void sum_over_ranks(ricadi_ctx* c, double* v, int n) {
   HIPCHK(hipMemcpyAsync(all.data(), ctl_recv(c), sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->st));
   HIPCHK(hipStreamSynchronize(c->st));
   for (int i = 0; i < n; ++i) {
-    double t = 0.0;
-    for (int r = 0; r < c->xworld; ++r) t += all[(size_t)r * n + i];
+    double t = all[i];
+    for (int r = 1; r < c->xworld; ++r) {
+      const double o = all[(size_t)r * n + i];
+      t = i < nsum ? t + o : std::max(t, o);
+    }
     v[i] = t;
   }
 }
@@ -2186,15 +2207,38 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
       acc += tk.lap();
     }
   };
-  {
+  // A failure in the OWNER-LOCAL work of a rank (per-shift setup: a singular block; its solves) must not leave the
+  // other ranks waiting in the sweep's all-gather: it is recorded here, the rank still takes part in the exchange
+  // -- with zero panels and its status word set --, and all ranks throw together once the words have gone round.
+  // The words ride in the pressure rows of each rank's first solution panel (the recombination reads velocity
+  // rows only), so a sweep costs ONE collective.
+  std::string fail;
+  auto guarded = [&](auto&& body) {
+    if (!shard) {
+      body();
+      return;
+    }
+    try {
+      body();
+    } catch (const HipError& e) {
+      fail = e.msg;
+    } catch (const std::exception& e) {
+      fail = e.what();
+    }
+  };
+  const bool words_fit = (size_t)c->np * m >= 2;
+  guarded([&] {
     std::vector<double> mine;
     const int nuse = std::min(ns, prm.adi_max_steps);
     for (int i = 0; i < nuse; ++i)
       if (owner[i] == rank) mine.push_back(shifts[i]);
     prefetch_setup(c, mine.data(), (int)mine.size(), prm.project_w != 0);
-  }
+  });
   lap(c->t_setup);
-  if (prm.project_w) project_panel(c, dW, m);
+  if (prm.project_w) {
+    // (replicated: the projection operator is set up by every rank; a rank whose own setup failed skips it)
+    if (fail.empty()) guarded([&] { project_panel(c, dW, m); });
+  }
   lap(c->t_proj);
   const long it0 = c->total_iters;
   if (!shard) c->sweep_u.ensure(nm * G);
@@ -2279,9 +2323,8 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     const int nslot = world * per_rank, nmine = (int)mine.size();
     std::vector<double> psm(nmine);
     for (int k = 0; k < nmine; ++k) psm[k] = ps[mine[k]];
-    if (nmine) get_shifts(c, psm.data(), be.data(), nmine, sds.data());
+    if (nmine && fail.empty()) guarded([&] { get_shifts(c, psm.data(), be.data(), nmine, sds.data()); });
     lap(c->t_setup);
-    load_rhs(c, dW, m, c->bvec.p);
     double* usolve = shard ? c->xsend : c->sweep_u.p;
     if (shard) {
       if ((size_t)per_rank * nm * sizeof(double) > exchange_panel_capacity(c))
@@ -2291,17 +2334,37 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
       if (nmine < per_rank)
         HIPCHK(hipMemsetAsync(c->xsend + (size_t)nmine * nm, 0, sizeof(double) * nm * (per_rank - nmine), st));
     }
-    if (nmine) solve_batch(c, sds.data(), nmine, c->bvec.p, 0, usolve, m, true, nullptr, res.data());
+    if (nmine && fail.empty())
+      guarded([&] {
+        // test hook (tests/test_gpu_round4.py): this rank's share of sweep k fails
+        if (const char* inj = shard ? getenv("RICADI_INJECT_SWEEP_FAILURE") : nullptr)
+          if (atoi(inj) == sw) throw HipError{"injected failure in sweep " + std::to_string(sw)};
+        load_rhs(c, dW, m, c->bvec.p);
+        solve_batch(c, sds.data(), nmine, c->bvec.p, 0, usolve, m, true, nullptr, res.data());
+      });
     c->lr_ucol = -1;            // only the first solve of a Newton step has U among its rhs columns
     lap(c->t_solve);
-    for (int k = 0; k < nmine; ++k)
-      if (!res[k].converged) {
-        stt.nonconverged++;
-        stt.worst_relres = std::max(stt.worst_relres, res[k].max_relres);
-      }
-    stt.shift_solves += nmine;
+    if (fail.empty()) {
+      for (int k = 0; k < nmine; ++k)
+        if (!res[k].converged) {
+          stt.nonconverged++;
+          stt.worst_relres = std::max(stt.worst_relres, res[k].max_relres);
+        }
+      stt.shift_solves += nmine;
+    }
     const double* ubase = usolve;
+    double words[2] = {fail.empty() ? 0.0 : 1.0, 0.0};
     if (shard) {
+      if (!fail.empty()) HIPCHK(hipMemsetAsync(c->xsend, 0, sizeof(double) * nm * per_rank, st));
+      if (words_fit) {
+        HIPCHK(hipMemcpyAsync(c->xsend + (size_t)nv * m, words, sizeof(words), hipMemcpyHostToDevice, st));
+      } else {
+        // no pressure rows to carry the words: a control message of their own
+        double any = words[0];
+        reduce_over_ranks(c, &any, 0, 1);
+        if (any != 0.0)
+          throw HipError{fail.empty() ? "another rank failed in its share of an ADI sweep" : fail};
+      }
       exchange(c, (size_t)per_rank * nm);
       ubase = c->xrecv;
     }
@@ -2317,7 +2380,8 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
                           hipMemcpyHostToDevice, st));
     // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
     static const bool fused_blocks = getenv("RICADI_SWEEP_UNFUSED") == nullptr;
-    if (fused_blocks && sweep_combine_ok(m, nslot, Gs)) {
+    const bool combined = fused_blocks && sweep_combine_ok(m, nslot, Gs);
+    if (combined) {
       // all blocks and their norms in two launches (K4s)
       c->sweep_part.ensure(sweep_combine_partial_len(nv, m, Gs));
       launch_sweep_combine(st, nv, m, nslot, Gs, ubase, nm, c->sweep_coef.p, c->Z.p, c->zld, c->zc,
@@ -2332,9 +2396,24 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     }
     hn.resize((size_t)Gs * m);
     HIPCHK(hipMemcpyAsync(hn.data(), c->nrm2.p, sizeof(double) * Gs * m, hipMemcpyDeviceToHost, st));
+    std::vector<double> rwords;
+    if (shard && words_fit) {
+      // the ranks' status words, one strided copy out of the gathered buffer
+      rwords.assign((size_t)2 * world, 0.0);
+      HIPCHK(hipMemcpy2DAsync(rwords.data(), sizeof(double) * 2, c->xrecv + (size_t)nv * m,
+                              sizeof(double) * nm * per_rank, sizeof(double) * 2, world, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));
-    for (int o = 0; o < Gs * m; o += RICADI_XCTL / 8)
-      values_of_rank0(c, hn.data() + o, std::min(RICADI_XCTL / 8, Gs * m - o));
+    for (int r = 0; r < (int)rwords.size() / 2; ++r)
+      if (rwords[(size_t)2 * r] != 0.0)
+        throw HipError{r == rank && !fail.empty() ? fail
+                                                  : "rank " + std::to_string(r) + " failed in its share of an ADI sweep"};
+    // The block norms steer the stopping decisions, which must not differ between the ranks.  The fused
+    // recombination sums in a fixed order (sweep_combine_kernel): every rank gets the same bits from the same
+    // gathered panels and decides alone.  The per-block fallback hands round rank 0's values.
+    if (!combined)
+      for (int o = 0; o < Gs * m; o += RICADI_XCTL / 8)
+        values_of_rank0(c, hn.data() + o, std::min(RICADI_XCTL / 8, Gs * m - o));
     // the reference's rule, block by block; blocks behind the stopping step are dropped
     int kept = Gs;
     bool stop = false;
@@ -2383,6 +2462,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     c->zc += kept * m;
     steps += kept;
     stt.steps = steps;
+    stt.sweeps = sw + 1;
     lap(c->t_recomb);
     static const bool dbg = getenv("RICADI_DEBUG_SWEEPS") != nullptr;
     if (prm.verbose || dbg) {
@@ -2418,11 +2498,12 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   stt.gmres_iters = c->total_iters - it0;
   if (shard) {
     // a rank has only seen its own solves
-    double v[3] = {(double)stt.gmres_iters, (double)stt.shift_solves, (double)stt.nonconverged};
-    sum_over_ranks(c, v, 3);
+    double v[4] = {(double)stt.gmres_iters, (double)stt.shift_solves, (double)stt.nonconverged, stt.worst_relres};
+    reduce_over_ranks(c, v, 3, 1);
     stt.gmres_iters = (long)(v[0] + 0.5);
     stt.shift_solves = (long)(v[1] + 0.5);
     stt.nonconverged = (long)(v[2] + 0.5);
+    stt.worst_relres = v[3];
   }
   DScalar::gram_norms(c, dW, c->nv, m, &stt.res_fro, nullptr);
   return true;
@@ -2895,7 +2976,7 @@ static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, 
 extern "C" {
 
 const char* ricadi_last_error(void) { return ricadi::g_err.c_str(); }
-int ricadi_version(void) { return 303; }
+int ricadi_version(void) { return 400; }
 int ricadi_sizeof_opts(void) { return (int)sizeof(ricadi_opts); }
 int ricadi_sizeof_adi_params(void) { return (int)sizeof(ricadi_adi_params); }
 // field types in declaration order (d = double, i = int); keep in step with include/ricadi.h
@@ -3336,20 +3417,30 @@ int ricadi_set_recycle(ricadi_ctx* c, int depth) {
   return RICADI_OK;
 }
 
+// the exchange state of a context back to "none" (a communicator the library created is destroyed)
+static void exchange_reset(ricadi_ctx* c) {
+  if (c->xcomm && c->xcomm_owned) (void)ncclCommDestroy(c->xcomm);
+  c->xcomm = nullptr;
+  c->xcomm_owned = false;
+  c->xforce = false;
+  c->xsend_own.release();
+  c->xrecv_own.release();
+  c->xrank = 0;
+  c->xworld = 1;
+  c->xfn = nullptr;
+  c->xuser = nullptr;
+  c->xsend = c->xrecv = nullptr;
+  c->xcap = 0;
+}
+
 int ricadi_set_exchange(ricadi_ctx* c, int rank, int world, ricadi_allgather_fn fn, void* user,
                         void* send_dev, void* recv_dev, int64_t send_capacity) {
   REQUIRE(c, RICADI_EINVAL, "NULL ctx");
-  if (world <= 1 || !fn) {
-    c->xrank = 0;
-    c->xworld = 1;
-    c->xfn = nullptr;
-    c->xuser = nullptr;
-    c->xsend = c->xrecv = nullptr;
-    c->xcap = 0;
-    return RICADI_OK;
-  }
+  API_BEGIN
+  exchange_reset(c);
+  if (world <= 1 || !fn) return RICADI_OK;
   REQUIRE(rank >= 0 && rank < world && world <= 64, RICADI_EINVAL, "bad rank / world size");
-  REQUIRE(send_dev && recv_dev && send_capacity >= 4096, RICADI_EINVAL, "exchange buffers missing or too small");
+  REQUIRE(send_dev && recv_dev && send_capacity >= 2 * RICADI_XCTL, RICADI_EINVAL, "exchange buffers missing or too small");
   c->xrank = rank;
   c->xworld = world;
   c->xfn = fn;
@@ -3357,6 +3448,64 @@ int ricadi_set_exchange(ricadi_ctx* c, int rank, int world, ricadi_allgather_fn 
   c->xsend = static_cast<double*>(send_dev);
   c->xrecv = static_cast<double*>(recv_dev);
   c->xcap = (size_t)send_capacity;
+  API_END
+}
+
+int ricadi_rccl_unique_id(void* id_out, int bytes) {
+  REQUIRE(id_out && bytes >= (int)sizeof(ncclUniqueId), RICADI_EINVAL, "id buffer of at least 128 bytes required");
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) {
+    ricadi::set_error(std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    return RICADI_EHIP;
+  }
+  std::memcpy(id_out, &id, sizeof(id));
+  return RICADI_OK;
+}
+
+int ricadi_set_exchange_rccl(ricadi_ctx* c, int rank, int world, const void* unique_id, void* comm,
+                             int64_t send_capacity) {
+  REQUIRE(c, RICADI_EINVAL, "NULL ctx");
+  REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, RICADI_EINVAL, "bad rank / world size");
+  const bool resize = !unique_id && !comm;      // keep the communicator, new buffer sizes
+  REQUIRE(!resize || (c->xcomm && c->xrank == rank && c->xworld == world), RICADI_EINVAL,
+          "a unique id (ricadi_rccl_unique_id) or a communicator is required");
+  REQUIRE(send_capacity >= 2 * RICADI_XCTL, RICADI_EINVAL, "send_capacity too small");
+  API_BEGIN
+  HIPCHK(hipSetDevice(c->dev));
+  if (resize) {
+    HIPCHK(hipStreamSynchronize(c->st));
+  } else if (comm) {
+    exchange_reset(c);
+    c->xcomm = static_cast<ncclComm_t>(comm);
+  } else {
+    exchange_reset(c);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&c->xcomm, world, id, rank);
+    if (r != ncclSuccess) {
+      c->xcomm = nullptr;
+      throw HipError{std::string("ncclCommInitRank: ") + ncclGetErrorString(r)};
+    }
+    c->xcomm_owned = true;
+  }
+  const size_t cap = ((size_t)send_capacity + 7) / 8;
+  c->xsend_own.alloc(cap);
+  c->xrecv_own.alloc(cap * world);
+  HIPCHK(hipMemsetAsync(c->xsend_own.p, 0, cap * sizeof(double), c->st));
+  HIPCHK(hipMemsetAsync(c->xrecv_own.p, 0, cap * world * sizeof(double), c->st));
+  c->xrank = rank;
+  c->xworld = world;
+  c->xforce = world == 1;
+  c->xsend = c->xsend_own.p;
+  c->xrecv = c->xrecv_own.p;
+  c->xcap = cap * sizeof(double);
+  API_END
+}
+
+int ricadi_exchange_count(ricadi_ctx* c, int64_t* count_out) {
+  REQUIRE(c && count_out, RICADI_EINVAL, "NULL argument");
+  *count_out = (int64_t)c->xcount;
   return RICADI_OK;
 }
 
@@ -3917,7 +4066,36 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   if (nout > 15) out[15] = c->kc > 0 && c->np > 0 ? (int)(c->synnz) : 0;
   // [16]: entries of the restriction (rows of P^T with smoothed aggregation; else one per dof)
   if (nout > 16) out[16] = c->kc > 0 ? (c->sa ? (int)c->pt_ci.n : c->n) : 0;
+  // [17]: route of the last batch of dense coarse inverses on the last level (0 block Gauss-Jordan, 1 rocSOLVER with
+  // partial pivoting; -1 none yet); [18]: kernel of the last saddle SpMM launch (0 CSR, 1 LDS-tiled per
+  // group, 2 LDS-tiled multi-shift, +4: FP32 x input; -1 none yet)
+  if (nout > 17) out[17] = lc->coarse_route;
+  if (nout > 18) out[18] = c->k1_variant;
   return RICADI_OK;
+}
+
+int ricadi_dense_inverse_batch(ricadi_ctx* c, int k, int nb, double* A, int* route_out) {
+  REQUIRE(c && A && k >= 1 && nb >= 1 && nb <= 4 * RICADI_MAX_GROUPS, RICADI_EINVAL, "bad argument");
+  API_BEGIN
+  hipStream_t st = c->st;
+  const size_t kk = (size_t)k * k;
+  DArr<double> dA, dA0;
+  dA.alloc(kk * nb);
+  dA0.alloc(kk * nb);
+  HIPCHK(hipMemcpyAsync(dA.p, A, sizeof(double) * kk * nb, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(dA0.p, dA.p, sizeof(double) * kk * nb, hipMemcpyDeviceToDevice, st));
+  std::vector<double*> hp(nb);
+  for (int i = 0; i < nb; ++i) hp[i] = dA.p + kk * i;
+  std::vector<int> info(nb, 0);
+  const int route = invert_dense_batch(c, hp, k, info, [&] {
+    HIPCHK(hipMemcpyAsync(dA.p, dA0.p, sizeof(double) * kk * nb, hipMemcpyDeviceToDevice, st));
+  });
+  if (route_out) *route_out = route;
+  for (int i = 0; i < nb; ++i)
+    if (info[i] != 0) throw HipError{"matrix " + std::to_string(i) + " singular (getrf/getri info " + std::to_string(info[i]) + ")"};
+  HIPCHK(hipMemcpyAsync(A, dA.p, sizeof(double) * kk * nb, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  API_END
 }
 
 int ricadi_time_qr_dev(ricadi_ctx* c, const double* dZ, int cz, int reps, double* ms_per_call) {
@@ -4046,7 +4224,7 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
     p2.compress_cols = cc;
   }
   double upd = 0, updrel = 0;
-  long adi_total = 0, gm_total = 0, sol_total = 0, nonconv = 0;
+  long adi_total = 0, gm_total = 0, sol_total = 0, nonconv = 0, sweep_total = 0;
   const long esc0 = c->escalations;
   double worst = 0.0, last_res = 0.0, last_rhs = 0.0;
   int steps = 0;
@@ -4086,6 +4264,7 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
     adi_total += s.steps;
     gm_total += s.gmres_iters;
     sol_total += s.shift_solves;
+    sweep_total += s.sweeps;
     nonconv += s.nonconverged;
     worst = std::max(worst, s.worst_relres);
     // compressed copy of the new iterate (truncation at the Gram noise floor)
@@ -4135,7 +4314,7 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
     stats_out[8] = last_res;
     stats_out[9] = last_rhs;
     stats_out[10] = (double)(c->escalations - esc0);
-    stats_out[11] = 0.0;
+    stats_out[11] = (double)sweep_total;
   }
 }
 

@@ -101,18 +101,15 @@ _orient_memo = {}
 
 
 def _content_sig(m):
-    """Cheap content signature of a scipy sparse matrix as handed over (no format conversion)."""
-    d = m.data
-    idx = getattr(m, "indices", None)
-    return (type(m).__name__, m.shape, int(m.nnz), float(d.sum()) if d.size else 0.0,
-            float(np.abs(d).sum()) if d.size else 0.0,
-            int(idx[::97].sum()) if idx is not None and idx.size else 0)
+    """Exact content key of a scipy sparse matrix as handed over (no format conversion): see backend.content_hash."""
+    return backend.content_hash(m)
 
 
 def _orient(amat, mmat, transposed):
     """(cal A, cal E) in CSR.  The reference re-passes the same matrices with every call
     (``optcont_main.py:488-492``): the conversion (two CSR transposes, ~5 ms at n = 3e4) is remembered for the last
-    operands -- keyed by object identity AND a content signature, so an operand changed in place is converted anew."""
+    operands -- keyed by object identity AND the exact content key (128-bit hash of the index and value bytes), so an
+    operand changed in place is converted anew, whatever its sums."""
     key = (id(amat), id(mmat), bool(transposed))
     if sps.issparse(amat) and sps.issparse(mmat):
         sig = (_content_sig(amat), _content_sig(mmat))

@@ -262,9 +262,26 @@ def item_layout(G, parts, world, owners=None):
     return items, per_rank
 
 
-def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
-                            group=None, width=None, max_width=8, verbose=False, col_parts=0,
-                            stop_rule="step"):
+def lyap_adi_shift_parallel(ops, ms, W, **kw):
+    """Shift-parallel LR-ADI (:func:`_lyap_adi_sweeps`, which documents the arguments) with the library's recycled
+    initial guesses switched on for the sweeps of this call: they solve nearly the same right-hand-side space
+    again and again, so every batched solve starts from the least-squares combination of its last solved panels
+    (``ricadi_set_recycle``, depth 3 or the caller's own if deeper; the C++ drivers do the same for their sweeps).
+    The contexts' depths are restored on the way out, also by an exception."""
+    ctxs = [cx for cx in getattr(ops, "ctxs", [getattr(ops, "ctx", None)]) if hasattr(cx, "set_recycle")]
+    prev = [int(getattr(cx, "recycle_depth", 0)) for cx in ctxs]
+    try:
+        for cx, d in zip(ctxs, prev):
+            cx.set_recycle(max(3, d))
+        return _lyap_adi_sweeps(ops, ms, W, **kw)
+    finally:
+        for cx, d in zip(ctxs, prev):
+            cx.set_recycle(d)
+
+
+def _lyap_adi_sweeps(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
+                     group=None, width=None, max_width=8, verbose=False, col_parts=0,
+                     stop_rule="step"):
     """Shift-parallel LR-ADI; returns ``(Z_blocks, info)``.
 
     ``W`` is the (already projected) NV x m residual factor as a tensor on the
@@ -327,18 +344,6 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             buffers[key] = (items, per_rank, U_loc, U_all)
         return buffers[key]
 
-    # the sweeps of one call solve nearly the same right-hand-side space again and again: let the library
-    # start every batched solve from the least-squares combination of its last solved panels
-    # (ricadi_set_recycle; the C++ drivers do the same for their own sweeps)
-    ctxs = [cx for cx in getattr(ops, "ctxs", [getattr(ops, "ctx", None)]) if hasattr(cx, "set_recycle")]
-
-    def recycle(depth):
-        for cx in ctxs:
-            cx.set_recycle(depth)
-    if not ctxs:
-        recycle = None
-    if recycle is not None:
-        recycle(3)
     step_rule = stop_rule == "step" and adi_newZ_reltol > 0.0
     rel_h1, rel_h2 = np.zeros(ns), np.zeros(ns)
     blocks = []
@@ -444,8 +449,6 @@ def lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=200, adi_newZ_reltol=1e-8,
             print("sweep {0:3d}: {1} shifts, kept {2}, rel new Z {3:9.3e}".format(nsweeps, g_now, kept, rel))
         if stop:
             break
-    if recycle is not None:
-        recycle(0)
     Wend = Wq[0] if parts == 1 else torch.cat(Wq, dim=1).contiguous()
     info = dict(adi_steps=steps, sweeps=nsweeps, width=G, col_parts=parts, adi_rel_newZ=rel, owners=fixed,
                 res_fro=ops.gram_fro(Wend), resfac=Wend,

@@ -97,6 +97,58 @@ def test_dropin_package_names():
     assert np.allclose(lau.apply_invsqrt_fromright(Ms, np.eye(2)), np.diag([0.5, 1 / 3.0]))
 
 
+def test_mirror_glue_functions_against_scipy():
+    """The MIRROR's mm_dnssps / app_luinv_to_spmat (host glue of the drop-in, not the oracle's copies):
+    `lau.mm_dnssps` for every mix of dense / sparse factors (optcont_main.py:232-236) and `lau.app_luinv_to_spmat`
+    with a SuperLU `factorized` handle applied to a sparse J^T, as the reference's test builds its projector
+    (tests/test_units_compfacres_compress.py:70-71)."""
+    import scipy.sparse.linalg as spsla
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    import optconpy_amd.lin_alg_utils as glau
+    assert lau.mm_dnssps is glau.mm_dnssps and lau.app_luinv_to_spmat is glau.app_luinv_to_spmat
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((6, 4))
+    Bs = sps.random(4, 5, density=0.5, random_state=1, format="csc")
+    As = sps.csr_matrix(A * (np.abs(A) > 0.5))
+    for X, Y in ((A, Bs.toarray()), (As, Bs), (A, Bs), (As, Bs.toarray())):
+        Z = lau.mm_dnssps(X, Y)
+        assert isinstance(Z, np.ndarray) and not sps.issparse(Z)
+        Xd = X.toarray() if sps.issparse(X) else X
+        Yd = Y.toarray() if sps.issparse(Y) else Y
+        assert np.allclose(Z, Xd @ Yd, rtol=1e-14, atol=1e-14)
+    M = (sps.random(9, 9, density=0.3, random_state=2) + 5.0 * sps.eye(9)).tocsc()
+    J = sps.random(3, 9, density=0.5, random_state=3, format="csr")
+    Mlu = spsla.factorized(M)
+    MinvJt = lau.app_luinv_to_spmat(Mlu, J.T)
+    assert MinvJt.shape == (9, 3) and isinstance(MinvJt, np.ndarray)
+    assert np.allclose(M @ MinvJt, J.T.toarray(), atol=1e-12)
+    assert np.allclose(lau.app_luinv_to_spmat(Mlu, J.T.toarray()), MinvJt)         # dense input as well
+
+
+def test_operator_cache_key_is_exact():
+    """The resident operator / the remembered CSR conversion are reused only for IDENTICAL matrices: the key is a
+    128-bit hash of the index and value bytes (backend.content_hash), not sums -- an in-place edit that
+    preserves every sum (two values swapped, a sign-symmetric change) is seen."""
+    from optconpy_amd import backend, proj_ric_utils as gpru
+    A = sps.random(40, 40, density=0.2, random_state=7, format="csr") + sps.eye(40, format="csr")
+    M = sps.eye(40, format="csr") * 2.0
+    k0 = backend._fingerprint(A)
+    assert backend._fingerprint(A.copy()) == k0 and backend._fingerprint(A.tocsc()) == k0
+    a1, e1 = gpru._orient(A, M, False)
+    a2, e2 = gpru._orient(A, M, False)
+    assert a2 is a1 and e2 is e1                                    # remembered for the same operands
+    i, j = 3, 11
+    A.data[i], A.data[j] = A.data[j], A.data[i]                     # sum, |sum|, nnz, indices all unchanged
+    assert A.data[i] != A.data[j]
+    assert backend._fingerprint(A) != k0
+    a3, e3 = gpru._orient(A, M, False)
+    assert a3 is not a1
+    assert np.allclose(a3.toarray(), A.T.toarray())
+    B = A.copy()
+    B.indices[[0, 1]] = B.indices[[1, 0]]                           # same multiset of column indices per row
+    assert backend._fingerprint(B) != backend._fingerprint(A)
+
+
 def test_struct_layout_matches_header(tmp_path):
     """sizeof / offsetof of the two structs that cross the C-ABI, three ways: a C probe
     compiled from include/ricadi.h, the library's own ricadi_sizeof_*(), and the ctypes

@@ -1,0 +1,215 @@
+"""GPU tests of round 4: wide panels as sixteen-column groups, the RCCL transport of the sharded sweeps
+(one-rank communicator), one collective per sweep, the failure word of a rank, the pivoted route of the
+coarse inverses, the steady-state Riccati run at the cylinder-wake surrogate's size (cfg3 fixture).
+
+All of them go through the C-ABI (``optconpy_amd._lib`` / the drop-in) and compare with the oracle (CPU
+restatement), its committed fixtures, or identities recomputed on the host.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from optconpy_amd import _lib, backend, problems as pb
+from oracle import lin_alg_utils as olau
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+# ------------------------------------------------------------------ wide panels (solve_dae_ric.py:149)
+def test_wide_panel_column_groups_against_sparse_lu(cfg1):
+    """An n x 66 panel (comprz_maxc + NY' + NU columns, solve_dae_ric.py:149) against three shifts in one
+    batched call: solved as sixteen-column groups of the same shift, 3 x 5 groups in one lockstep batch, the
+    last group ragged (2 of 16 columns, one of them zero).  Every column meets the tolerance, the solutions
+    equal the sparse LU's (SuperLU, the reference's technology), a zero right-hand side column stays zero."""
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    MT = pr.M.T.tocsr()
+    rng = np.random.default_rng(66)
+    R = rng.standard_normal((pr.NV, 66))
+    R[:, 65] = 0.0                                   # a zero column inside the ragged last group
+    ps = [-2.0, -30.0, -400.0]
+    with _lib.Context(0) as ctx:
+        ctx.set_operator(calA, MT, pr.J)
+        import torch
+        Rd = torch.from_numpy(R).cuda()
+        Xd = torch.empty((len(ps), pr.NV + pr.NP, 66), dtype=torch.float64, device="cuda")
+        its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), Rd.data_ptr(), 0, 66, Xd.data_ptr())
+        ctx.synchronize()
+        X = Xd.cpu().numpy()
+    assert np.asarray(rr).max() <= 1e-10
+    for g, p in enumerate(ps):
+        lu = olau.SaddleLU(calA + p * MT, pr.J)
+        ref = lu.solve(R)
+        assert rel(X[g][:pr.NV], ref[:pr.NV]) < 1e-8
+        assert np.abs(X[g][:, 65]).max() == 0.0
+
+
+# ------------------------------------------------------------------ coarse inverses: the pivoted route
+def _needs_pivoting(k, seed, eps):
+    """Well-conditioned k x k matrix whose leading 128 x 128 block (the first diagonal block of the blocked
+    Gauss-Jordan elimination) has one singular value of `eps` times its scale (0: exactly singular)."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((k, k)) / np.sqrt(k) + 2.0 * np.eye(k)
+    Q, _ = np.linalg.qr(rng.standard_normal((128, 128)))
+    sv = np.ones(128)
+    sv[-1] = eps
+    A[:128, :128] = (Q * sv) @ Q.T
+    return A
+
+
+def test_near_singular_coarse_block_takes_the_pivoted_route(cfg1):
+    """ADVICE round 2 / VERDICT round 3: the unpivoted block Gauss-Jordan inverse of the coarse matrices judges
+    its pivots RELATIVE to the scale of the diagonal block.  Matrices whose first diagonal block is singular to
+    1e-14 of its scale (and exactly singular), inside an otherwise well-conditioned matrix, must come back
+    inverted through the pivoted rocSOLVER route -- for the whole batch, the healthy matrix included -- and a
+    healthy batch must stay on route 0.  (ricadi_dense_inverse_batch is the setup's own routine.)"""
+    k = 300
+    good = _needs_pivoting(k, 1, 1.0)
+    with _lib.Context(0) as ctx:
+        inv, route = ctx.dense_inverse_batch(np.stack([good, good.T]))
+        assert route == 0
+        for a, b in zip((good, good.T), inv):
+            assert np.linalg.norm(a @ b - np.eye(k)) < 1e-10
+        for eps in (1e-14, 0.0):
+            bad = _needs_pivoting(k, 2, eps)
+            assert np.linalg.cond(bad) < 1e4
+            inv, route = ctx.dense_inverse_batch(np.stack([good, bad]))
+            assert route == 1, "a vanishing pivot must send the batch through the pivoted route"
+            assert np.linalg.norm(good @ inv[0] - np.eye(k)) < 1e-10
+            assert np.linalg.norm(bad @ inv[1] - np.eye(k)) < 1e-9
+        # the production operators stay on the unpivoted route, and the setup says so
+        pr, tb, trct, ms = cfg1
+        ctx.set_operator((-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr(), pr.J)
+        R = np.random.default_rng(3).standard_normal((pr.NV, 4))
+        X, its, rr = ctx.shift_solve(-3.0, 1.0, R)
+        assert rr.max() <= 1e-10
+        assert ctx.setup_info()["coarse_route"] == 0
+
+
+# ------------------------------------------------------------------ RCCL transport, one collective per sweep
+def _newton(ctx, cfg1):
+    pr, tb, trct, ms = cfg1
+    tbd = tb.toarray() if hasattr(tb, "toarray") else tb
+    prm = _lib.adi_params(dict(pb.default_nwtn_adi_dict(), sweep_width=8))
+    Z, info = ctx.ric_newtonadi(ms, tbd, trct, prm)
+    return -ctx.gain(tbd), info
+
+
+def test_rccl_one_rank_communicator_one_collective_per_sweep(cfg1):
+    """ricadi_set_exchange_rccl with a communicator of ONE rank (ncclGetUniqueId / ncclCommInitRank inside the
+    library): the sweeps of the Newton-ADI then run the sharded path -- solutions into the send buffer,
+    ncclAllGather on the context's stream, recombination out of the receive buffer, status words -- and give
+    the gain of the plain path.  Collectives issued: ONE per sweep, plus per Newton step one for the ADI
+    statistics and one for the update-norm decision."""
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    with _lib.Context(0) as ctx:
+        ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+        K0, info0 = _newton(ctx, cfg1)
+        assert info0["adi_sweeps"] > 0 and ctx.exchange_count() == 0
+        ident = C.create_string_buffer(128)
+        assert ctx._lib.ricadi_rccl_unique_id(ident, 128) == 0
+        cap = 8 * ctx.n * 16 * 8 + 4096 * 2
+        _lib._chk(ctx._lib.ricadi_set_exchange_rccl(ctx._h, 0, 1, ident, None, cap))
+        ctx.clear_cache()
+        K1, info1 = _newton(ctx, cfg1)
+        assert info1["nwtn_steps"] == info0["nwtn_steps"] and info1["adi_steps"] == info0["adi_steps"]
+        assert info1["shift_solves"] == info0["shift_solves"]
+        assert rel(K1, K0) < 1e-9
+        assert ctx.exchange_count() == info1["adi_sweeps"] + 2 * info1["nwtn_steps"]
+        # a buffer too small for a sweep's panels is an error, not a fault
+        _lib._chk(ctx._lib.ricadi_set_exchange_rccl(ctx._h, 0, 1, None, None, 2 * 4096 + 64))
+        with pytest.raises(RuntimeError, match="exchange buffer too small"):
+            _newton(ctx, cfg1)
+        _lib._chk(ctx._lib.ricadi_set_exchange(ctx._h, 0, 1, None, None, None, None, 0))
+        K2, info2 = _newton(ctx, cfg1)
+        assert rel(K2, K0) < 1e-9
+
+
+def test_failure_of_one_rank_goes_round_with_the_panels(cfg1, monkeypatch):
+    """a rank that fails in its OWN share of a sweep (setup of its shifts, its solves) must not
+    leave the others waiting in the all-gather.  The failing rank still takes part in the sweep's collective --
+    zero panels, status word set in the pressure rows of its first panel -- and every rank raises after it.
+    Here on a one-rank RCCL communicator: the injected failure of sweep 1 surfaces as an error AFTER the
+    collective of that sweep was issued (2 collectives: sweeps 0 and 1), and the context stays usable."""
+    pr, tb, trct, ms = cfg1
+    F = (-pr.A - pr.Nc).tocsr()
+    with _lib.Context(0) as ctx:
+        ctx.set_operator(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+        ident = C.create_string_buffer(128)
+        assert ctx._lib.ricadi_rccl_unique_id(ident, 128) == 0
+        _lib._chk(ctx._lib.ricadi_set_exchange_rccl(ctx._h, 0, 1, ident, None, 8 * ctx.n * 16 * 8 + 8192))
+        monkeypatch.setenv("RICADI_INJECT_SWEEP_FAILURE", "1")
+        c0 = ctx.exchange_count()
+        with pytest.raises(RuntimeError, match="injected failure in sweep 1"):
+            _newton(ctx, cfg1)
+        assert ctx.exchange_count() - c0 == 2
+        monkeypatch.delenv("RICADI_INJECT_SWEEP_FAILURE")
+        ctx.clear_cache()
+        K1, info1 = _newton(ctx, cfg1)
+        assert info1["gmres_nonconverged"] == 0 and np.isfinite(K1).all()
+
+
+# ------------------------------------------------------------------ cfg3: steady-state Riccati at n = 5e4
+def _cfg3_fixture():
+    path = os.path.join(ROOT, "tests", "golden", "cfg3_golden.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/cfg3_golden.npz not generated (tests/golden/make_golden.py --cfg3)")
+    return np.load(path)
+
+
+def test_cfg3_newton_adi_gain_vs_oracle_fixture():
+    """BASELINE cfg3 as what it is -- the steady-state Riccati run of cyl_wake_cont.py:34-50 through
+    optcont_main.py:488-506 -- on the surrogate of SURVEY.md 8d (N = 75, n = 50 177, nu = 0.15/40, 32 shifts):
+    Newton-ADI to convergence through the drop-in with the three-level preconditioner, K against the oracle's
+    fixture at the 1e-6 bar, Newton steps equal; then the continuation of optcont_main.py:471-486: started from
+    the iterate of a run at twice the viscosity (z0), the iteration ends in the same K."""
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    g = _cfg3_fixture()
+    N, nu, alphau, NU, NY, ns, pmin, pmax = g["cfg"]
+    backend.reset()
+    try:
+        def inputs(nu_):
+            pr = pb.ricc_problem(int(N), float(nu_), NU=int(NU), NY=int(NY), alphau=float(alphau))
+            mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
+            tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
+            trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
+            return pr, tb, trct
+        pr, tb, trct = inputs(nu)
+        chk = np.array([pr.M.data.sum(), pr.A.data.sum(), abs(pr.J.data).sum(), abs(pr.Nc.data).sum(),
+                        pr.M.nnz, pr.A.nnz, pr.J.nnz, pr.Nc.nnz])
+        assert np.allclose(chk, g["mat_checks"], rtol=1e-12)          # identical FEM matrices
+        ms = pb.logshifts(float(pmin), float(pmax), int(ns))
+        assert np.allclose(ms, g["shifts"])
+        d = dict(pb.default_nwtn_adi_dict(), ms=ms)
+        F = (-pr.A - pr.Nc).tocsr()
+        out = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, nwtn_adi_dict=d)
+        K = -pru.get_mTzzTtb(pr.M.T, out["zfac"], tb)
+        info = backend.context().setup_info()
+        assert info["levels"] == 3, info
+        assert out["gmres_nonconverged"] == 0
+        assert out["nwtn_steps"] == int(g["nwtn_steps"][0])
+        err = rel(K, g["K_ric"])
+        print("cfg3: K vs oracle fixture %.2e, Newton steps %d, ADI steps %d, %d shift-solves, %.1f GMRES its each"
+              % (err, out["nwtn_steps"], out["adi_steps"], out["shift_solves"],
+                 out["gmres_iters"] / max(out["shift_solves"], 1)))
+        assert err < 1e-6
+        # continuation in Re (optcont_main.py:471-486, cyl_wake_cont.py:37-45)
+        pr2, tb2, trct2 = inputs(2.0 * float(nu))
+        F2 = (-pr2.A - pr2.Nc).tocsr()
+        low = pru.proj_alg_ric_newtonadi(mmat=pr2.M, amat=F2, jmat=pr2.J, bmat=tb2, wmat=trct2, nwtn_adi_dict=d)
+        z0 = pru.compress_Zsvd(low["zfac"], thresh=1e-8, k=400)
+        out2 = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=z0, nwtn_adi_dict=d)
+        K2 = -pru.get_mTzzTtb(pr.M.T, out2["zfac"], tb)
+        print("cfg3 from z0 (nu x 2): K vs fixture %.2e, Newton steps %d" % (rel(K2, g["K_ric"]), out2["nwtn_steps"]))
+        assert rel(K2, g["K_ric"]) < 1e-6
+    finally:
+        backend.reset()

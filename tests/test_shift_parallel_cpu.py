@@ -161,6 +161,32 @@ def test_rejects_repeated_shift_in_sweep():
         lyap_adi_shift_parallel(ops, [-1.0, -2.0], torch.from_numpy(W.copy()), width=3)
 
 
+def test_recycle_depth_restored_also_by_an_exception():
+    """the sweep driver raises the contexts' recycling depth for its own sweeps (at least 3, or the
+    caller's own if deeper) and restores what the caller had set -- also when the call ends in an exception."""
+    pr, F, W, tb = _problem(4)
+
+    class Cx:
+        def __init__(self, d):
+            self.recycle_depth, self.seen = d, []
+
+        def set_recycle(self, d):
+            self.seen.append(d)
+            self.recycle_depth = d
+
+    class Ops(OracleOps):
+        pass
+    for user_depth, during in ((0, 3), (5, 5)):
+        ops = Ops(F.T.tocsr(), pr.M.T.tocsr(), pr.J)
+        ops.ctx = Cx(user_depth)
+        ops.ctxs = [ops.ctx]
+        with pytest.raises(ValueError):
+            lyap_adi_shift_parallel(ops, [-1.0, -2.0], torch.from_numpy(W.copy()), width=3)
+        assert ops.ctx.seen == [during, user_depth] and ops.ctx.recycle_depth == user_depth
+        lyap_adi_shift_parallel(ops, [-1.0, -2.0, -4.0], torch.from_numpy(W.copy()), width=3, adi_max_steps=3)
+        assert ops.ctx.seen[-2:] == [during, user_depth]
+
+
 def test_sweep_width_shrinks_when_cauchy_matrix_is_singular():
     """A shift cycle with a repeated shift cannot be swept 4 wide (singular Cauchy matrix):
     the width is halved until every sweep is admissible, the result is the sequential one."""
