@@ -74,15 +74,16 @@ def build_inputs(N, nu, nshifts, pmax=3e3):
 
 
 def oracle_gain(N, nu, nshifts):
-    """K of the CPU oracle for this workload from the committed fixture (cfg2 only)."""
-    path = os.path.join(ROOT, "tests", "golden", "cfg2_golden.npz")
-    if not os.path.exists(path):
-        return None
-    g = np.load(path)
-    cfg = g["cfg"]
-    if int(cfg[0]) != N or abs(cfg[1] - nu) > 1e-15 or int(cfg[5]) != nshifts:
-        return None
-    return g["K_ric"]
+    """K of the CPU oracle for this workload from the committed fixtures (cfg2: N = 58; cfg3: N = 75)."""
+    for name in ("cfg2_golden.npz", "cfg3_golden.npz"):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        cfg = g["cfg"]
+        if int(cfg[0]) == N and abs(cfg[1] - nu) <= 1e-15 and int(cfg[5]) == nshifts:
+            return g["K_ric"]
+    return None
 
 
 def trials(fn, ntrial=5):
@@ -92,7 +93,7 @@ def trials(fn, ntrial=5):
 
 
 def traffic_entry(key):
-    for name in ("r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
+    for name in ("r04_spmm_traffic.json", "r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 e = json.load(f).get(key)
@@ -120,27 +121,35 @@ def spmm_roofline(ctx, nnz_k, nnz_j, n, m, shifts, reps=200):
     al, be = [float(p) for p in shifts], [1.0] * G
     ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
     med, best = trials(lambda: ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), reps))
+    variant = ctx.setup_info().get("k1_variant", -1)          # kernel of the batched launch (the library's own record)
     med1, best1 = trials(lambda: ctx.time_spmm_dev(al[0], 1.0, x.data_ptr(), m, y.data_ptr(), reps))
     unit = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
     nbytes = unit * G
     b_batch = nnz_k * 20.0 + 2.0 * nnz_j * 12.0 + 4.0 * (n + 1) + 16.0 * n * m * G
     gbs = nbytes / (med * 1e-3) / 1e9
     traffic, tsrc = traffic_entry("%dx%dx%d" % (G, n, m))
-    # which kernel served the launch (ricadi_solver.hip: ms_pays): the multi-shift kernel reads ONE value set
-    # for all groups -- its honest byte model is the batched form, and `frac` follows the kernel that ran
-    ms = G >= 4 and nnz_s * 10.0 * G > 200e6 and not os.environ.get("RICADI_MS_SPMM") == "0"
-    model = b_batch if ms else nbytes
+    # which kernel served the launch: the library says (ricadi_setup_info slot 18), nothing is guessed here
+    ms = (variant & 3) == 2
+    kname = {0: "ricadi::spmm_kernel_v2 (CSR)", 1: "ricadi::spmm_blocked_kernel", 2: "ricadi::spmm_blocked_ms_kernel"}.get(
+        variant & 3, "unknown")
+    # `frac`: the launch serves G shifts of ONE pattern, so the bytes that HAVE to move are the batched form's
+    # (matrix once for all shifts) whatever the kernel streams; a single-shift launch is the per-panel
+    # form.  The per-panel reading of the same launch (each shift's assembled value array counted) is kept beside it.
+    model = b_batch if G > 1 else nbytes
     gbs_model = model / (med * 1e-3) / 1e9
     return dict(bound="hbm", achieved=round(gbs_model, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(gbs_model / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
-                byte_model="batched form (one value set for all groups)" if ms else "per panel (G x B_spmm)",
+                byte_model=("batched form: K and M values + pattern once for all %d shifts of the launch, panels in/out "
+                            "per shift" % G) if G > 1 else "per panel (B_spmm)",
                 frac_per_panel_model=round(gbs / HBM_PEAK_GBS, 4),
-                kernel="ricadi::spmm_blocked_ms_kernel" if ms else "ricadi::spmm_blocked_kernel",
+                kernel=kname, kernel_reads=("one value set for all groups (18 B per non-zero)" if ms else
+                                            "one assembled value array per group (10 B per non-zero and group)"),
                 us_per_launch=round(med * 1e3, 2),
                 us_per_launch_best=round(best * 1e3, 2),
                 frac_best=round(model / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                units_per_launch=G, algorithmic_bytes=int(nbytes),
+                units_per_launch=G, algorithmic_bytes=int(model),
                 algorithmic_bytes_per_unit=int(unit),
+                algorithmic_bytes_per_panel_model=int(nbytes),
                 algorithmic_bytes_batched_form=int(b_batch),
                 frac_batched_form=round(b_batch / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 traffic_over_batched_form=(round(traffic / b_batch, 3) if traffic else None),
@@ -304,6 +313,35 @@ def _cpu_shift_worker(args):
     return t_lu, time.perf_counter() - t0
 
 
+def cpu_baseline_sample(calA, M, J, ms, m, units, npick=2, label="", n_lu=None):
+    """Bounded single-core sample of the oracle (scipy SuperLU, the reference's technology) for the larger
+    workloads: `npick` of the sparse LUs and one panel solve on each, LU and solve time reported separately
+    (the reference amortises one LU per shift over the ADI cycles), priced up to the line's step of
+    `units` shift-solves over len(ms) shifts."""
+    from oracle import lin_alg_utils as olau
+    R = np.random.default_rng(0).standard_normal((M.shape[0], m))
+    ns = len(ms)
+    pick = [ms[(k * (ns - 1)) // max(npick - 1, 1)] for k in range(npick)] if npick > 1 else [ms[ns // 2]]
+    t_lu = t_sol = 0.0
+    for p in pick:
+        t0 = time.perf_counter()
+        lu = olau.SaddleLU(calA + p * M, J)
+        t_lu += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        lu.solve(R)
+        t_sol += time.perf_counter() - t0
+        del lu
+    lu_s, sol_s = t_lu / len(pick), t_sol / len(pick)
+    n_lu = ns if n_lu is None else n_lu
+    step_time = n_lu * lu_s + units * sol_s
+    return dict(value=round(units / step_time, 3), unit="shift-solves/s", cores=1, kind="port",
+                sample="%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) of the %s saddle matrices "
+                       "(n = %d), scipy SuperLU single-threaded; priced up to one step = %d LUs + %d shift-solves "
+                       "(%.0f s)" % (len(pick), lu_s, len(pick), m, sol_s, label, M.shape[0] + J.shape[0], n_lu, units,
+                                     step_time),
+                lu_seconds=round(lu_s, 3), solve_seconds=round(sol_s, 4), step_seconds=round(step_time, 2))
+
+
 def cpu_baseline(pr, ms, m, adi_steps, full=False):
     """Oracle (scipy SuperLU -- the reference's technology) on the host cores, same matrices.
     One step = len(ms) sparse LUs + adi_steps shift-solves (the reference amortises one LU per
@@ -375,9 +413,13 @@ def cpu_baseline(pr, ms, m, adi_steps, full=False):
 
 # BASELINE.json configs 3-5: fixed-work units for runs at their sizes.  One step =
 # ONE pass over the whole shift list of the open-loop projected Lyapunov ADI (s shift-solves with
-# an NV x m panel each, sweeps of 16 shifts, Cauchy recombination and residual hand-off included).
+# an NV x m panel each, sweeps of 16 shifts, Cauchy recombination and residual hand-off included),
+# through the boundary call pru.solve_proj_lyap_stein (tests/test_units_compfacres_compress.py:62-64).
+# `--workload cfg3` itself is the steady-state Riccati run of cyl_wake_cont.py:34-50 (the Newton step to K
+# of the default workload at N = 75, 32 shifts); `cfg3-cycle` is the open-loop pass at that size.
+CFG3 = dict(N=75, nu=0.15 / 40.0, shifts=32)
 WORKLOADS = {
-    "cfg3": dict(N=75, nu=0.15 / 40.0, shifts=32, m=16, dre=False, pmin=1.0, pmax=3e3,
+    "cfg3-cycle": dict(N=75, nu=0.15 / 40.0, shifts=32, m=16, dre=False, pmin=1.0, pmax=3e3,
                  note="cylinder-wake surrogate, n = 50 177, 32 shifts (BASELINE: 4 GPUs)"),
     "cfg4": dict(N=106, nu=0.15 / 60.0, shifts=64, m=66, dre=True, pmin=0.5, pmax=2e3,
                  note="n = 100 490, time-varying DRE operator -(M^T/2 + tau (A+N)^T) at the largest step "
@@ -396,13 +438,17 @@ def _xopts():
     return xopts
 
 
-def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_fn):
-    """Times `steps` shift cycles of a WORKLOADS entry with the shift-parallel sweep driver (one
-    process per GPU; at world size 1 the same code on one GPU).  Returns the result dict (rank 0)."""
+def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_fn, python_driver=False,
+                   with_cpu_baseline=True):
+    """Times `steps` passes over the shift list of a WORKLOADS entry.  Default: through the boundary call
+    pru.solve_proj_lyap_stein (C++ sweep driver; under torch.distributed the library shards the sweeps by shift
+    over the ranks, RCCL all-gather on its stream) -- the same call at every rank count.  `python_driver`:
+    the Python sweep driver (shift_parallel.py; supports column parts).  Returns the result dict (rank 0)."""
     import torch
     import torch.distributed as dist
-    from optconpy_amd import _lib, problems as pb
+    from optconpy_amd import _lib, backend, problems as pb
     from optconpy_amd.shift_parallel import HipOps, lyap_adi_shift_parallel, plan_items
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
     w = WORKLOADS[name]
     pr = pb.ricc_problem(w["N"], w["nu"])
     MT = pr.M.T.tocsr()
@@ -412,24 +458,42 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
     else:
         calA = (-pr.A - pr.Nc).T.tocsr()
     ms = pb.logshifts(w["pmin"], w["pmax"], w["shifts"])
-    ctx = _lib.Context(local, **_xopts())
-    ctx.set_operator(calA, MT, pr.J)
-    ops = HipOps(ctx)
+    xo = _xopts()
+    if xo:
+        backend.configure(**xo)
+    ctx = backend.context_for(calA, MT, pr.J) if not python_driver else _lib.Context(local, **xo)
+    if python_driver:
+        ctx.set_operator(calA, MT, pr.J)
     # right-hand-side factor: seeded random panel, Leray-projected on the device
     R = np.random.default_rng(1234).standard_normal((pr.NV, w["m"]))
     X, _, _ = ctx.shift_solve(1.0, 0.0, R)
-    W = ops.to_panel(MT @ X[:pr.NV])
+    Wh = np.ascontiguousarray(MT @ X[:pr.NV])
     n = pr.NV + pr.NP
     G = min(16, len(ms))
     parts = plan_items(G, world, col_split)
+    if python_driver:
+        ops = HipOps(ctx)
+        W = ops.to_panel(Wh)
 
-    def step():
-        ops.clear_cache()
-        ops.gmres_iters = ops.shift_solves = ops.nonconverged = 0
-        ops.worst_relres = 0.0
-        blocks, info = lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=len(ms), adi_newZ_reltol=0.0,
-                                               width=G, col_parts=parts)
-        return info
+        def step():
+            ops.clear_cache()
+            ops.gmres_iters = ops.shift_solves = ops.nonconverged = 0
+            ops.worst_relres = 0.0
+            blocks, info = lyap_adi_shift_parallel(ops, ms, W, adi_max_steps=len(ms), adi_newZ_reltol=0.0,
+                                                   width=G, col_parts=parts)
+            info["gmres_iters"] = ops.gmres_iters
+            info["shift_solves"] = ops.shift_solves
+            return info
+    else:
+        dd = dict(pb.default_nwtn_adi_dict(), ms=ms, adi_max_steps=len(ms), adi_newZ_reltol=0.0, sweep_width=G,
+                  project_w=False, device_resident=True)
+
+        def step():
+            ctx.clear_cache()
+            o = pru.solve_proj_lyap_stein(amat=calA, mmat=MT, jmat=pr.J, wmat=Wh, transposed=True, adi_dict=dd)
+            return dict(adi_steps=o["adi_steps"], gmres_iters=o["gmres_iters"], shift_solves=o["shift_solves"],
+                        gmres_nonconverged=o["gmres_nonconverged"], gmres_worst_relres=o["gmres_worst_relres"],
+                        res_fro=o["res_fro"])
 
     for _ in range(warmup):
         step()
@@ -446,16 +510,30 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
         t = torch.tensor([el], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    sinfo = ctx.setup_info()
     res = dict(workload="%s: driven-cavity pattern N=%d (%s), nu=%g; one step = one pass over the %d-shift list of "
-                        "the open-loop Lyapunov ADI, panel m=%d, GMRES tol 1e-10, per-shift setup inside the step"
-                        % (name, w["N"], w["note"], w["nu"], len(ms), w["m"]),
+                        "the open-loop Lyapunov ADI, panel m=%d, GMRES tol 1e-10, per-shift setup inside the step; %s"
+                        % (name, w["N"], w["note"], w["nu"], len(ms), w["m"],
+                           "Python sweep driver" if python_driver else
+                           "through pru.solve_proj_lyap_stein (C++ sweep driver%s)"
+                           % ("" if world == 1 else ", sweeps sharded by shift inside the library over %d ranks, RCCL "
+                              "all-gather on the library's stream" % world)),
                value=round(units / el, 3), unit="shift-solves/s", ms_per_step=round(1e3 * el / steps, 1),
                steps=steps, warmup=warmup, n=int(n), m=int(w["m"]), shifts=len(ms), col_parts=parts,
                gmres_nonconverged=info["gmres_nonconverged"], gmres_worst_relres=info["gmres_worst_relres"],
-               gmres_iters_per_shift_solve=round(ops.gmres_iters / max(ops.shift_solves, 1), 1),
+               gmres_iters_per_shift_solve=round(info["gmres_iters"] / max(info["shift_solves"], 1), 1),
                final_residual_fro=info["res_fro"],
-               preconditioner_levels=ctx.setup_info()["levels"], dense_coarse_dim=ctx.setup_info()["dense_coarse"])
-    ctx.close()
+               preconditioner_levels=sinfo["levels"], dense_coarse_dim=sinfo["dense_coarse"])
+    if python_driver:
+        ctx.close()
+    else:
+        backend.reset()
+    if with_cpu_baseline and rank == 0 and world == 1:
+        try:
+            res["cpu_baseline"] = cpu_baseline_sample(calA, MT, pr.J, ms, w["m"], len(ms),
+                                                      npick=2 if n < 150000 else 1, label=name)
+        except Exception as e:                       # never lose the line
+            res["cpu_baseline"] = {"error": str(e)}
     return res
 
 
@@ -531,7 +609,19 @@ def dre_workload(args, rank):
         tot += el
     units = sum(r["shift_solves"] for r in steps_rec)
     info = backend.context().setup_info()
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            MT = pr.M.T.tocsr()
+            tau = float(np.diff(tmesh).max())
+            ft = (-(0.5 * MT + tau * (pr.A.T + 1.5 * pr.Nc.T))).tocsr()
+            # the operator changes with t: the reference factorises every shifted matrix anew in every time step
+            cpu = cpu_baseline_sample(ft, MT, pr.J, list(nad["ms"]), 66, units, npick=2,
+                                      label="cfg4-dre (largest time step)", n_lu=ns * Nts)
+        except Exception as e:
+            cpu = {"error": str(e)}
     return {
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
         "metric": "ADI shift-solves/sec (wall-clock of the backward DRE sweep in ms_per_step)",
         "value": round(units * args.steps / tot, 3), "unit": "shift-solves/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * tot / args.steps, 1),
@@ -566,7 +656,7 @@ def main():
                          "hold fewer than 4 groups)")
     ap.add_argument("--streams", type=int, default=1, help="Python driver only: concurrent batches per rank")
     ap.add_argument("--nts", type=int, default=8, help="cfg4-dre: time steps of the backward sweep")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4-dre"] + sorted(WORKLOADS),
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4-dre"] + sorted(WORKLOADS),
                     help="cfg2 (default): the metric's configuration, one Newton step to K.  cfg3 / cfg4 / cfg5: "
                          "the larger BASELINE.json configurations as fixed-work shift cycles (see WORKLOADS)")
     ap.add_argument("--also-baseline-config", action="store_true",
@@ -640,17 +730,25 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    if args.workload != "cfg2":
-        res = cycle_workload(args.workload, world, rank, local, args.steps, args.warmup, args.col_split, bar)
+    if args.workload in WORKLOADS:
+        res = cycle_workload(args.workload, world, rank, local, args.steps, args.warmup, args.col_split, bar,
+                             python_driver=args.python_driver, with_cpu_baseline=not args.no_cpu_baseline)
         if rank == 0:
-            print(json.dumps({
+            line = {
                 "metric": "ADI shift-solves/sec", "value": res["value"], "unit": "shift-solves/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-                "data": "synthetic", "config": res}), flush=True)
+                "data": "synthetic", "config": res}
+            if "cpu_baseline" in res:
+                line["cpu_baseline"] = res.pop("cpu_baseline")
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
+    if args.workload == "cfg3":
+        # BASELINE cfg3 as what it is: the steady-state Riccati run (cyl_wake_cont.py:34-50 -> optcont_main.py:488-506)
+        # on the surrogate of SURVEY.md 8d -- the Newton step to K below at N = 75, nu = 0.15 / 40, 32 shifts
+        args.N, args.nu, args.shifts = CFG3["N"], CFG3["nu"], CFG3["shifts"]
 
     xopts = _xopts()
     if xopts:
@@ -817,11 +915,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "driven cavity N=%d (cfg2: n=%d, nnz(S)=%d), nu=%g, %d log-spaced ADI shifts, "
+                "workload": "%s: driven cavity N=%d (n=%d, nnz(S)=%d), nu=%g, %d log-spaced ADI shifts, "
                             "1 Newton step from the converged iterate (closed-loop Lyapunov ADI to "
                             "adi_newZ_reltol=1e-8, update norm, recompression) + gain K; panel m=%d; "
                             "GMRES tol 1e-10; per-shift setup inside the step"
-                            % (args.N, n, nnz_s, args.nu, len(ms), m),
+                            % ("cfg3 (steady-state Riccati, cylinder-wake surrogate)" if args.workload == "cfg3"
+                               else "cfg2" if args.N == 58 else "custom", args.N, n, nnz_s, args.nu, len(ms), m),
+                "preconditioner_levels": ctx.setup_info()["levels"],
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),
                 "parallelism": par,
@@ -858,6 +958,28 @@ def main():
                     None if K_oracle is None else float(np.linalg.norm(K2 - K_oracle) / np.linalg.norm(K_oracle)))
         except Exception as e:
             out["second_figure_error"] = str(e)
+        if args.workload == "cfg3":
+            # continuation in Re (optcont_main.py:471-486, cyl_wake_cont.py:37-45): the Newton iteration at nu started
+            # from the iterate of a run at twice the viscosity, to convergence, through the boundary
+            try:
+                pr2, tb2, trct2, _ = build_inputs(args.N, 2.0 * args.nu, args.shifts)
+                F2 = (-pr2.A - pr2.Nc).tocsr()
+                low = pru.proj_alg_ric_newtonadi(mmat=pr2.M, amat=F2, jmat=pr2.J, bmat=tb2, wmat=trct2, nwtn_adi_dict=d)
+                z0 = pru.compress_Zsvd(low["zfac"], thresh=1e-8, k=400)
+                backend.context_for(calA, calE, pr.J)
+                tz = time.perf_counter()
+                oz = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct, z0=z0, nwtn_adi_dict=d)
+                Kz = -pru.get_mTzzTtb(MT, oz["zfac"], tb)
+                tz = time.perf_counter() - tz
+                out["continuation_from_lower_re"] = dict(
+                    z0="converged iterate at nu = %g (twice the viscosity), compressed to %d columns" % (2.0 * args.nu, z0.shape[1]),
+                    newton_steps=oz["nwtn_steps"], shift_solves=oz["shift_solves"], seconds_to_K=round(tz, 3),
+                    newton_steps_from_zero=conv["nwtn_steps"],
+                    K_rel_diff_vs_oracle=None if K_oracle is None else
+                    float(np.linalg.norm(Kz - K_oracle) / np.linalg.norm(K_oracle)))
+                ctx = backend.context_for(calA, calE, pr.J)
+            except Exception as e:
+                out["continuation_from_lower_re"] = {"error": str(e)}
         # --- kernel rooflines on the launches of this workload ---------------------------------
         G = max(1, min(args.sweep_width, 16, len(ms)))
         gsh = [float(p) for p in ms[:G]]
@@ -915,7 +1037,7 @@ def main():
         own = [float(p) for p, o in zip(ms, _lib.host_deal(ms, world)) if o == 0][:16]
         out["roofline"] = spmm_roofline(ctx, nnz_k, pr.J.nnz, n, m, own or [float(ms[0])])
     if world > 1 and args.also_baseline_config:
-        cfg_for_n = {4: "cfg3", 8: "cfg4"}.get(world)
+        cfg_for_n = {4: "cfg3-cycle", 8: "cfg4"}.get(world)
         if cfg_for_n:
             try:
                 extra = cycle_workload(cfg_for_n, world, rank, local, 1, 0, args.col_split, bar)

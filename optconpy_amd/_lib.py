@@ -517,6 +517,10 @@ class Context:
         _warn_nonconverged(info)
         return Z, info
 
+    def factor_get_dev(self, z_ptr, c):
+        """Copy the context's resident factor (NV x c, packed) into a device buffer."""
+        _chk(self._lib.ricadi_factor_get_dev(self._h, z_ptr, int(c)))
+
     def ric_newtonadi_dev(self, shifts, B_t, W_t, prm, Z0_t=None, old_t=None):
         """``ricadi_ric_newtonadi_dev``: every panel is a torch CUDA tensor (float64, contiguous, NV rows);
         the new iterate comes back as a fresh NV x c CUDA tensor.  No PCIe traffic."""

@@ -167,11 +167,20 @@ def solve_proj_lyap_stein(amat=None, mmat=None, jmat=None, wmat=None,
         if W.shape[1] > _lib.MAX_M:
             raise ValueError("right-hand side factor wider than {0} columns".format(_lib.MAX_M))
         backend.ensure_exchange(ctx, W.shape[1], len(_shifts(d)))
-        Z, info = ctx.lyap_adi(_shifts(d), W, prm)
+        if d.get("device_resident", False):
+            # the factor stays in HBM (DeviceFactor): NV x (steps m) doubles need not cross PCIe to form a gain
+            import torch
+            _, info = ctx.lyap_adi(_shifts(d), W, prm, fetch=False)
+            Zt = torch.empty((ctx.nv, info["cols"]), dtype=torch.float64, device="cuda")
+            if info["cols"] > 0:
+                ctx.factor_get_dev(Zt.data_ptr(), info["cols"])
+            Z = DeviceFactor(Zt)
+        else:
+            Z, info = ctx.lyap_adi(_shifts(d), W, prm)
         if d.get("check_lyap_res", False):
             # optcont_main.py:130 -- the residual of the equation just solved, evaluated
             # independently of the ADI recurrence from the factors (a5, same context)
-            out["lyap_res"] = float(np.sqrt(abs(ctx.lyap_res_norm(Z, W))))
+            out["lyap_res"] = float(np.sqrt(abs(ctx.lyap_res_norm(_dense(_host(Z)), W))))
             if d.get("verbose", False):
                 print("projected Lyapunov residual (factored): {0:.3e}; ADI recurrence: {1:.3e}"
                       .format(out["lyap_res"], info["res_fro"]))

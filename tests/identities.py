@@ -114,3 +114,32 @@ def dre_step_inputs(pr, tau=0.05, seed=0, with_old=False):
         old = -(MT @ (Y @ (Y.T @ tb)))
         kw["mtxoldb"] = np.sqrt(tau) * old
     return kw, dict(MT=MT, ft=ft, tb=tb, wmat=wmat, tau=tau, old=old)
+
+
+def dense_dre_sweep_gains(pr, kw, tmesh):
+    """Independent dense restatement of the backward implicit-Euler sweep of the differential Riccati equation
+    (/root/reference/solve_dae_ric.py:100,122-189): per time step the projected algebraic Riccati equation of the
+    step -- cal A = -(M^T/2 + tau (A + N(t))^T), cal E = M^T, B = sqrt(tau) B~, W W^T = M^T X_{k+1} M + tau C~^T C~ --
+    is solved by :func:`dense_projected_are` (scipy's Schur method on ker J), starting from the terminal value
+    X(T) = gamma M^-1 C~^T C~ M^-T.  Nothing is compressed, nothing is iterated.  Returns {t: -M^T X(t) B~}."""
+    import scipy.linalg as sla
+    from oracle import lin_alg_utils as olau
+    MT = pr.M.T.tocsr()
+    tct = olau.apply_invsqrt_fromright(kw["vmat"], kw["mcmat"].T, output="dense")
+    tb = olau.apply_invsqrt_fromright(kw["rmat"], kw["bmat"], output="dense")
+    Zc = np.sqrt(kw["gamma"]) * olau.apply_massinv(pr.M, tct)
+    X = Zc @ Zc.T
+    gains = {tmesh[-1]: -(MT @ (X @ tb))}
+    for tk in range(len(tmesh) - 2, -1, -1):
+        t = tmesh[tk]
+        tau = tmesh[tk + 1] - t
+        nmat, _ = kw["get_tdpart"](time=t)
+        ft = -(0.5 * MT + tau * (pr.A.T + nmat.T))
+        # factor of M^T X M + tau C~^T C~ (any factor does: only W W^T enters)
+        Q = MT @ X @ MT.T + tau * (tct @ tct.T)
+        ev, U = sla.eigh(0.5 * (Q + Q.T))
+        keep = ev > 1e-15 * ev.max()
+        W = U[:, keep] * np.sqrt(ev[keep])
+        X = dense_projected_are(ft.toarray(), MT, pr.J, np.sqrt(tau) * tb, W)
+        gains[t] = -(MT @ (X @ tb))
+    return gains

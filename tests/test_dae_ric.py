@@ -85,6 +85,46 @@ def test_c_consistency_check_raises():
         solve_flow_daeric(store=MemoryStore(), pru=opru, lau=olau, **bad)
 
 
+def _pin_setup():
+    """Two backward time steps at N = 8 (NV = 450), tight tolerances, no compression to speak of."""
+    pr, kw, tmesh = _setup(N=8, Nts=2)
+    kw = dict(kw, comprz_thresh=1e-10, comprz_maxc=400,
+              nwtn_adi_dict=dict(kw["nwtn_adi_dict"], adi_max_steps=300, adi_newZ_reltol=1e-12, nwtn_max_steps=30,
+                                 nwtn_upd_reltol=1e-11, nwtn_upd_abstol=1e-14, ms=pb.logshifts(0.4, 200.0, 10)))
+    return pr, kw, tmesh
+
+
+def test_two_step_sweep_oracle_vs_dense_riccati_solver():
+    """The oracle's sweep pinned by dense mathematics: the gains of two backward time
+    steps against scipy.linalg.solve_continuous_are on ker J, step by step (identities.dense_dre_sweep_gains) --
+    no ADI, no Newton-Kleinman, no saddle-point solve shared."""
+    from identities import dense_dre_sweep_gains
+    pr, kw, tmesh = _pin_setup()
+    dense = dense_dre_sweep_gains(pr, kw, tmesh)
+    store = MemoryStore()
+    fb = solve_flow_daeric(store=store, pru=opru, lau=olau, **kw)
+    for t in tmesh:
+        K = store.load(fb[t]["mtxtb"])
+        assert np.linalg.norm(K - dense[t]) <= 1e-6 * np.linalg.norm(dense[t]), t
+
+
+@pytest.mark.gpu
+def test_two_step_sweep_gpu_vs_dense_riccati_solver():
+    """The same pin for the MI355X modules: the product's sweep against the dense solver directly (not via the
+    oracle), gain by gain at the 1e-6 bar."""
+    from identities import dense_dre_sweep_gains
+    from optconpy_amd import backend
+    backend.reset()
+    pr, kw, tmesh = _pin_setup()
+    dense = dense_dre_sweep_gains(pr, kw, tmesh)
+    store = MemoryStore()
+    fb = solve_flow_daeric(store=store, **kw)
+    for t in tmesh:
+        K = store.load(fb[t]["mtxtb"])
+        assert np.linalg.norm(K - dense[t]) <= 1e-6 * np.linalg.norm(dense[t]), t
+    backend.reset()
+
+
 @pytest.mark.gpu
 def test_sweep_gpu_vs_oracle():
     from optconpy_amd import backend

@@ -183,14 +183,17 @@ def test_cfg5_batched_shift_solves_properties():
 
 
 # ------------------------------------------------------------ independent dense pin (GPU)
-def test_hip_newton_adi_vs_dense_are_three_call_forms():
+@pytest.mark.parametrize("N", [4, 8])
+def test_hip_newton_adi_vs_dense_are_three_call_forms(N):
+    """N = 4 (NV = 98) and N = 8 (NV = 450, 370 divergence-free directions): the HIP path against scipy's dense
+    Riccati solver for the three call forms of the reference."""
     import sadptprj_riclyap_adi.proj_ric_utils as pru
     from identities import dense_projected_are, dre_step_inputs
     backend.reset()
     tight = dict(adi_max_steps=300, adi_newZ_reltol=1e-12, nwtn_max_steps=30, nwtn_upd_reltol=1e-11,
                  nwtn_upd_abstol=1e-14)
     # steady call
-    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-3)
+    pr = pb.ricc_problem(N, 0.2, NU=2, NY=2, alphau=1e-3)
     mct = olau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tb = olau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
     trct = olau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
@@ -202,7 +205,7 @@ def test_hip_newton_adi_vs_dense_are_three_call_forms():
     assert rel(Z @ Z.T, X) < 1e-6
     assert rel(pru.get_mTzzTtb(pr.M.T, Z, tb), pr.M.T @ (X @ tb)) < K_TOL
     # time-step call: transposed=True, z0, then also mtxoldb
-    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-2)
+    pr = pb.ricc_problem(N, 0.2, NU=2, NY=2, alphau=1e-2)
     for with_old in (False, True):
         kw, p = dre_step_inputs(pr, tau=0.05, with_old=with_old)
         B = np.sqrt(p["tau"]) * p["tb"]

@@ -5,6 +5,7 @@ five identities) on this repo's seeded matrices, adds convergence checks the
 reference test lacks, and compares with the committed golden vectors.
 """
 import numpy as np
+import pytest
 import scipy.sparse as sps
 import scipy.sparse.linalg as spsla
 
@@ -146,10 +147,12 @@ def _xrel(Z, X):
     return np.linalg.norm(Z @ Z.T - X) / np.linalg.norm(X)
 
 
-def test_dense_are_pin_steady_call():
-    """optcont_main.py:488-492: mmat=M, amat=-A-N, transposed=False -> cal A = amat^T, cal E = M^T."""
+@pytest.mark.parametrize("N", [4, 8])
+def test_dense_are_pin_steady_call(N):
+    """optcont_main.py:488-492: mmat=M, amat=-A-N, transposed=False -> cal A = amat^T, cal E = M^T.
+    N = 4 (NV = 98) and N = 8 (NV = 450: 370 divergence-free directions)."""
     from identities import dense_projected_are
-    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-3)
+    pr = pb.ricc_problem(N, 0.2, NU=2, NY=2, alphau=1e-3)
     mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
     trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
@@ -164,13 +167,14 @@ def test_dense_are_pin_steady_call():
         assert np.linalg.norm(K - pr.M.T @ (X @ tb)) < 1e-8 * np.linalg.norm(K)
 
 
-def test_dense_are_pin_dre_call_transposed_z0_mtxoldb():
+@pytest.mark.parametrize("N", [4, 8])
+def test_dense_are_pin_dre_call_transposed_z0_mtxoldb(N):
     """solve_dae_ric.py:147-159: transposed=True (cal A = amat = ft_mat, cal E = mmat = M^T), z0 = Zc,
     and mtxoldb: the Riccati equation of cal A + mtxoldb bmat^T (sign consistent with the
     feed-forward solve of the same step, solve_dae_ric.py:181,192-194).  The implicit-Euler
     step of the differential Riccati equation these arguments encode is solved densely."""
     from identities import dense_projected_are, dre_step_inputs
-    pr = pb.ricc_problem(4, 0.2, NU=2, NY=2, alphau=1e-2)
+    pr = pb.ricc_problem(N, 0.2, NU=2, NY=2, alphau=1e-2)
     d = dict(_TIGHT, ms=pb.logshifts(0.4, 60.0, 8))
     for with_old in (False, True):
         kw, p = dre_step_inputs(pr, tau=0.05, with_old=with_old)
