@@ -439,7 +439,7 @@ def _xopts():
 
 
 def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_fn, python_driver=False,
-                   with_cpu_baseline=True):
+                   with_cpu_baseline=True, interleave=True):
     """Times `steps` passes over the shift list of a WORKLOADS entry.  Default: through the boundary call
     pru.solve_proj_lyap_stein (C++ sweep driver; under torch.distributed the library shards the sweeps by shift
     over the ranks, RCCL all-gather on its stream) -- the same call at every rank count.  `python_driver`:
@@ -457,7 +457,7 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
         calA = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
     else:
         calA = (-pr.A - pr.Nc).T.tocsr()
-    ms = pb.logshifts(w["pmin"], w["pmax"], w["shifts"])
+    ms = pb.logshifts(w["pmin"], w["pmax"], w["shifts"], interleave=interleave)
     xo = _xopts()
     if xo:
         backend.configure(**xo)
@@ -520,6 +520,8 @@ def cycle_workload(name, world, rank, local, steps, warmup, col_split, barrier_f
                               "all-gather on the library's stream" % world)),
                value=round(units / el, 3), unit="shift-solves/s", ms_per_step=round(1e3 * el / steps, 1),
                steps=steps, warmup=warmup, n=int(n), m=int(w["m"]), shifts=len(ms), col_parts=parts,
+               shift_order=("interleaved (pb.logshifts(..., interleave=True): any 16 consecutive shifts span the range; "
+                            "sweeps of 16)" if interleave and len(ms) > 16 else "ascending |p|"),
                gmres_nonconverged=info["gmres_nonconverged"], gmres_worst_relres=info["gmres_worst_relres"],
                gmres_iters_per_shift_solve=round(info["gmres_iters"] / max(info["shift_solves"], 1), 1),
                final_residual_fro=info["res_fro"],
@@ -557,7 +559,7 @@ def dre_workload(args, rank):
     pr = pb.ricc_problem(N, nu, NU=4, NY=4, alphau=1e-2)
     mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tmesh = pb.get_tint(0.0, 1.0, Nts, True)
-    nad = dict(pb.default_nwtn_adi_dict(), ms=pb.logshifts(0.5, 2e3, ns))
+    nad = dict(pb.default_nwtn_adi_dict(), ms=pb.logshifts(0.5, 2e3, ns, interleave=not args.sorted_shifts))
     NY2 = mct.shape[1]
 
     def ystar(t):
@@ -628,7 +630,7 @@ def dre_workload(args, rank):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": "cfg4-dre: driven-cavity pattern N=%d (n=%d), nu=%g, differential Riccati sweep over "
-                        "get_tint(0,1,%d) (sine-squeezed), %d ADI shifts, comprz_maxc=50, time-varying "
+                        "get_tint(0,1,%d) (sine-squeezed), %d ADI shifts (interleaved order unless --sorted-shifts), comprz_maxc=50, time-varying "
                         "convection; through solve_flow_daeric -> pru.proj_alg_ric_newtonadi / compress_Zsvd / "
                         "get_mTzzTtb / lau.solve_sadpnt_smw" % (N, pr.NV + pr.NP, nu, Nts, ns),
             "time_steps": steps_rec, "seconds_in_newton_adi": round(sum(r["seconds"] for r in steps_rec), 2),
@@ -663,6 +665,8 @@ def main():
                     help="N>1: after the cfg2 headline also time one shift cycle of the BASELINE configuration "
                          "quoted for this GPU count (cfg3 @ 4, cfg4 @ 8) and add it as `baseline_config_for_n`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sorted-shifts", action="store_true",
+                    help="cfg3-cycle / cfg4 / cfg5 / cfg4-dre: the shift list in ascending |p| (rounds 1-3) instead of interleaved")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 on a one-GPU box: all ranks on device 0 with gloo (checks the code path only)")
     ap.add_argument("--cpu-full", action="store_true",
@@ -732,7 +736,8 @@ def main():
         return
     if args.workload in WORKLOADS:
         res = cycle_workload(args.workload, world, rank, local, args.steps, args.warmup, args.col_split, bar,
-                             python_driver=args.python_driver, with_cpu_baseline=not args.no_cpu_baseline)
+                             python_driver=args.python_driver, with_cpu_baseline=not args.no_cpu_baseline,
+                             interleave=not args.sorted_shifts)
         if rank == 0:
             line = {
                 "metric": "ADI shift-solves/sec", "value": res["value"], "unit": "shift-solves/s",

@@ -2172,23 +2172,34 @@ static void reduce_over_ranks(ricadi_ctx* c, double* v, int nsum, int nmax) {
 
 static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, double* dW, int m,
                                 const ricadi_adi_params& prm, AdiStats& stt) {
-  const int G = std::min(std::min(prm.sweep_width, ns), RICADI_MAX_GROUPS);
-  if (G < 2 || prm.adi_max_steps < G || G * m > 2048) return false;
+  int G = std::min(std::min(prm.sweep_width, ns), RICADI_MAX_GROUPS);
+  while (G >= 2 && (prm.adi_max_steps < G || G * m > 2048)) G /= 2;
+  if (G < 2) return false;
   for (int i = 0; i < ns; ++i)
     for (int j = i + 1; j < ns; ++j)
       if (shifts[i] == shifts[j]) return false;     // sweeps need distinct shifts
-  // Cauchy data of every sweep of the cycle up front: a numerically singular Cauchy
-  // matrix (shifts too many / too close) sends the caller back to the sequential form
-  const int ncyc = ns / std::gcd(ns, G);          // sweeps until the shift pattern repeats
-  std::vector<std::vector<double>> rinvs(ncyc), cinvs(ncyc);
-  std::vector<std::vector<double>> pss(ncyc);
-  for (int sw = 0; sw < ncyc; ++sw) {
-    pss[sw].resize(G);
-    for (int g = 0; g < G; ++g) pss[sw][g] = shifts[(sw * G + g) % ns];
-    rinvs[sw].resize((size_t)G * G);
-    cinvs[sw].resize(G);
-    if (cauchy_data(pss[sw].data(), G, rinvs[sw].data(), cinvs[sw].data()) != RICADI_OK) return false;
+  // Cauchy data of every sweep of the cycle up front.  A numerically singular Cauchy matrix (the shifts of a
+  // sweep too many / too close: 16 consecutive entries of a 128-shift list over 3.5 decades) halves the sweep
+  // width until every sweep of the cycle is admissible -- as shift_parallel.py does --; only when no width
+  // >= 2 is left does the caller go back to the sequential form
+  int ncyc = 0;
+  std::vector<std::vector<double>> rinvs, cinvs, pss;
+  for (; G >= 2; G /= 2) {
+    ncyc = ns / std::gcd(ns, G);                  // sweeps until the shift pattern repeats
+    rinvs.assign(ncyc, {});
+    cinvs.assign(ncyc, {});
+    pss.assign(ncyc, {});
+    bool ok = true;
+    for (int sw = 0; sw < ncyc && ok; ++sw) {
+      pss[sw].resize(G);
+      for (int g = 0; g < G; ++g) pss[sw][g] = shifts[(sw * G + g) % ns];
+      rinvs[sw].resize((size_t)G * G);
+      cinvs[sw].resize(G);
+      ok = cauchy_data(pss[sw].data(), G, rinvs[sw].data(), cinvs[sw].data()) == RICADI_OK;
+    }
+    if (ok) break;
   }
+  if (G < 2) return false;
   hipStream_t st = c->st;
   const int n = c->n, nv = c->nv;
   const size_t nm = (size_t)n * m;
@@ -4156,7 +4167,16 @@ int ricadi_lyap_adi(ricadi_ctx* c, const double* shifts, int ns, const double* W
   DArr<double> dW;
   dW.alloc((size_t)c->nv * m);
   HIPCHK(hipMemcpyAsync(dW.p, W, sizeof(double) * c->nv * m, hipMemcpyHostToDevice, c->st));
+  if (c->timing) c->t_setup = c->t_solve = c->t_recomb = c->t_compress = c->t_proj = c->t_cyc = c->t_iter = c->t_guess = 0;
+  Tick tka;
   AdiStats s = lyap_adi_dev(c, shifts, ns, dW.p, m, *prm);
+  if (c->timing) {
+    (void)hipStreamSynchronize(c->st);
+    fprintf(stderr, "[ricadi timing] lyap_adi: total %.1f ms = setup %.1f + projection %.1f + solves %.1f (Arnoldi iterations %.1f, "
+            "restart-cycle bookkeeping %.1f, recycled guesses %.1f) + recombination %.1f + recompression %.1f (+ rest)\n",
+            1e3 * tka.lap(), 1e3 * c->t_setup, 1e3 * c->t_proj, 1e3 * c->t_solve, 1e3 * c->t_iter, 1e3 * c->t_cyc,
+            1e3 * c->t_guess, 1e3 * c->t_recomb, 1e3 * c->t_compress);
+  }
   if (c_out) *c_out = c->zc;
   if (Z_out && c->zc > 0) {
     HIPCHK(hipMemcpy2DAsync(Z_out, sizeof(double) * c->zc, c->Z.p, sizeof(double) * c->zld,

@@ -417,9 +417,21 @@ def default_nwtn_adi_dict():
                 full_upd_norm_check=False, check_lyap_res=False)
 
 
-def logshifts(pmin, pmax, s):
-    """``ms = -logspace(log10 pmin, log10 pmax, s)``."""
-    return (-np.logspace(np.log10(pmin), np.log10(pmax), int(s))).tolist()
+def logshifts(pmin, pmax, s, interleave=False):
+    """``ms = -logspace(log10 pmin, log10 pmax, s)``.
+
+    ``interleave``: the same values in the order ``0, k, 2k, ..., 1, k+1, ...`` with ``k = ceil(s / 16)``, so that
+    any 16 consecutive entries of the list are spread over the whole range.  The ADI applies the shifts in list order
+    (the reference takes ``ms`` as given, ``run_optcont.py:18-19``: an unsorted list); after every complete pass over
+    the list the iterate is the same for every order, but the sweep form of the ADI -- G consecutive shifts solved
+    against one residual factor, recombined with their G x G Cauchy matrix -- needs the shifts of a sweep well
+    separated: 16 neighbours of a 128-shift list over 3.5 decades have a numerically singular Cauchy matrix (the
+    sweeps then shrink to 4 shifts), 16 interleaved ones are as far apart as the 16 shifts of cfg2."""
+    ms = (-np.logspace(np.log10(pmin), np.log10(pmax), int(s))).tolist()
+    if interleave and len(ms) > 16:
+        k = -(-len(ms) // 16)
+        ms = [ms[i] for r in range(k) for i in range(r, len(ms), k)]
+    return ms
 
 
 class RicProblem(dict):
