@@ -60,7 +60,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_inputs(N, nu, nshifts, pmax=3e3):
+def build_inputs(N, nu, nshifts, pmax=3e3, interleave=False):
     """cfg2 inputs, prepared with the drop-in's own modules (GPU solves), as
     optcont_main.py:405-425 prepares them."""
     import sadptprj_riclyap_adi.lin_alg_utils as lau
@@ -69,19 +69,21 @@ def build_inputs(N, nu, nshifts, pmax=3e3):
     mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="dense")
     trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
-    ms = pb.logshifts(1.0, pmax, nshifts)
+    ms = pb.logshifts(1.0, pmax, nshifts, interleave=interleave)
     return pr, tb, trct, ms
 
 
-def oracle_gain(N, nu, nshifts):
-    """K of the CPU oracle for this workload from the committed fixtures (cfg2: N = 58; cfg3: N = 75)."""
-    for name in ("cfg2_golden.npz", "cfg3_golden.npz"):
+def oracle_gain(N, nu, ms):
+    """K of the CPU oracle for this workload from the committed fixtures (cfg2: N = 58; cfg3 / cfg3i: N = 75 with
+    the 32 shifts in ascending / interleaved order): the fixture whose mesh, viscosity and shift LIST match."""
+    for name in ("cfg2_golden.npz", "cfg3i_golden.npz", "cfg3_golden.npz"):
         path = os.path.join(ROOT, "tests", "golden", name)
         if not os.path.exists(path):
             continue
         g = np.load(path)
         cfg = g["cfg"]
-        if int(cfg[0]) == N and abs(cfg[1] - nu) <= 1e-15 and int(cfg[5]) == nshifts:
+        if int(cfg[0]) == N and abs(cfg[1] - nu) <= 1e-15 and len(g["shifts"]) == len(ms) and \
+                np.allclose(g["shifts"], ms, rtol=1e-14):
             return g["K_ric"]
     return None
 
@@ -759,7 +761,8 @@ def main():
     if xopts:
         backend.configure(**xopts)
     t0 = time.time()
-    pr, tb, trct, ms = build_inputs(args.N, args.nu, args.shifts)
+    il = args.workload == "cfg3" and not args.sorted_shifts      # 32 shifts: interleaved so that sweeps of 16 are admissible
+    pr, tb, trct, ms = build_inputs(args.N, args.nu, args.shifts, interleave=il)
     F = (-pr.A - pr.Nc).tocsr()
     MT = pr.M.T.tocsr()
     calA, calE = F.T.tocsr(), MT
@@ -769,7 +772,7 @@ def main():
     n = pr.NV + pr.NP
     nnz_k = (calA + calE).nnz
     nnz_s = nnz_k + 2 * pr.J.nnz
-    K_oracle = oracle_gain(args.N, args.nu, args.shifts)
+    K_oracle = oracle_gain(args.N, args.nu, ms)
 
     # untimed: converge the Newton iteration once through the boundary; its compressed
     # iterate is the linearisation point Z_k of the timed Newton step
@@ -920,12 +923,13 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: driven cavity N=%d (n=%d, nnz(S)=%d), nu=%g, %d log-spaced ADI shifts, "
+                "workload": "%s: driven cavity N=%d (n=%d, nnz(S)=%d), nu=%g, %d log-spaced ADI shifts%s, "
                             "1 Newton step from the converged iterate (closed-loop Lyapunov ADI to "
                             "adi_newZ_reltol=1e-8, update norm, recompression) + gain K; panel m=%d; "
                             "GMRES tol 1e-10; per-shift setup inside the step"
                             % ("cfg3 (steady-state Riccati, cylinder-wake surrogate)" if args.workload == "cfg3"
-                               else "cfg2" if args.N == 58 else "custom", args.N, n, nnz_s, args.nu, len(ms), m),
+                               else "cfg2" if args.N == 58 else "custom", args.N, n, nnz_s, args.nu, len(ms),
+                               " (interleaved order)" if il else "", m),
                 "preconditioner_levels": ctx.setup_info()["levels"],
                 "shift_solves_per_step": units // args.steps,
                 "gmres_iters_per_shift_solve": round(iters / max(local_solves, 1), 1),
@@ -967,7 +971,7 @@ def main():
             # continuation in Re (optcont_main.py:471-486, cyl_wake_cont.py:37-45): the Newton iteration at nu started
             # from the iterate of a run at twice the viscosity, to convergence, through the boundary
             try:
-                pr2, tb2, trct2, _ = build_inputs(args.N, 2.0 * args.nu, args.shifts)
+                pr2, tb2, trct2, _ = build_inputs(args.N, 2.0 * args.nu, args.shifts, interleave=il)
                 F2 = (-pr2.A - pr2.Nc).tocsr()
                 low = pru.proj_alg_ric_newtonadi(mmat=pr2.M, amat=F2, jmat=pr2.J, bmat=tb2, wmat=trct2, nwtn_adi_dict=d)
                 z0 = pru.compress_Zsvd(low["zfac"], thresh=1e-8, k=400)

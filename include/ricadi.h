@@ -462,9 +462,13 @@ int ricadi_host_sa_criterion(int nv, const int32_t* a_rowptr, const int32_t* a_c
  * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */
 int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col,
                           int bsize, int32_t* blk_out);
-/* Cauchy recombination data for a sweep of g distinct real shifts
+/* Cauchy recombination data for a sweep of g distinct real negative shifts
  * (SURVEY.md section 8e):  C_ij = -1/(p_i+p_j) = R^T R (upper R);
- * rinv_out = R^-1 (g x g row-major), cinv1_out = C^-1 * ones (g).          */
+ * rinv_out = R^-1 (g x g row-major), cinv1_out = C^-1 * ones (g), both in closed form (partial
+ * fractions of the ADI steps' rational functions: accurate to a few ulp per entry whatever the
+ * condition of C).  RICADI_EBREAKDOWN for repeated shifts and for sweeps whose recombination would
+ * amplify the solves' errors by more than ~1e5 (smallest relative pivot of C below 1e-6: shifts too
+ * many / too close); the drivers then halve the sweep width.                                    */
 int ricadi_host_cauchy(const double* shifts, int g, double* rinv_out, double* cinv1_out);
 
 #ifdef __cplusplus

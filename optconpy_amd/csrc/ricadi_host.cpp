@@ -800,41 +800,54 @@ int gram_lstsq_scaled(int h, int m, std::vector<double>& Ghh, std::vector<double
   return r;
 }
 
+// Cauchy data of an ADI sweep, C_ij = -1 / (p_i + p_j) = R^T R:  rinv = R^-1 (g x g, row major, upper
+// triangular) and cinv1 = C^-1 1 -- in CLOSED FORM, not by a numerical Cholesky factorisation.  Column j of R^-1
+// holds the partial-fraction coefficients of the rational function of ADI step j,
+//   f_j(s) = sqrt(-2 p_j) / (s + p_j) * prod_{k<j} (s - p_k) / (s + p_k) = sum_{i<=j} c_ij / (s + p_i),
+//   c_ij = sqrt(-2 p_j) prod_{k<j} (-p_i - p_k) / ( [i<j] (p_j - p_i) prod_{k<j, k!=i} (p_k - p_i) ),
+// and C^-1 1 those of the residual's  prod_k (s - p_k) / (s + p_k) = 1 + sum_i d_i / (s + p_i),
+//   d_i = -2 p_i prod_{k!=i} (p_i + p_k) / (p_i - p_k):
+// products of sums and differences of the shifts, each entry accurate to a few ulp however ill conditioned C is.
+// (Round 1-3 factorised C numerically: the 16 x 16 matrix of 16 NEIGHBOURS of a 32-shift list has condition 4e13,
+// its computed R^-1 was wrong by 1e-6 relative, and the gain of the cfg3 Newton iteration came out 1.3e-5 off the
+// oracle's -- whatever the GMRES tolerance -- while 16 shifts spread over the same range, cfg2, agreed to 1e-10.)
+// Admissible sweeps: the recombination still amplifies the ERRORS OF THE SOLVES by ~ cond(R), so a sweep whose
+// smallest pivot R_jj^2 / C_jj = prod_{k<j} ((p_j - p_k) / (p_j + p_k))^2 falls below 1e-6 (cond(R) >~ 1e5; cfg2:
+// 2e-3) is refused: the drivers then halve the sweep width.
 int cauchy_data(const double* shifts, int g, double* rinv, double* cinv1) {
   if (g < 1) return RICADI_EINVAL;
-  std::vector<double> L((size_t)g * g, 0.0);  // lower Cholesky factor, C = L L^T
-  for (int i = 0; i < g; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = -1.0 / (shifts[i] + shifts[j]);
-      for (int k = 0; k < j; ++k) s -= L[(size_t)i * g + k] * L[(size_t)j * g + k];
-      if (i == j) {
-        // relative test: a numerically singular Cauchy matrix (repeated or
-        // too many shifts) must not slip through on a rounding-level pivot
-        if (!(s > 1e-13 * (-0.5 / shifts[i]))) return RICADI_EBREAKDOWN;
-        L[(size_t)i * g + i] = std::sqrt(s);
-      } else {
-        L[(size_t)i * g + j] = s / L[(size_t)j * g + j];
-      }
-    }
-  // Linv (lower): solve L * Linv = I
-  std::vector<double> Li((size_t)g * g, 0.0);
-  for (int c = 0; c < g; ++c)
-    for (int i = c; i < g; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) s -= L[(size_t)i * g + k] * Li[(size_t)k * g + c];
-      Li[(size_t)i * g + c] = s / L[(size_t)i * g + i];
-    }
-  // R = L^T  =>  R^-1 = Linv^T
-  for (int i = 0; i < g; ++i)
-    for (int j = 0; j < g; ++j) rinv[(size_t)i * g + j] = Li[(size_t)j * g + i];
-  // C^-1 1 = Linv^T (Linv 1)
-  std::vector<double> t(g, 0.0);
-  for (int i = 0; i < g; ++i)
-    for (int j = 0; j <= i; ++j) t[i] += Li[(size_t)i * g + j];
+  typedef long double ld;
+  std::vector<ld> p(g);
   for (int i = 0; i < g; ++i) {
-    double s = 0.0;
-    for (int k = i; k < g; ++k) s += Li[(size_t)k * g + i] * t[k];
-    cinv1[i] = s;
+    p[i] = (ld)shifts[i];
+    if (!(shifts[i] < 0.0)) return RICADI_EINVAL;
+    for (int k = 0; k < i; ++k)
+      if (shifts[k] == shifts[i]) return RICADI_EBREAKDOWN;
+  }
+  for (int j = 0; j < g; ++j) {
+    ld piv = 1.0L;
+    for (int k = 0; k < j; ++k) {
+      const ld q = (p[j] - p[k]) / (p[j] + p[k]);
+      piv *= q * q;
+    }
+    if (!(piv > 1e-6L)) return RICADI_EBREAKDOWN;
+  }
+  for (int i = 0; i < g; ++i)
+    for (int j = 0; j < g; ++j) rinv[(size_t)i * g + j] = 0.0;
+  for (int j = 0; j < g; ++j)
+    for (int i = 0; i <= j; ++i) {
+      ld num = sqrtl(-2.0L * p[j]), den = 1.0L;
+      for (int k = 0; k < j; ++k) num *= (-p[i] - p[k]);
+      if (i < j) den *= (p[j] - p[i]);
+      for (int k = 0; k < j; ++k)
+        if (k != i) den *= (p[k] - p[i]);
+      rinv[(size_t)i * g + j] = (double)(num / den);
+    }
+  for (int i = 0; i < g; ++i) {
+    ld v = -2.0L * p[i];
+    for (int k = 0; k < g; ++k)
+      if (k != i) v *= (p[i] + p[k]) / (p[i] - p[k]);
+    cinv1[i] = (double)v;
   }
   return RICADI_OK;
 }

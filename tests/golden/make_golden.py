@@ -23,6 +23,9 @@ CFG2 = dict(N=58, nu=0.05, alphau=1e-2, NU=4, NY=4, nshifts=16, pmin=1.0, pmax=3
 # BASELINE cfg3 surrogate (bench.py --workload cfg3): N = 75 -> n = 50 177, nu = 0.15 / 40, 32 shifts --
 # the steady-state Riccati run of cyl_wake_cont.py:34-50 / optcont_main.py:488-506
 CFG3 = dict(N=75, nu=0.15 / 40.0, alphau=1e-2, NU=4, NY=4, nshifts=32, pmin=1.0, pmax=3e3)
+# the same with the shift list in interleaved order (pb.logshifts(..., interleave=True)): any 16 consecutive shifts
+# are spread over the whole range, so that the sweep form of the ADI can take 16 at a time (bench.py --workload cfg3)
+CFG3I = dict(CFG3, interleave=True)
 
 
 def cfg1_inputs(cfg=CFG1):
@@ -30,7 +33,7 @@ def cfg1_inputs(cfg=CFG1):
     mct = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=pr.mc_mat.T, transposedprj=True)
     tb = lau.apply_invsqrt_fromright(pr.rmat, pr.b_mat, output="sparse")
     trct = lau.apply_invsqrt_fromright(pr.y_masmat, mct, output="dense")
-    ms = pb.logshifts(cfg["pmin"], cfg["pmax"], cfg["nshifts"])
+    ms = pb.logshifts(cfg["pmin"], cfg["pmax"], cfg["nshifts"], interleave=cfg.get("interleave", False))
     return pr, tb, trct, ms
 
 
@@ -86,8 +89,11 @@ def main_cfg2(CFG=CFG2, name="cfg2_golden.npz"):
     ro = pru.proj_alg_ric_newtonadi(mmat=pr.M, amat=F, jmat=pr.J, bmat=tb, wmat=trct,
                                     nwtn_adi_dict=d, stats=stats)
     K_ric = -pru.get_mTzzTtb(pr.M.T, ro["zfac"], tb)
-    lo = pru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=trct, adi_dict=d)
-    K_lyap = -pru.get_mTzzTtb(pr.M.T, lo["zfac"], tb)
+    if name == "cfg2_golden.npz":
+        lo = pru.solve_proj_lyap_stein(amat=F, mmat=pr.M, jmat=pr.J, wmat=trct, adi_dict=d)
+        K_lyap, lyap_steps = -pru.get_mTzzTtb(pr.M.T, lo["zfac"], tb), lo["adi_steps"]
+    else:                       # the larger fixtures hold the Riccati gain only
+        K_lyap, lyap_steps = np.zeros((0, 0)), 0
     out = dict(
         cfg=np.array([CFG2[k] for k in ("N", "nu", "alphau", "NU", "NY", "nshifts", "pmin", "pmax")]),
         shifts=np.array(ms),
@@ -96,7 +102,7 @@ def main_cfg2(CFG=CFG2, name="cfg2_golden.npz"):
         tb_fro=np.array([np.linalg.norm(tb.toarray())]), trct_fro=np.array([np.linalg.norm(trct)]),
         K_ric=K_ric, nwtn_steps=np.array([ro["nwtn_steps"]]),
         upd_hist=np.array([[u[0], u[1], u[2]] for u in ro["upd_hist"]]),
-        K_lyap=K_lyap, lyap_steps=np.array([lo["adi_steps"]]),
+        K_lyap=K_lyap, lyap_steps=np.array([lyap_steps]),
         oracle_seconds=np.array([time.time() - t0, stats.get("lu_time", 0.0), stats.get("solve_time", 0.0),
                                  stats.get("n_lu", 0), stats.get("n_shift_solves", 0)]),
     )
@@ -135,5 +141,7 @@ if __name__ == "__main__":
         main_cfg2()
     elif "--cfg3" in sys.argv:
         main_cfg2(CFG3, "cfg3_golden.npz")
+    elif "--cfg3i" in sys.argv:
+        main_cfg2(CFG3I, "cfg3i_golden.npz")
     else:
         main()

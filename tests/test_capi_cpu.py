@@ -149,6 +149,34 @@ def test_operator_cache_key_is_exact():
     assert backend._fingerprint(B) != backend._fingerprint(A)
 
 
+def test_cauchy_data_closed_form_and_conditioning_bound():
+    """ricadi_host_cauchy: R^-1 and C^-1 1 of a sweep's Cauchy matrix in closed form (partial fractions of the ADI
+    steps' rational functions).  Checked against the defining identities in extended precision on the sets the
+    workloads use -- also the worst admissible one (8 neighbours of the 32-shift list, cond(C) = 6e9) --, and the
+    conditioning bound: 16 neighbours of that list (cond(C) = 4e13, where round 3's numerically factorised data were
+    wrong by 1e-6 and the cfg3 gain by 1.3e-5) are refused, so that the drivers halve the sweep."""
+    from optconpy_amd import problems as pb
+    ld = np.longdouble
+    for ps in (pb.logshifts(1.0, 3e3, 16), pb.logshifts(1.0, 3e3, 32)[:8], pb.logshifts(1.0, 3e3, 32)[8:16],
+               pb.logshifts(1.0, 3e3, 128, interleave=True)[:16], [-5.0, -3.0, -2.0, -1.5, -1.3, -1.1, -1.0][:4]):
+        g = len(ps)
+        rinv, c1 = _lib.host_cauchy(ps)
+        Ri = np.asarray(rinv, dtype=ld).reshape(g, g)
+        assert np.allclose(np.tril(np.asarray(rinv).reshape(g, g), -1), 0.0)
+        p = np.asarray(ps, dtype=ld)
+        Cm = -1.0 / (p[:, None] + p[None, :])
+        # R^-T C R^-1 = I and C (C^-1 1) = 1, evaluated in extended precision
+        E = Ri.T @ Cm @ Ri - np.eye(g, dtype=ld)
+        scale = float(np.abs(Ri).max()) ** 2 * float(np.abs(Cm).max())
+        assert float(np.abs(E).max()) < 1e-13 * max(scale, 1.0)
+        one = Cm @ np.asarray(c1, dtype=ld)
+        assert float(np.abs(one - 1.0).max()) < 1e-13 * float(np.abs(np.asarray(c1)).max()) * float(np.abs(Cm).max())
+    with pytest.raises((RuntimeError, ValueError)):
+        _lib.host_cauchy(pb.logshifts(1.0, 3e3, 32)[:16])
+    with pytest.raises((RuntimeError, ValueError)):
+        _lib.host_cauchy([-1.0, -2.0, -1.0])
+
+
 def test_struct_layout_matches_header(tmp_path):
     """sizeof / offsetof of the two structs that cross the C-ABI, three ways: a C probe
     compiled from include/ricadi.h, the library's own ricadi_sizeof_*(), and the ctypes
