@@ -121,7 +121,7 @@ def get_tdpart_from_velocities(N, dictofvalues, store=None, ordering="component"
 def simulate_nse_flow(mmat=None, amat=None, jmat=None, N=None, tb_mat=None, rhsv=None, iniv=None,
                       tmesh=None, feedbackthroughdict=None, store=None, closed_loop=False,
                       static_feedback=False, vel_pcrd_stps=1, vel_nwtn_stps=2, ordering="component",
-                      lau=None, return_info=False):
+                      lau=None, return_info=False, lin_vel_point=None):
     """Implicit Euler for the NONLINEAR Navier-Stokes flow, optionally in closed loop -- the
     ``snu.solve_nse(closed_loop=True, feedbackthroughdict=..., vel_pcrd_stps=1, vel_nwtn_stps=2)`` of
     ``optcont_main.py:609-626`` (and, without feedback, the forward solve of ``:548-550`` whose stored
@@ -154,7 +154,9 @@ def simulate_nse_flow(mmat=None, amat=None, jmat=None, N=None, tb_mat=None, rhsv
             gain = store.load(feedbackthroughdict[key]["mtxtb"])          # NV x NU
             w = store.load(feedbackthroughdict[key]["w"])
             base = base + tb @ (tb.T @ w)
-        vbar = v.copy()
+        # linearisation point of the first step of this time step: the previous time step's velocity, or the
+        # given trajectory (`lin_vel_point`: {t: v}, optcont_main.py:612 -- the linearised NSE about the last flow)
+        vbar = v.copy() if lin_vel_point is None else np.asarray(lin_vel_point[t1], dtype=float).reshape(NV, 1)
         upd = 0.0
         for it in range(int(vel_pcrd_stps) + int(vel_nwtn_stps)):
             newton = it >= int(vel_pcrd_stps)

@@ -45,6 +45,12 @@ class NpyStore:
             raise IOError("no stored array " + path)
         return np.load(path)
 
+    def remove_matching(self, prefix, infix):
+        """Delete the stored arrays ``prefix*infix*`` (``glob`` + ``os.remove``, optcont_main.py:207-208)."""
+        import glob
+        for f in glob.glob(glob.escape(prefix) + "*" + glob.escape(infix) + "*.npy"):
+            os.remove(f)
+
 
 class MemoryStore(dict):
     """In-memory stand-in for the file cache (tests, benchmarks)."""
@@ -56,6 +62,10 @@ class MemoryStore(dict):
         if name not in self:
             raise IOError("no stored array " + name)
         return self[name]
+
+    def remove_matching(self, prefix, infix):
+        for k in [k for k in self if k.startswith(prefix) and infix in k[len(prefix):]]:
+            del self[k]
 
 
 def solve_flow_daeric(mmat=None, amat=None, jmat=None, bmat=None,
