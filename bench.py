@@ -189,7 +189,7 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
         "update_dots": ("ricadi::cols_update_dots_kernel (+reduce_partials)", G * ((nvec * b + 16.0) * n * m)),
         # ... + w read + the new vector in storage precision (+ its FP64 copy unless the preconditioner reads the FP16 one)
         "update": ("ricadi::cols_update16_hess_kernel (last Arnoldi pass + Hessenberg / Givens update)" if b == 2 and m == 16
-                   and os.environ.get("RICADI_HESS_FUSE", "1") != "0" else "ricadi::cols_update_kernel",
+                   else "ricadi::cols_update_kernel",
                    G * ((nvec * b + 8.0 + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
     }
     out = {}
@@ -229,7 +229,7 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
         "pc_rect": ("ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl) if rk else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
                     G * (pb_ * nb * 32.0 * max(rk, 32) + (8.0 + 8.0) * nv * m + 4.0 * n * m + 8.0 * npn * m + 8.0 * kc0 * m)),
     }
-    if m == 16 and os.environ.get("RICADI_PFUSE", "1") != "0" and info["bs"] == 32 and npn > 0:
+    if m == 16 and info["bs"] == 32 and npn > 0:
         # K2p: the three launches of the pressure step are ONE kernel; its bytes: J once (shared by the groups), per
         # group the Schur block inverses, the gathered velocity rows of z, r_p, the coarse correction and z_p (+ plain
         # copy for the J^T product and the FP32 copy)

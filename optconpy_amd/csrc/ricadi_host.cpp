@@ -322,8 +322,6 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   // within kSbMaxCols, so that the x tile of a block fits the LDS budget.
   {
     int kSbMaxRows = 32, kSbMaxCols = 152;   // 152 x 16 x 8 B tiles: 8 workgroups per CU fit the 160 KB LDS
-    if (const char* e = getenv("RICADI_SB_MAXCOLS")) kSbMaxCols = std::max(48, atoi(e));
-    if (const char* e = getenv("RICADI_SB_MAXROWS")) kSbMaxRows = std::max(1, std::min(32, atoi(e)));
     std::vector<int> order;
     order.reserve(n);
     for (int q = 0; q < nv; ++q) order.push_back(hs.bv_rows[q]);
@@ -366,7 +364,7 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       // consecutive local rows together (DPP broadcasts need all lanes), i.e. through the LONGEST of the four;
       // sorted by (half-)chunk count the four rows of a wave-pass need the same number of steps almost everywhere
       // (P2 vertex / edge-midpoint rows differ by a factor two in their entry counts).  RICADI_SB_SORT=0: visit order.
-      static const bool sort_rows_by_len = !(getenv("RICADI_SB_SORT") && atoi(getenv("RICADI_SB_SORT")) == 0);
+      const bool sort_rows_by_len = true;
       if (sort_rows_by_len)
         std::stable_sort(brows.begin(), brows.end(), [&](int a, int b) {
           return (hs.s_rp[a + 1] - hs.s_rp[a] + 7) / 8 > (hs.s_rp[b + 1] - hs.s_rp[b] + 7) / 8;   // half chunks
@@ -377,7 +375,7 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
       // rows have opposite parity (LDS bank = (byte / 4) mod 64).  Even local rows therefore list
       // their even tile rows first, odd local rows their odd ones: the parities differ wherever both
       // rows are in their first or both in their second part.
-      static const bool parity_order = !(getenv("RICADI_SB_PARITY") && atoi(getenv("RICADI_SB_PARITY")) == 0);
+      const bool parity_order = true;
       int ql = 0;
       for (int row : brows) {
         for (int pass = 0; pass < 2; ++pass)

@@ -275,14 +275,6 @@ void launch_gmres_hess_b(hipStream_t st, const GroupTab& gt, int m, int j, int r
 // store per element); the Hessenberg kernel then writes h1 + h2 to `hsum` and the final update uses those on w
 bool update_dots_keeps_w(int m, bool fp16_basis, int nvec_max);
 void set_update_dots_nostore(bool v);
-// the two dot passes of the hot Arnoldi path (FP16 basis, m = 16) with atomic accumulation: no partial rows, no
-// reduce launches; `out` must be zero at launch (the Hessenberg kernel clears zero_h1 / zero_h2 as it goes)
-bool dots_atomic_ok(int m);
-void launch_cols_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
-                               size_t vstride, size_t gsb, const double* w, size_t gsw, double* out, size_t gso);
-void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
-                                      size_t vstride, size_t gsb, const double* h, size_t gsh, double* w, size_t gsw,
-                                      double* out, size_t gso);
 void launch_gmres_backsolve_b(hipStream_t st, const GroupTab& gt, int m, const GroupInts& k,
                               int restart, const double* H, const double* g, double* y);
 void launch_cols_update_bk(hipStream_t st, const GroupTab& gt, int nrows, int m, const GroupInts& nvec,

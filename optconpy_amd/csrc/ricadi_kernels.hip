@@ -198,14 +198,7 @@ __global__ __launch_bounds__(256) void spmm_kernel_v2(
   }
 }
 
-static int spmm_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("RICADI_SPMM");
-    v = (e && e[0] == '1') ? 1 : 2;
-  }
-  return v;
-}
+static int spmm_variant() { return 2; }
 
 static void spmm_dispatch(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
                           const int* ci, const GroupPtrs& vals, const double* x, int ldx,
@@ -724,7 +717,7 @@ void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* al
   // blocks alone do not fill the chip
   int ysplit = 1;
   while (ysplit < gt.ng && (long)nblk * ysplit < 900 && ysplit < 8) ysplit *= 2;
-  static const int ys_env = getenv("RICADI_MS_YSPLIT") ? atoi(getenv("RICADI_MS_YSPLIT")) : 0;
+  static const int ys_env = 0;
   if (ys_env > 0) ysplit = ys_env;
   ysplit = std::min(ysplit, gt.ng);
   const dim3 grid(nblk, ysplit, 1), block(256);
@@ -1394,12 +1387,8 @@ __global__ __launch_bounds__(256) void cols_update_f4_kernel(
     op[1] = make_double2(a[2], a[3]);
   }
 }
-// RICADI_ARNOLDI16: bit mask of the launch classes that use these kernels (1 dots, 2 update+dots, 4 update;
-// 8: also for panels of 8, 24 and 32 columns)
-static bool arnoldi16(int which) {
-  static const int mask = getenv("RICADI_ARNOLDI16") ? atoi(getenv("RICADI_ARNOLDI16")) : 15;
-  return (mask & which) != 0;
-}
+// the launch classes that use these kernels (1 dots, 2 update+dots, 4 update; 8: also for panels of 8, 24 and 32 columns)
+static bool arnoldi16(int) { return true; }
 
 template <class BT>
 static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m, int nvec,
@@ -1457,30 +1446,10 @@ void launch_cols_dots_b(hipStream_t st, const GroupTab& gt, int nrows, int m, in
   cols_dots_impl(st, gt, nrows, m, nvec, basis, vstride, gsb, w, gsw, want_self, partial, gsp, out,
                  gso);
 }
-// The two dot passes of the hot Arnoldi path (FP16-stored basis, 16-column panels) WITHOUT partial rows and
-// reduce launches: every workgroup adds its sums to the result with FP64 atomics.  `out` (group stride gso, (nvec (+1))
-// x 16 doubles used) must be zero when the kernel starts -- the Hessenberg kernel clears what it has consumed
-// (launch_gmres_hess_b, zero_h1 / zero_h2).  MEASURED SLOWER and therefore OFF by default (RICADI_DOTS_ATOMIC=1 switches
-// it on): 468 workgroups per group add to the same 112-192 addresses, and contended FP64 atomics serialise at the
-// memory side -- cfg2 step 393 -> 741 ms (same-call A/B, round 3), although two launches per iteration disappear.
-bool dots_atomic_ok(int m) {
-  static const bool on = getenv("RICADI_DOTS_ATOMIC") && atoi(getenv("RICADI_DOTS_ATOMIC")) == 1;
-  return on && m == 16 && arnoldi16(1) && arnoldi16(2);
-}
-void launch_cols_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
-                               size_t vstride, size_t gsb, const double* w, size_t gsw, double* out, size_t gso) {
-  if (nvec <= 0 || gt.ng <= 0) return;
-  hipLaunchKernelGGL(cols_dots16_kernel<true>, dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec,
-                     basis, vstride, gsb, w, gsw, 0, out, gso);
-}
-void launch_cols_update_dots16_atomic(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
-                                      size_t vstride, size_t gsb, const double* h, size_t gsh, double* w, size_t gsw,
-                                      double* out, size_t gso) {
-  if (gt.ng <= 0) return;
-  hipLaunchKernelGGL((cols_update_dots16_kernel<true, true>), dim3(dots_num_blocks(nrows), 1, gt.ng), dim3(256),
-                     (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb, h, gsh,
-                     w, gsw, out, gso);
-}
+// (The two dot passes with FP64 atomic accumulation instead of partial rows + reduce launches -- two launches fewer per
+// iteration -- were measured in round 3: 468 workgroups per group add to the same 112-192 addresses, contended FP64 atomics
+// serialise at the memory side, cfg2 step 393 -> 741 ms.  The launchers are gone; the kernels keep their ATOMIC template
+// parameter at false.)
 void launch_cols_dots(hipStream_t st, int nrows, int m, int nvec, const double* basis,
                       size_t vstride, const double* w, int want_self, double* partial,
                       double* out) {
@@ -1551,8 +1520,7 @@ __global__ __launch_bounds__(256) void cols_update_dots_kernel(
 // set by update_dots_keeps_w(): the 16-column FP16 launch leaves w untouched (see cols_update_dots16_kernel)
 static thread_local bool g_update_dots_nostore = false;
 bool update_dots_keeps_w(int m, bool fp16_basis, int nvec_max) {
-  static const bool on = !(getenv("RICADI_KEEP_W") && atoi(getenv("RICADI_KEEP_W")) == 0);
-  return on && fp16_basis && m == 16 && arnoldi16(2) && arnoldi16(4) &&
+  return fp16_basis && m == 16 && arnoldi16(2) && arnoldi16(4) &&
          (size_t)(DOT_ROWS * 18 + nvec_max * 16) * sizeof(double) <= 48 * 1024;
 }
 void set_update_dots_nostore(bool v) { g_update_dots_nostore = v; }
@@ -2117,7 +2085,7 @@ static void block_apply_impl(hipStream_t st, const GroupTab& gt, int bs, int nbl
   // Only where the launch is latency bound (few waves: the Schur sweep of cfg2 has 110 blocks x 16 groups): with many
   // waves the rectangle kernel's 152 VGPRs cost more than its grouped loads gain (velocity-sized sweep at cfg2:
   // 43 vs 33 us).
-  static const bool via_rect = !(getenv("RICADI_BA_PLAIN") && atoi(getenv("RICADI_BA_PLAIN")) != 0);
+  static const bool via_rect = true;
   if (via_rect && !ci.rp && bs == 32 && (long)nblocks * gt.ng <= 8192) {
     block_apply_rect_impl(st, gt, 32, 32, nblocks, bptr, rows, bptr, rows, inv, in, ldi, gsi, out, ldo, gso, m,
                           subtract, pa);
@@ -4506,7 +4474,7 @@ __global__ __launch_bounds__(256) void cols_update16_hess_kernel(
   }
 }
 bool update_hess_fused_ok(int m, bool fp16_basis) {
-  static const bool on = !(getenv("RICADI_HESS_FUSE") && atoi(getenv("RICADI_HESS_FUSE")) == 0);
+  static const bool on = true;
   return on && fp16_basis && m == 16 && arnoldi16(4);
 }
 void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,

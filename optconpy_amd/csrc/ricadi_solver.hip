@@ -50,8 +50,6 @@ struct DArr {
   ~DArr() { release(); }
   void release() {
     if (p) {
-      static const bool dbg = getenv("RICADI_DEBUG_FREE") != nullptr;
-      if (dbg) fprintf(stderr, "[ricadi free] %zu bytes\n", n * sizeof(T));
       (void)hipFree(p);
     }
     p = nullptr;
@@ -444,7 +442,7 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
     c->basis.alloc((size_t)(restart + 1) * nm);
     c->basisf.release();
   }
-  c->flex = !(getenv("RICADI_FGMRES") && atoi(getenv("RICADI_FGMRES")) == 0);
+  c->flex = true;      // flexible GMRES: Z_j = P^-1 v_j kept (FP32), x += Z y at the cycle end
   if (c->flex) c->zbasisf.alloc((size_t)restart * nm);
   else c->zbasisf.release();
   c->wv.alloc(nm);
@@ -824,8 +822,7 @@ static bool ms_pays(const ricadi_ctx* c, int ng, size_t nnz) {
 // gsx / gsy / gsr: group strides of x, y, r.
 // The LDS-tiled kernels serve panels of width m (else the CSR kernel runs)
 static bool saddle_tiled(const ricadi_ctx* c, int m) {
-  static const int force_csr = getenv("RICADI_SPMM") ? 1 : 0;
-  return c->sb_ok && !force_csr &&
+  return c->sb_ok &&
          spmm_blocked_lds_bytes(m, c->sb_max_cols, c->sb_max_nnz) <= (size_t)40 * 1024;
 }
 // x32 (optional): FP32 copy of x with the same leading dimension and group stride; the tiled kernels read it
@@ -867,9 +864,7 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
 
 // Does the GMRES iteration apply the operator to the FP32-stored Z_j (RICADI_X32=0: to the FP64 z)?
 static bool operator_reads_x32(const ricadi_ctx* c, int m) {
-  static const bool x32_on = !(getenv("RICADI_X32") && atoi(getenv("RICADI_X32")) == 0);
-  const bool flex = !(getenv("RICADI_FGMRES") && atoi(getenv("RICADI_FGMRES")) == 0);
-  return flex && x32_on && saddle_tiled(c, m);
+  return c->flex && saddle_tiled(c, m);
 }
 
 // y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
@@ -900,17 +895,14 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
 // r16: the same residual panel as stored in FP16 (the current Krylov vector; group stride gsr); where the folded
 // path runs, its three readers of r take the 2-byte copy (exactly the same values) and r itself is not touched.
 static bool precond_folds(const ricadi_ctx* c) {
-  static const bool fold = getenv("RICADI_NO_FOLD") == nullptr;
-  return fold && c->kc > 0 && c->ady_ok && c->np > 0;
+  return c->kc > 0 && c->ady_ok && c->np > 0;
 }
 static bool precond_reads_h16_static(const ricadi_ctx* c) {
-  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
-  return h16_on && precond_folds(c);
+  return precond_folds(c);
 }
 // Does the GMRES iteration hand the preconditioner the FP16-stored vector (RICADI_H16=0: the FP64 copy)?
 static bool precond_reads_h16(const ricadi_ctx* c, int m) {
-  static const bool h16_on = !(getenv("RICADI_H16") && atoi(getenv("RICADI_H16")) == 0);
-  return h16_on && c->basis16 && m <= 16 && precond_folds(c);
+  return c->basis16 && m <= 16 && precond_folds(c);
 }
 static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_t gsr, double* z,
                           float* z32 = nullptr, size_t gs32 = 0, bool only32 = false,
@@ -927,9 +919,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   auto on = [&](int stage) { return c->pc_stage < 0 || c->pc_stage == stage; };
   // the pressure step -- pressure rows of r - (S Y) e, J product, Schur sweep -- as ONE launch (K2p) for
   // 16-column panels (RICADI_PFUSE=0: the three launches of round 2)
-  static const bool pfuse_env = !(getenv("RICADI_PFUSE") && atoi(getenv("RICADI_PFUSE")) == 0);
-  static const bool fuse_jt_env = getenv("RICADI_NOFUSE_JT") == nullptr;
-  const bool fusedp = pfuse_env && fuse_jt_env && np > 0 && m == 16 && c->bs == 32;
+  const bool fusedp = np > 0 && m == 16 && c->bs == 32;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
@@ -974,7 +964,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       // velocity sweep instead, like the J^T product below, was measured slower: 249 vs
       // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
       // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
-      static const bool sy_csr = getenv("RICADI_SY_CSR") != nullptr;
+      const bool sy_csr = false;
       if (c->syb_ok && !sy_csr && ms_pays(c, gt.ng, c->snnz) &&
           spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
         launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
@@ -1041,8 +1031,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
                     rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
-    static const bool fuse_jt = getenv("RICADI_NOFUSE_JT") == nullptr;
-    static const bool rect = getenv("RICADI_NO_RECT") == nullptr;
+    const bool fuse_jt = true, rect = true;
     // Fused variant: the pressure sweep writes z_p already WITH its coarse part and keeps
     // the plain z_p (the operand of the J^T product below) in tp -- in place: a wave
     // reads its block's rows of tp before it writes them, blocks are disjoint.
@@ -1177,11 +1166,10 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   // the preconditioner reads the current vector from the FP16 basis itself; its FP64 copy is then not written
   const bool h16 = precond_reads_h16(c, m);
   // dot passes with atomic accumulation (no partial rows, no reduce launches): FP16 basis, 16 columns
-  const bool adots = b16 && dots_atomic_ok(m);
   // w is not rewritten between the two Gram-Schmidt passes: the final update subtracts V (h1 + h2) from the original w
-  const bool keepw = !adots && update_dots_keeps_w(m, b16, restart);
+  const bool keepw = update_dots_keeps_w(m, b16, restart);
   // last Arnoldi pass and Hessenberg update in ONE launch (K3h)
-  const bool fuseh = !adots && update_hess_fused_ok(m, b16);
+  const bool fuseh = update_hess_fused_ok(m, b16);
   const size_t resbuf = (size_t)c->wcols;                    // doubles between the two residual-estimate buffers
   struct NoStoreScope {
     explicit NoStoreScope(bool v) { set_update_dots_nostore(v); }
@@ -1229,7 +1217,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
   // iteration: three passes over it) small; a cycle that gains less than a factor 10
   // on some column lengthens the following ones, up to gmres_restart.
-  static const int cyc0 = getenv("RICADI_CYC0") ? std::max(2, atoi(getenv("RICADI_CYC0"))) : 10;
+  const int cyc0 = 10;
   int cyc = std::min(restart, cyc0);
   std::vector<double> rstart(GM, 0.0);
   Tick tkc;
@@ -1291,8 +1279,6 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
     // Few groups left (the stragglers of the sweep): the launches are latency bound then and
     // the traffic of a longer Krylov basis costs nothing -- let the cycles run to the full
     // restart length instead of throwing the subspace away every `cyc` vectors.
-    static const int tail_groups = getenv("RICADI_TAIL_GROUPS") ? atoi(getenv("RICADI_TAIL_GROUPS")) : 0;
-    if ((int)next.size() <= tail_groups) cyc = restart;
     act.swap(next);
     if (act.empty()) break;
     bt.set(act);
@@ -1305,11 +1291,6 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
     live = act;
     for (int g : act) kk[g] = 0;
     lapc(c->t_cyc);
-    if (adots) {
-      HIPCHK(hipMemsetAsync(c->h1.p, 0, sizeof(double) * gsh * G, st));
-      HIPCHK(hipMemsetAsync(c->h2.p, 0, sizeof(double) * gsh * G, st));
-      HIPCHK(hipMemsetAsync(c->h2.p + h2buf, 0, sizeof(double) * gsh * G, st));
-    }
     for (int j = 0; j < cyc && !live.empty(); ++j) {
       bt.set(live);
       const double* vj = (b32 || b16) ? c->vcur.p : V + (size_t)j * vs;
@@ -1320,11 +1301,8 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       float* zj = flex ? c->zbasisf.p + (size_t)j * vs : nullptr;
       precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32, h16 ? Vh + (size_t)j * vs : nullptr);
       op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr);
-      double* h2cur = adots ? c->h2.p + (size_t)(j & 1) * h2buf : c->h2.p;
-      if (adots) {
-        launch_cols_dots16_atomic(st, bt.tab, n, j + 1, Vh, vs, nm, c->wv.p, nm, c->h1.p, gsh);
-        launch_cols_update_dots16_atomic(st, bt.tab, n, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, h2cur, gsh);
-      } else if (b16) {
+      double* h2cur = c->h2.p;
+      if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
                            c->h1.p, gsh);
         launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm,
@@ -1351,8 +1329,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
                                     c->resid.p + (size_t)((j + 1) & 1) * resbuf, c->bnorm2.p, tol, cur);
       else
         launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
-                            c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, adots ? c->h1.p : nullptr,
-                            adots ? c->h2.p + (size_t)((j + 1) & 1) * h2buf : nullptr,
+                            c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, nullptr, nullptr,
                             keepw ? c->h2.p + h2buf : nullptr);
       if (fuseh) {
       } else if (b16)
@@ -1683,7 +1660,7 @@ static int storage_level(const ricadi_ctx* c) {
 static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
                               size_t gsb, double* x, int m, bool lowrank, double* relres_host,
                               GmresResult* res) {
-  static const bool no_net = getenv("RICADI_NO_ESCALATION") != nullptr;
+  const bool no_net = false;
   hipStream_t st = c->st;
   const bool plain = !(lowrank && c->q > 0);
   const bool shared = (gsb == 0 || G == 1) && plain && c->rec_depth > 0;
@@ -2259,8 +2236,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   std::vector<double> be(G, 1.0), coef;
   std::vector<ShiftData*> sds(G);
   std::vector<GmresResult> res(G);
-  static const bool sync_recompress = getenv("RICADI_SYNC_RECOMPRESS") != nullptr;
-  static const bool narrow_tail = getenv("RICADI_FULL_SWEEPS") == nullptr;
+  const bool sync_recompress = false, narrow_tail = true;
   AsyncRecompress job(c);
   int steps = 0;
   // relative block norm of the last two visits of every position of the shift cycle
@@ -2390,8 +2366,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     HIPCHK(hipMemcpyAsync(c->sweep_coef.p, coef.data(), sizeof(double) * (size_t)Gs * nslot * m,
                           hipMemcpyHostToDevice, st));
     // Z <- [Z, U R^-1]: block j = sum_i rinv[i][j] U_i, with its squared norm
-    static const bool fused_blocks = getenv("RICADI_SWEEP_UNFUSED") == nullptr;
-    const bool combined = fused_blocks && sweep_combine_ok(m, nslot, Gs);
+    const bool combined = sweep_combine_ok(m, nslot, Gs);
     if (combined) {
       // all blocks and their norms in two launches (K4s)
       c->sweep_part.ensure(sweep_combine_partial_len(nv, m, Gs));
@@ -2715,7 +2690,7 @@ static int compress_pchol_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, 
 // wide for it), then the Gram + eigensolver route.
 static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
                            double* dOut) {
-  static const bool eig = getenv("RICADI_RECOMPRESS_EIG") != nullptr;
+  const bool eig = false;
   if (!eig) {
     const int k = compress_pchol_exec(c, ex, dZ, cz, ldz, rel, dOut);
     if (k >= 0) return k;
@@ -2860,8 +2835,8 @@ static void panel_cholqr2_wide(ricadi_ctx* c, const double* P, int ldp, int n, i
 static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
                          double* R, int split) {
   hipStream_t st = c->st;
-  static const bool hh_only = getenv("RICADI_TSQR_HOUSEHOLDER") != nullptr;
-  static const int pw_env = getenv("RICADI_QR_PANEL") ? atoi(getenv("RICADI_QR_PANEL")) : 128;
+  const bool hh_only = false;
+  const int pw_env = 128;
   const int PWF = pw_env <= 32 ? 32 : 128;          // panel width of the fast path
   TArr<double> P(c->pool, (size_t)n * PWF), C1(c->pool, (size_t)kk * PWF), C2(c->pool, (size_t)kk * PWF);
   TArr<double> Q1(c->pool), Gw(c->pool), Tw(c->pool);
@@ -3108,11 +3083,11 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
     if (J.ci[k] < 0 || J.ci[k] >= nv) throw ricadi::HipError{"J: column index out of range"};
   HostSetup hs;
   if (!c->borrowed)
-    c->levels = getenv("RICADI_LEVELS") ? std::max(2, atoi(getenv("RICADI_LEVELS"))) : std::max(2, c->opts.max_levels);
+    c->levels = std::max(2, c->opts.max_levels);
   // smoothed aggregation of the velocity prolongation (two-level setups, folded preconditioner cycle only);
   // RICADI_SA=0 switches it off, RICADI_SA=<omega> sets the damping
   double sa_omega = getenv("RICADI_SA") ? atof(getenv("RICADI_SA")) : 0.5;
-  if (c->borrowed || np == 0 || getenv("RICADI_NO_FOLD") || c->opts.bj_block != 32) sa_omega = 0.0;
+  if (c->borrowed || np == 0 || c->opts.bj_block != 32) sa_omega = 0.0;
   build_setup(A, E, J, c->opts, hs, c->levels, sa_omega);
   if (hs.sa) {
     // the folded first sweep takes per-block dense slices of S*P of at most 64 columns
@@ -3144,8 +3119,8 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
     ch->opts = c->opts;
     // aggregates of the child level (in units of ITS dofs = this level's aggregates); they double
     // until the last level's dense inverse fits coarse_max
-    ch->opts.agg_v = getenv("RICADI_L2_AV") ? std::max(1, atoi(getenv("RICADI_L2_AV"))) : 2;
-    ch->opts.agg_p = getenv("RICADI_L2_AP") ? std::max(1, atoi(getenv("RICADI_L2_AP"))) : 1;
+    ch->opts.agg_v = 2;
+    ch->opts.agg_p = 1;
     ch->opts.coarse_max = c->opts.coarse_max + c->opts.coarse_max / 8;   // pairs do not always pair up
     ch->levels = 2;
     ch->precond32 = c->precond32;
@@ -3335,22 +3310,6 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
       for (int j = 0; j < nc; ++j) {
         cols2[(size_t)b * mc + j] = hs.sb_cols[c0 + j];
         colsm2[(size_t)b * mc + j] = hs.kc > 0 ? hs.aggof[hs.sb_cols[c0 + j]] : -1;
-      }
-    }
-    // developer ablations of the tile SpMM (wrong results, timing only):
-    //   RICADI_ABL=c: every block gathers the same x rows; =v: every block reads block 0's
-    //   matrix slice; =r: every block writes the same y rows
-    if (const char* e = getenv("RICADI_ABL")) {
-      for (int b = 0; b < nb; ++b) {
-        if (strchr(e, 'c'))
-          for (int j = 0; j < mc; ++j)
-            if (cols2[(size_t)b * mc + j] >= 0) cols2[(size_t)b * mc + j] = j;
-        if (strchr(e, 'v'))
-          for (int q = 0; q <= 32; ++q)
-            rp2[(size_t)b * 33 + q] = std::min(rp2[q], rp2[32]);
-        if (strchr(e, 'r'))
-          for (int q = 0; q < 32; ++q)
-            if (rows2[(size_t)b * 32 + q] >= 0) rows2[(size_t)b * 32 + q] = q;
       }
     }
     c->sb_rows2.upload(rows2, st);
@@ -3966,21 +3925,19 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
                               -1.0, 1.0, m, c->syb_max_cols);
         break;
       case 5:
-        if (b16 && dots_atomic_ok(m)) launch_cols_dots16_atomic(st, gt, n, nvec, Vh, vs, nm, c->wv.p, nm, c->h1.p, gsh);
-        else if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else if (b32) launch_cols_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else launch_cols_dots_b(st, gt, n, m, nvec, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         break;
       case 6:
-        set_update_dots_nostore(!dots_atomic_ok(m) && update_dots_keeps_w(m, b16, restart));   // as the iteration launches it
-        if (b16 && dots_atomic_ok(m)) launch_cols_update_dots16_atomic(st, gt, n, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->h2.p, gsh);
-        else if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        set_update_dots_nostore(update_dots_keeps_w(m, b16, restart));   // as the iteration launches it
+        if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else if (b32) launch_cols_update_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         set_update_dots_nostore(false);
         break;
       case 7:
-        if (b16 && !dots_atomic_ok(m) && update_hess_fused_ok(m, b16))     // as the iteration launches it: with the Hessenberg update
+        if (b16 && update_hess_fused_ok(m, b16))     // as the iteration launches it: with the Hessenberg update
           launch_cols_update16_hess_b(st, gt, n, nvec, Vh, vs, nm, c->h1.p, c->h2.p, gsh, update_dots_keeps_w(m, b16, restart) ? 1 : 0,
                                       c->wv.p, nm, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm,
                                       nvec - 1, restart, c->H.p, c->cs.p, c->sn.p, c->g.p, c->resid.p, c->resid.p + c->wcols,
@@ -4240,8 +4197,7 @@ static void ric_newtonadi_run(ricadi_ctx* c, const double* shifts, int ns, const
   if (p2.compress_cols <= 0) {
     // columns the factor may grow by before it is recompressed (RICADI_COMPRESS_COLS overrides): rocSOLVER's
     // tridiagonalisation is launch bound at these sizes (~32 us per column), so fewer, larger eigenproblems are cheaper
-    static const int cc = getenv("RICADI_COMPRESS_COLS") ? std::max(64, atoi(getenv("RICADI_COMPRESS_COLS"))) : 512;
-    p2.compress_cols = cc;
+    p2.compress_cols = 512;
   }
   double upd = 0, updrel = 0;
   long adi_total = 0, gm_total = 0, sol_total = 0, nonconv = 0, sweep_total = 0;
