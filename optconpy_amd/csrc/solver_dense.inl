@@ -1,0 +1,364 @@
+// solver_dense.inl -- compression, recompression by pivoted Cholesky, block QR / TSQR, gain.
+// Part of ricadi_solver.hip (one translation unit; included there in order).
+
+// ---- compression: Gram matrix on the matrix cores, eigendecomposition, Z * V_k -----
+// dZ: NV x cz (ld = ldz).  Returns k and writes Zc (NV x k, ld = k) into dOut
+// (which must hold NV*cz doubles).  Singular values (descending) to sv_host.
+static Exec main_exec(ricadi_ctx* c) {
+  Exec ex;
+  ex.st = c->st;
+  ex.rb = c->rb;
+  ex.pool = &c->pool;
+  ex.info = c->info.p;
+  return ex;
+}
+
+// Gram route of the compression on the given execution resources:  G = Z^T Z on the FP64
+// matrix cores, symmetric eigendecomposition (rocSOLVER), Zc = Z V_k.  Returns k; dOut is
+// NV x k (ld = k).  Synchronises ex.st before it returns.
+static int compress_gram_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz,
+                              double thresh, int kmax, bool thresh_relative, double* dOut,
+                              std::vector<double>* sv_host) {
+  hipStream_t st = ex.st;
+  if (cz == 0) return 0;
+  TArr<double> G(*ex.pool, (size_t)cz * cz), ev(*ex.pool, cz), work(*ex.pool, cz), sel(*ex.pool);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
+  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
+  RBCHK(rocsolver_dsyevd(ex.rb, rocblas_evect_original, rocblas_fill_upper, cz, G.p, cz, ev.p,
+                         work.p, ex.info));
+  std::vector<double> lam(cz);
+  HIPCHK(hipMemcpyAsync(lam.data(), ev.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  // eigenvalues ascending; singular values descending
+  std::vector<double> sv(cz);
+  for (int i = 0; i < cz; ++i) sv[i] = std::sqrt(std::max(lam[cz - 1 - i], 0.0));
+  int k = std::min(cz, c->nv);
+  if (thresh >= 0.0) {
+    const double t = thresh_relative ? thresh * sv[0] : thresh;
+    int cnt = 0;
+    while (cnt < cz && sv[cnt] > t) ++cnt;
+    k = std::min(k, cnt);
+  }
+  if (kmax > 0) k = std::min(k, kmax);
+  if (sv_host) *sv_host = sv;
+  if (k == 0) return 0;
+  // row-major view of syevd's output: row j = eigenvector j (ascending); the cz x k
+  // selection of the k largest is formed on the device
+  sel.alloc((size_t)cz * k);
+  launch_select_evecs(st, cz, k, G.p, sel.p);
+  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
+  HIPCHK(hipStreamSynchronize(st));
+  return k;
+}
+
+// Recompression without an eigensolver (round 3; the route of the INTERNAL recompressions, which need
+// no singular values -- only Zc Zc^T = Z Z^T to rounding):
+//   G = Z^T Z (MFMA);  pivoted Cholesky  G ~ R^T R,  R k x cz, stopped at rel^2 of the first pivot
+//   (the error of a stopped pivoted Cholesky is the remaining Schur complement, <= its trace);
+//   then the rows of R are orthonormalised: with H = R R^T = L L^T the matrix V^T = L^-1 R has orthonormal
+//   rows spanning the row space of R, and Zc = Z V, Zc Zc^T = Z (V V^T) Z^T is Z Z^T up to that Schur
+//   complement.  chol(H) and the triangular solve are ONE more pivoted Cholesky, of the augmented matrix
+//   [H | R] (its pivoting also drops what the first pass kept beyond the tolerance: the final column
+//   count equals the eigensolver route's, measured +-1).  Even where L is ill-conditioned the product
+//   V V^T is the projector to rounding (the CholQR argument: the error is that of H = L L^T, eps ||H||).
+// rocSOLVER's dsyevd on the same Gram matrix was ~4000 launches (12-16 ms) per call; this is ~60.
+// Returns k; dOut is NV x k (ld k); synchronises ex.st.  Returns -1 when the matrix is too wide for the
+// panel kernel (the caller then takes the eigensolver route).
+static int compress_pchol_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                               double* dOut) {
+  hipStream_t st = ex.st;
+  if (cz == 0) return 0;
+  const int kcap = std::min(cz, c->nv);
+  if (pchol_block(cz) == 0 || pchol_block(cz + kcap) == 0) return -1;
+  const double tol = rel * rel;
+  TArr<double> G(*ex.pool, (size_t)cz * cz), R(*ex.pool, (size_t)kcap * cz), stt(*ex.pool, 8);
+  TArr<int> done(*ex.pool, (size_t)cz + kcap);
+  PcholState* s1 = reinterpret_cast<PcholState*>(stt.p);
+  PcholState* s2 = s1 + 1;
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * cz * cz, st));
+  HIPCHK(hipMemsetAsync(stt.p, 0, sizeof(double) * 8, st));
+  HIPCHK(hipMemsetAsync(done.p, 0, sizeof(int) * ((size_t)cz + kcap), st));
+  launch_gemm_tn(st, c->nv, cz, cz, dZ, ldz, dZ, ldz, G.p, cz);
+  {
+    const int nb = pchol_block(cz);
+    for (int r0 = 0; r0 < kcap; r0 += nb) {
+      launch_pchol_panel(st, G.p, cz, cz, cz, tol, kcap, s1, R.p, cz, done.p);
+      launch_pchol_trail(st, G.p, cz, cz, cz, s1, R.p, cz);
+    }
+  }
+  PcholState h1;
+  HIPCHK(hipMemcpyAsync(&h1, s1, sizeof(PcholState), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int k1 = h1.rank;
+  if (k1 <= 0) return 0;
+  // [H | R] with H = R R^T  (gemm_tn wants the tall operand: R^T, cz x k1)
+  const int nc2 = k1 + cz;
+  TArr<double> Rt(*ex.pool, (size_t)cz * k1), A2(*ex.pool, (size_t)k1 * nc2), R2(*ex.pool, (size_t)k1 * nc2);
+  launch_transpose(st, k1, cz, R.p, cz, Rt.p, k1);
+  HIPCHK(hipMemsetAsync(A2.p, 0, sizeof(double) * (size_t)k1 * nc2, st));
+  launch_gemm_tn(st, cz, k1, k1, Rt.p, k1, Rt.p, k1, A2.p, nc2);
+  launch_copy_cols(st, k1, cz, R.p, cz, 0, A2.p, nc2, k1, 1.0);
+  {
+    const int nb = pchol_block(nc2);
+    int* done2 = done.p + cz;
+    for (int r0 = 0; r0 < k1; r0 += nb) {
+      launch_pchol_panel(st, A2.p, nc2, k1, nc2, tol, k1, s2, R2.p, nc2, done2);
+      launch_pchol_trail(st, A2.p, nc2, k1, nc2, s2, R2.p, nc2);
+    }
+  }
+  PcholState h2;
+  HIPCHK(hipMemcpyAsync(&h2, s2, sizeof(PcholState), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int k = h2.rank;
+  if (k <= 0) return 0;
+  // V = (rows 0..k of the carried part)^T: cz x k;  Zc = Z V
+  TArr<double> V(*ex.pool, (size_t)cz * k);
+  launch_transpose(st, k, cz, R2.p + k1, nc2, V.p, k);
+  launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, V.p, k, dOut, k, 1.0, 0.0);
+  HIPCHK(hipStreamSynchronize(st));
+  return k;
+}
+
+// The internal recompressions: pivoted-Cholesky route unless RICADI_RECOMPRESS_EIG=1 (or the factor is too
+// wide for it), then the Gram + eigensolver route.
+static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
+                           double* dOut) {
+  const bool eig = false;
+  if (!eig) {
+    const int k = compress_pchol_exec(c, ex, dZ, cz, ldz, rel, dOut);
+    if (k >= 0) return k;
+  }
+  return compress_gram_exec(c, ex, dZ, cz, ldz, rel, 0, true, dOut, nullptr);
+}
+
+static int compress_dev(ricadi_ctx* c, const double* dZ, int cz, int ldz, double thresh, int kmax,
+                        bool thresh_relative, double* dOut, std::vector<double>* sv_host,
+                        bool use_qr) {
+  hipStream_t st = c->st;
+  if (cz == 0) return 0;
+  if (use_qr && cz <= c->nv) {
+    // Z = Q R (TSQR panels), R^T = U' S V'^T (rocSOLVER, column-major view of the
+    // row-major R), right singular vectors of R = U'; Zc = Z V_k.
+    TArr<double> Q(c->pool, (size_t)c->nv * cz), R(c->pool, (size_t)cz * cz), S(c->pool, cz),
+        U(c->pool, (size_t)cz * cz), E5(c->pool, cz);
+    block_qr_dev(c, dZ, ldz, c->nv, cz, Q.p, R.p);
+    RBCHK(rocsolver_dgesvd(c->rb, rocblas_svect_all, rocblas_svect_none, cz, cz, R.p, cz, S.p, U.p, cz,
+                           nullptr, 1, E5.p, rocblas_outofplace, c->info.p));
+    std::vector<double> sv(cz), Uh((size_t)cz * cz);
+    HIPCHK(hipMemcpyAsync(sv.data(), S.p, sizeof(double) * cz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(Uh.data(), U.p, sizeof(double) * cz * cz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int k = std::min(cz, c->nv);
+    if (thresh >= 0.0) {
+      const double t = thresh_relative ? thresh * sv[0] : thresh;
+      int cnt = 0;
+      while (cnt < cz && sv[cnt] > t) ++cnt;
+      k = std::min(k, cnt);
+    }
+    if (kmax > 0) k = std::min(k, kmax);
+    if (sv_host) *sv_host = sv;
+    if (k == 0) return 0;
+    // row jj of the row-major view of U' = right singular vector jj of R
+    std::vector<double> Ch((size_t)cz * k);
+    for (int jj = 0; jj < k; ++jj)
+      for (int i = 0; i < cz; ++i) Ch[(size_t)i * k + jj] = Uh[(size_t)jj * cz + i];
+    TArr<double> sel(c->pool, (size_t)cz * k);
+    HIPCHK(hipMemcpyAsync(sel.p, Ch.data(), sizeof(double) * cz * k, hipMemcpyHostToDevice, st));
+    launch_gemm_nn(st, c->nv, cz, k, dZ, ldz, sel.p, k, dOut, k, 1.0, 0.0);
+    HIPCHK(hipStreamSynchronize(st));
+    return k;
+  }
+  return compress_gram_exec(c, main_exec(c), dZ, cz, ldz, thresh, kmax, thresh_relative, dOut, sv_host);
+}
+
+// ---- K5: Householder TSQR tree and block QR ----------------------------------------
+// Q (n x w, leading dimension ldq) and R (w x w upper, row-major, written with leading
+// dimension ldr) of the n x w panel P (ldp), w <= 32.
+static void tsqr_dev(ricadi_ctx* c, const double* P, int ldp, int n, int w, double* Q, int ldq,
+                     double* R, int ldr) {
+  hipStream_t st = c->st;
+  std::vector<int> rows;        // rows of the matrix factorised at each level
+  rows.push_back(n);
+  while (tsqr_num_blocks(rows.back()) > 1) rows.push_back(tsqr_num_blocks(rows.back()) * 32);
+  const int L = (int)rows.size();
+  std::vector<TArr<double>> qloc, rst, qfin;
+  for (int l = 0; l < L; ++l) {
+    qloc.emplace_back(c->pool, (size_t)rows[l] * 32);
+    rst.emplace_back(c->pool, (size_t)tsqr_num_blocks(rows[l]) * 32 * 32);
+    qfin.emplace_back(c->pool);
+  }
+  for (int l = 0; l < L; ++l) {
+    launch_tsqr_local(st, rows[l], w, l == 0 ? P : rst[l - 1].p, l == 0 ? ldp : 32, qloc[l].p,
+                      rst[l].p);
+  }
+  // R of the top level; Q on the way down
+  launch_copy_cols(st, w, w, rst[L - 1].p, 32, 0, R, ldr, 0, 1.0);
+  const double* upper = qloc[L - 1].p;       // explicit Q of the top level (one block)
+  if (L == 1) {
+    launch_copy_cols(st, n, w, qloc[0].p, 32, 0, Q, ldq, 0, 1.0);
+  } else {
+    for (int l = L - 2; l >= 0; --l) {
+      double* dst;
+      int ld;
+      if (l == 0) {
+        dst = Q;
+        ld = ldq;
+      } else {
+        qfin[l].alloc((size_t)rows[l] * 32);
+        dst = qfin[l].p;
+        ld = 32;
+      }
+      // intermediate levels keep all 32 columns (ld 32); the final Q only w
+      launch_tsqr_apply(st, rows[l], l == 0 ? w : 32, qloc[l].p, upper, dst, ld);
+      upper = dst;
+    }
+    // tsqr_apply writes all 32 columns; columns >= w of Q are exact zeros
+  }
+  // no synchronisation: the temporaries go back to the context's pool and are reused in
+  // stream order
+}
+
+// One panel by Cholesky QR, twice (CholQR2): Gram matrices and Q = P T on the MFMA GEMMs,
+// the 32 x 32 Cholesky / triangular inverse in cholqr_small_kernel.  Raises c->flag[1] when
+// the panel is too ill-conditioned for it (the caller then redoes the factorisation with the
+// Householder TSQR tree).
+static void panel_cholqr2(ricadi_ctx* c, const double* P, int n, int w, double* Q, int ldq, double* R,
+                          int ldr) {
+  hipStream_t st = c->st;
+  TArr<double> G(c->pool, 1024), T1(c->pool, 1024), R1(c->pool, 1024), T2(c->pool, 1024),
+      R2(c->pool, 1024), Q1(c->pool, (size_t)n * 32);
+  int* flag = c->flag.p + 1;
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * 1024, st));
+  launch_gemm_tn(st, n, 32, 32, P, 32, P, 32, G.p, 32);
+  launch_cholqr_small(st, w, G.p, nullptr, T1.p, R1.p, flag);
+  launch_gemm_nn(st, n, 32, 32, P, 32, T1.p, 32, Q1.p, 32, 1.0, 0.0);
+  HIPCHK(hipMemsetAsync(G.p, 0, sizeof(double) * 1024, st));
+  launch_gemm_tn(st, n, 32, 32, Q1.p, 32, Q1.p, 32, G.p, 32);
+  launch_cholqr_small(st, w, G.p, R1.p, T2.p, R2.p, flag);
+  launch_gemm_nn(st, n, 32, w, Q1.p, 32, T2.p, 32, Q, ldq, 1.0, 0.0);
+  launch_copy_cols(st, w, w, R2.p, 32, 0, R, ldr, 0, 1.0);
+}
+
+// One panel of up to 128 columns by CholQR2 (round 3): both Gram matrices and both products Q = P T on the MFMA
+// GEMMs, Cholesky factor + triangular inverse of the 128 x 128 Gram matrix in one workgroup
+// (cholqr_wide_kernel).  P: n x w (ld ldp); Q1: scratch n x w (ld ldp); Q (ld ldq), R (ld ldr).
+static void panel_cholqr2_wide(ricadi_ctx* c, const double* P, int ldp, int n, int w, double* Q1, double* Q, int ldq,
+                               double* R, int ldr, double* G, double* T1, double* R1, double* T2, double* R2) {
+  hipStream_t st = c->st;
+  int* flag = c->flag.p + 1;
+  HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * 128 * 128, st));
+  launch_gemm_tn(st, n, w, w, P, ldp, P, ldp, G, 128);
+  launch_cholqr_wide(st, w, G, 128, T1, R1, flag);
+  launch_gemm_nn(st, n, w, w, P, ldp, T1, 128, Q1, ldp, 1.0, 0.0);
+  HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * 128 * 128, st));
+  launch_gemm_tn(st, n, w, w, Q1, ldp, Q1, ldp, G, 128);
+  launch_cholqr_wide(st, w, G, 128, T2, R2, flag);
+  launch_gemm_nn(st, n, w, w, Q1, ldp, T2, 128, Q, ldq, 1.0, 0.0);
+  launch_gemm_nn(st, w, w, w, R2, 128, R1, 128, R, ldr, 1.0, 0.0);        // R = R_2 R_1
+}
+
+// D = Q R for a tall n x kk matrix (ldd): block classical Gram-Schmidt with
+// re-orthogonalisation between panels (both passes on the FP64 MFMA GEMMs).  Inside a panel:
+// CholQR2 on the matrix cores -- panels of 128 columns (panel_cholqr2_wide; round 2: 32 columns,
+// ~20 dependent launches per panel, RICADI_QR_PANEL=32 restores it) when the panel allows it --
+// checked once, after the last panel -- else the whole factorisation is redone with 32-column panels
+// through the Householder TSQR tree (numerically rank-deficient panels, e.g. raw
+// ADI blocks; RICADI_TSQR_HOUSEHOLDER=1 forces it).  Q: n x kk (ld kk), R: kk x kk
+// row-major upper triangular.  No panel straddles column `split` (the update norm factorises [Z_new, Z_old]).
+static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
+                         double* R, int split) {
+  hipStream_t st = c->st;
+  const bool hh_only = false;
+  const int pw_env = 128;
+  const int PWF = pw_env <= 32 ? 32 : 128;          // panel width of the fast path
+  TArr<double> P(c->pool, (size_t)n * PWF), C1(c->pool, (size_t)kk * PWF), C2(c->pool, (size_t)kk * PWF);
+  TArr<double> Q1(c->pool), Gw(c->pool), Tw(c->pool);
+  if (PWF == 128) {
+    Q1.alloc((size_t)n * 128);
+    Gw.alloc(128 * 128);
+    Tw.alloc(4 * 128 * 128);
+  }
+  for (int attempt = hh_only ? 1 : 0; attempt < 2; ++attempt) {
+    const bool fast = attempt == 0;
+    const int PW = fast ? PWF : 32;
+    if (fast) HIPCHK(hipMemsetAsync(c->flag.p + 1, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(R, 0, sizeof(double) * kk * kk, st));
+    for (int c0 = 0, wnext = 0; c0 < kk; c0 += wnext) {
+      int w = std::min(PW, kk - c0);
+      if (c0 < split && c0 + w > split) w = split - c0;       // no panel straddles `split`
+      wnext = w;
+      if (PW == 32) HIPCHK(hipMemsetAsync(P.p, 0, sizeof(double) * (size_t)n * 32, st));   // 32-wide kernels read all 32
+      launch_copy_cols(st, n, w, D, ldd, c0, P.p, PW, 0, 1.0);
+      if (c0 > 0) {
+        for (int pass = 0; pass < 2; ++pass) {
+          double* C = pass == 0 ? C1.p : C2.p;
+          HIPCHK(hipMemsetAsync(C, 0, sizeof(double) * c0 * w, st));
+          launch_gemm_tn(st, n, c0, w, Q, kk, P.p, PW, C, w);
+          launch_gemm_nn(st, n, c0, w, Q, kk, C, w, P.p, PW, -1.0, 1.0);
+        }
+        launch_axpby(st, (size_t)c0 * w, 1.0, C2.p, 1.0, C1.p);
+        launch_copy_cols(st, c0, w, C1.p, w, 0, R, kk, c0, 1.0);
+      }
+      if (fast && PW == 128)
+        panel_cholqr2_wide(c, P.p, PW, n, w, Q1.p, Q + c0, kk, R + (size_t)c0 * kk + c0, kk, Gw.p, Tw.p,
+                           Tw.p + 16384, Tw.p + 2 * 16384, Tw.p + 3 * 16384);
+      else if (fast)
+        panel_cholqr2(c, P.p, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
+      else
+        tsqr_dev(c, P.p, 32, n, w, Q + c0, kk, R + (size_t)c0 * kk + c0, kk);
+    }
+    if (!fast) break;
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, c->flag.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!flag) break;
+    if (c->opts.verbose) fprintf(stderr, "[ricadi] block QR: ill-conditioned panel, Householder TSQR instead\n");
+  }
+}
+
+// || Z1 Z1^T - Z0 Z0^T ||_F  via an LQ factorisation of [Z1, Z0]^T (Householder,
+// rocSOLVER) -- no squaring, so updates far below 1e-8 relative are resolved.
+static double diff_zzt_fnorm(ricadi_ctx* c, const double* dZ1, int k1, const double* dZ0, int k0,
+                             double* x1norm) {
+  // D = [Z1, Z0] = Q R  (Householder TSQR panels, no squaring of the condition
+  // number);  D S D^T = Q (R S R^T) Q^T with S = diag(I_k1, -I_k0), so the norm
+  // is that of the small matrix R S R^T -- updates far below 1e-8 are resolved.
+  hipStream_t st = c->st;
+  const int kk = k1 + k0, nv = c->nv;
+  TArr<double> D(c->pool, (size_t)nv * kk), Q(c->pool, (size_t)nv * kk), R(c->pool, (size_t)kk * kk),
+      Rt(c->pool, (size_t)kk * kk), Rts(c->pool, (size_t)kk * kk), T(c->pool, (size_t)kk * kk);
+  launch_copy_cols(st, nv, k1, dZ1, k1, 0, D.p, kk, 0, 1.0);
+  if (k0 > 0) launch_copy_cols(st, nv, k0, dZ0, k0, 0, D.p, kk, k1, 1.0);
+  // panels never hold columns of both factors: Z1 ~ Z0 at convergence, and near-duplicate columns inside one
+  // panel would send the factorisation to the Householder fallback
+  block_qr_dev(c, D.p, kk, nv, kk, Q.p, R.p, k1);
+  std::vector<double> Th((size_t)kk * kk);
+  auto fro_of = [&](double sneg) {
+    // (S R^T)^T (R^T) = R S R^T  with the transposes formed explicitly (kk x kk)
+    launch_transpose_sign(st, kk, kk, 1.0, R.p, Rt.p);
+    launch_transpose_sign(st, kk, k1, sneg, R.p, Rts.p);
+    HIPCHK(hipMemsetAsync(T.p, 0, sizeof(double) * kk * kk, st));
+    launch_gemm_tn(st, kk, kk, kk, Rts.p, kk, Rt.p, kk, T.p, kk);
+    HIPCHK(hipMemcpyAsync(Th.data(), T.p, sizeof(double) * kk * kk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double f = 0.0;
+    for (double v : Th) f += v * v;
+    return std::sqrt(f);
+  };
+  if (x1norm) *x1norm = fro_of(0.0);     // S1 = diag(I, 0): || Z1 Z1^T ||_F
+  return fro_of(-1.0);
+}
+
+// K = E * (Z * (Z^T B))  (device);  dK is NV x nb
+static void gain_dev(ricadi_ctx* c, const DevCsr& Mt, const double* dZ, int cz, int ldz,
+                     const double* dB, int nb, double* dK) {
+  hipStream_t st = c->st;
+  TArr<double> ZtB(c->pool, (size_t)std::max(cz, 1) * nb), T(c->pool, (size_t)c->nv * nb);
+  HIPCHK(hipMemsetAsync(ZtB.p, 0, sizeof(double) * std::max(cz, 1) * nb, st));
+  launch_gemm_tn(st, c->nv, cz, nb, dZ, ldz, dB, nb, ZtB.p, nb);
+  launch_gemm_nn(st, c->nv, cz, nb, dZ, ldz, ZtB.p, nb, T.p, nb, 1.0, 0.0);
+  launch_spmm(st, c->nv, Mt.rp.p, Mt.ci.p, Mt.v.p, T.p, nb, nullptr, dK, nb, nullptr, 0, 1.0, 0.0,
+              nullptr, nb);
+  HIPCHK(hipStreamSynchronize(st));
+}
+
