@@ -251,6 +251,7 @@ struct ricadi_ctx {
   DArr<double> srcA, srcE, srcJ;
   DevCsr A, E, J, JT;
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
+  DArr<int> ps_meta;          // fused pressure step: {row, J range, (S Y) range} per (Schur block, row), stride 5
   DArr<double> bvA, bvE, jd_val;
   DArr<int> agg_ptr, agg_rows, aggof;
   // last velocity sweep in rectangular form: per velocity block the pressure dofs its rows touch

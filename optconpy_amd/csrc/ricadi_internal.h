@@ -385,17 +385,18 @@ void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a
                      const double* a2, double alpha, double beta, double* out);
 
 // K2p: the pressure step of the SIMPLE cycle fused into one launch (m = 16, 32 x 32 Schur blocks):
-//   out[rows_b] = inv_b (J z + (S Y)_p ec - r_p)[rows_b]  with the epilogue options of the Schur sweep (pa);
-// rows / jrp / syrp are pressure-local (syrp = NULL: no coarse term), z is the n x 16 panel whose velocity rows
-// are read, rp_ / rp16 the pressure rows of the residual (FP64 or FP16-stored), out the pressure rows of z.
-void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
-                            const GroupPtrsF& inv, const int* jrp, const int* jci, const double* jv, const double* z,
-                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+//   out[rows_b] = inv_b (J z + (S Y)_p ec - r_p)[rows_b]  with the epilogue options of the Schur sweep (pa).
+// meta: per (block, row of the block) five ints {pressure-local row or -1, J row range [k0, k1), (S Y) pressure-row
+// range [s0, s1)} at stride 5 (ricadi_ctx::ps_meta); with_sy = false: no coarse term; z is the n x 16 panel whose
+// velocity rows are read, rp_ / rp16 the pressure rows of the residual (FP64 or FP16-stored), out the pressure rows of z.
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrsF& inv, const int* jci, const double* jv, const double* z,
+                            size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                             const ProlongArgs& pa);
-void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
-                            const GroupPtrs& inv, const int* jrp, const int* jci, const double* jv, const double* z,
-                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrs& inv, const int* jci, const double* jv, const double* z,
+                            size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                             const ProlongArgs& pa);
 

@@ -1152,17 +1152,22 @@ void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int 
 //     z_p = Shat_b^-1 t[rows_b]               (FP64 MFMA 16x16x4 on the FP32- / FP64-stored block inverse)
 // with the epilogue of the Schur sweep it replaces (plain copy for the J^T product of the last velocity sweep,
 // coarse prolongation, FP32 copy).  Round 2 issued three dependent launches here (pressure rows of r - (S Y) e,
-// J product, Schur sweep: 10 + 25 + 9 us at 16 groups, ~20 us of latency floor at one group).  One workgroup of
-// four waves per block: the 16-lane rows of all four waves form the block's 32 rows of t in two passes (index /
-// value chunks by one coalesced load, DPP row broadcasts, 16 gathers in flight as in spmm_kernel_v2), t goes
-// through LDS, waves 0 and 1 apply the inverse.
+// J product, Schur sweep: 10 + 25 + 9 us at 16 groups, ~20 us of latency floor at one group).
+// Round 4: the launch is a chain of dependent round trips per workgroup, not bytes (cfg2: 1 744 workgroups, all
+// resident at once, 41 us; the 151 KB of z rows a block gathers come out of L2), so the chain is what was cut:
+//   * 512 threads -- a 16-lane row per pressure row of the block, all 32 rows at once (two passes of 16 before);
+//   * per (block, row) ONE 5-word record {row, J row range, (S Y) row range} at a fixed stride (ps_meta, built at
+//     set_operator): block list -> row index -> row pointers were three dependent loads;
+//   * the first (index, value) chunks of the J row and of the (S Y) row and r_p are requested together, the next
+//     J chunk while the 16 gathers of the current one are in flight.
+// Indices are loaded unconditionally (clamped to the row's last entry, the value zeroed instead): no exec-masked
+// load blocks, cf. the scheduling rule in DESIGN.md.
 // ---------------------------------------------------------------------------
 template <class T, class RT>
-__global__ __launch_bounds__(256) void pressure_step_kernel(
-    GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows, GroupPtrsT<T> invs,
-    const int* __restrict__ jrp, const int* __restrict__ jci, const double* __restrict__ jv,
-    const double* __restrict__ z, size_t gsz,
-    const int* __restrict__ syrp, const int* __restrict__ syci, GroupPtrs syv, const double* __restrict__ ec, size_t gse,
+__global__ __launch_bounds__(512) void pressure_step_kernel(
+    GroupTab gt, const int* __restrict__ meta, GroupPtrsT<T> invs,
+    const int* __restrict__ jci, const double* __restrict__ jv, const double* __restrict__ z, size_t gsz,
+    int with_sy, const int* __restrict__ syci, GroupPtrs syv, const double* __restrict__ ec, size_t gse,
     const RT* __restrict__ rp_, size_t gsr, double* __restrict__ out, size_t gso, ProlongArgs pa) {
   __shared__ double tl[32][17];
   const int grp = gt.gid[blockIdx.z];
@@ -1170,66 +1175,73 @@ __global__ __launch_bounds__(256) void pressure_step_kernel(
   z += (size_t)grp * gsz;
   rp_ += (size_t)grp * gsr;
   out += (size_t)grp * gso;
-  const double* __restrict__ sval = syrp ? syv.p[grp] : nullptr;
-  const double* __restrict__ ecg = ec ? ec + (size_t)grp * gse : nullptr;
-  const int b0 = bptr[blockIdx.x], nb = bptr[blockIdx.x + 1] - b0;
-  const int g = threadIdx.x & 15, rg = threadIdx.x >> 4;        // column, row group (16 of them)
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int il = rg + 16 * pass;
-    const bool live = il < nb;
-    const int prow = live ? rows[b0 + il] : 0;
-    double acc = 0.0;
-    {
-      const int k0 = live ? jrp[prow] : 0, k1 = live ? jrp[prow + 1] : 0;
-      int nch = (k1 - k0 + 15) >> 4;
-      nch = max(nch, __shfl_xor(nch, 16, 64));
-      nch = max(nch, __shfl_xor(nch, 32, 64));
-      for (int ch = 0; ch < nch; ++ch) {
-        const int k = k0 + ch * 16 + g;
-        int myc = 0;
-        double myv = 0.0;
-        if (k < k1) {
-          myc = jci[k];
-          myv = jv[k];
-        }
+  const double* __restrict__ sval = with_sy ? syv.p[grp] : nullptr;
+  const double* __restrict__ ecg = with_sy ? ec + (size_t)grp * gse : nullptr;
+  const int g = threadIdx.x & 15, il = threadIdx.x >> 4;        // column, row of the block
+  const int* __restrict__ mt = meta + ((size_t)blockIdx.x * 32 + il) * 5;
+  const int prow_ = mt[0], k0 = mt[1], k1 = mt[2], s0 = mt[3], s1 = mt[4];
+  const bool live = prow_ >= 0;
+  const int prow = live ? prow_ : 0;
+  // round 1 of loads, all independent: r_p, first J chunk, first (S Y) chunk
+  const RT rraw = rp_[(size_t)prow * 16 + g];
+  const int klast = max(k1 - 1, k0);
+  int nch = (k1 - k0 + 15) >> 4;
+  nch = max(nch, __shfl_xor(nch, 16, 64));
+  nch = max(nch, __shfl_xor(nch, 32, 64));
+  int kk = k0 + g;
+  int cn = jci[min(kk, klast)];
+  double vn = jv[min(kk, klast)];
+  bool okn = kk < k1;
+  int sc = 0;
+  double sv = 0.0;
+  int nsch = 0;
+  const int slast = max(s1 - 1, s0);
+  if (with_sy) {
+    nsch = (s1 - s0 + 7) >> 3;
+    nsch = max(nsch, __shfl_xor(nsch, 16, 64));
+    nsch = max(nsch, __shfl_xor(nsch, 32, 64));
+    const int sk = s0 + (g & 7);
+    sc = syci[min(sk, slast)];
+    sv = syv.p[grp][min(sk, slast)];
+    if (!(g < 8 && sk < s1)) sv = 0.0;
+  }
+  double acc = 0.0;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int myc = cn;
+    const double myv = okn ? vn : 0.0;
+    if (ch + 1 < nch) {          // uniform per wave: the next chunk's indices travel while this one's gathers do
+      kk += 16;
+      cn = jci[min(kk, klast)];
+      vn = jv[min(kk, klast)];
+      okn = kk < k1;
+    }
 #define RICADI_PS_STEP(TT)                                  \
   {                                                         \
     const int c0 = bc16i<TT>(myc);                          \
     const double v0 = bc16d<TT>(myv);                       \
     acc = fma(v0, z[(size_t)c0 * 16 + g], acc);             \
   }
-        RICADI_FOR16(RICADI_PS_STEP)
+    RICADI_FOR16(RICADI_PS_STEP)
 #undef RICADI_PS_STEP
-      }
+  }
+  for (int ch = 0; ch < nsch; ++ch) {
+    if (ch > 0) {
+      const int sk = s0 + ch * 8 + (g & 7);
+      sc = syci[min(sk, slast)];
+      sv = sval[min(sk, slast)];
+      if (!(g < 8 && sk < s1)) sv = 0.0;
     }
-    if (syrp) {
-      const int k0 = live ? syrp[prow] : 0, k1 = live ? syrp[prow + 1] : 0;
-      int nch = (k1 - k0 + 7) >> 3;
-      nch = max(nch, __shfl_xor(nch, 16, 64));
-      nch = max(nch, __shfl_xor(nch, 32, 64));
-      for (int ch = 0; ch < nch; ++ch) {
-        const int k = k0 + ch * 8 + g;
-        int myc = 0;
-        double myv = 0.0;
-        if (g < 8 && k < k1) {
-          myc = syci[k];
-          myv = sval[k];
-        }
 #define RICADI_PS_STEP(TT)                                  \
   {                                                         \
-    const int c0 = bc16i<TT>(myc);                          \
-    const double v0 = bc16d<TT>(myv);                       \
+    const int c0 = bc16i<TT>(sc);                           \
+    const double v0 = bc16d<TT>(sv);                        \
     acc = fma(v0, ecg[(size_t)c0 * 16 + g], acc);           \
   }
-        RICADI_PS_STEP(0) RICADI_PS_STEP(1) RICADI_PS_STEP(2) RICADI_PS_STEP(3)
-        RICADI_PS_STEP(4) RICADI_PS_STEP(5) RICADI_PS_STEP(6) RICADI_PS_STEP(7)
+    RICADI_PS_STEP(0) RICADI_PS_STEP(1) RICADI_PS_STEP(2) RICADI_PS_STEP(3)
+    RICADI_PS_STEP(4) RICADI_PS_STEP(5) RICADI_PS_STEP(6) RICADI_PS_STEP(7)
 #undef RICADI_PS_STEP
-      }
-    }
-    const double rv = live ? (double)rp_[(size_t)prow * 16 + g] : 0.0;
-    tl[il][g] = live ? acc - rv : 0.0;
   }
+  tl[il][g] = live ? acc - (double)rraw : 0.0;
   __syncthreads();
   const int wave = threadIdx.x >> 6;
   if (wave >= 2) return;
@@ -1246,9 +1258,9 @@ __global__ __launch_bounds__(256) void pressure_step_kernel(
   const double* __restrict__ pec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int il = 16 * t + q + 4 * e;
-    if (il < nb) {
-      const int row = rows[b0 + il];
+    const int ol = 16 * t + q + 4 * e;
+    const int row = meta[((size_t)blockIdx.x * 32 + ol) * 5];
+    if (row >= 0) {
       double v = acc4[e];
       if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * 16 + r] = v;
       if (pec) v += pec[(size_t)pa.aggof[row] * 16 + r];
@@ -1258,35 +1270,35 @@ __global__ __launch_bounds__(256) void pressure_step_kernel(
   }
 }
 template <class T>
-static void pressure_step_impl(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
-                               const GroupPtrsT<T>& inv, const int* jrp, const int* jci, const double* jv, const double* z,
-                               size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec,
+static void pressure_step_impl(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                               const GroupPtrsT<T>& inv, const int* jci, const double* jv, const double* z,
+                               size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec,
                                size_t gse, const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                                const ProlongArgs& pa) {
   if (nblocks <= 0 || gt.ng <= 0) return;
-  dim3 grid(nblocks, 1, gt.ng), block(256);
+  dim3 grid(nblocks, 1, gt.ng), block(512);
   if (rp16)
-    hipLaunchKernelGGL((pressure_step_kernel<T, _Float16>), grid, block, 0, st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z,
-                       gsz, syrp, syci, syv, ec, gse, rp16, gsr, out, gso, pa);
+    hipLaunchKernelGGL((pressure_step_kernel<T, _Float16>), grid, block, 0, st, gt, meta, inv, jci, jv, z, gsz,
+                       with_sy ? 1 : 0, syci, syv, ec, gse, rp16, gsr, out, gso, pa);
   else
-    hipLaunchKernelGGL((pressure_step_kernel<T, double>), grid, block, 0, st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z,
-                       gsz, syrp, syci, syv, ec, gse, rp_, gsr, out, gso, pa);
+    hipLaunchKernelGGL((pressure_step_kernel<T, double>), grid, block, 0, st, gt, meta, inv, jci, jv, z, gsz,
+                       with_sy ? 1 : 0, syci, syv, ec, gse, rp_, gsr, out, gso, pa);
 }
-void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
-                            const GroupPtrsF& inv, const int* jrp, const int* jci, const double* jv, const double* z,
-                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrsF& inv, const int* jci, const double* jv, const double* z,
+                            size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                             const ProlongArgs& pa) {
-  pressure_step_impl(st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z, gsz, syrp, syci, syv, ec, gse, rp_, rp16, gsr, out,
-                     gso, pa);
+  pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, z, gsz, with_sy, syci, syv, ec, gse, rp_, rp16, gsr, out, gso,
+                     pa);
 }
-void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* bptr, const int* rows,
-                            const GroupPtrs& inv, const int* jrp, const int* jci, const double* jv, const double* z,
-                            size_t gsz, const int* syrp, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
+void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrs& inv, const int* jci, const double* jv, const double* z,
+                            size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
                             const ProlongArgs& pa) {
-  pressure_step_impl(st, gt, nblocks, bptr, rows, inv, jrp, jci, jv, z, gsz, syrp, syci, syv, ec, gse, rp_, rp16, gsr, out,
-                     gso, pa);
+  pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, z, gsz, with_sy, syci, syv, ec, gse, rp_, rp16, gsr, out, gso,
+                     pa);
 }
 
 

@@ -289,6 +289,31 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
             (double)c->synnz / std::max(c->n, 1));
   c->sy_rp.upload(hs.sy_rp, st);
   c->sy_ci.upload(hs.sy_ci, st);
+  {
+    // records of the fused pressure step (pressure_step_kernel): one load per (block, row) instead of the chain
+    // block list -> row index -> row pointers
+    std::vector<int> meta((size_t)std::max(hs.nbp, 0) * 32 * 5, 0);
+    const bool with_sy = hs.kc > 0 && (int)hs.sy_rp.size() == hs.n + 1;
+    for (int b = 0; b < hs.nbp; ++b)
+      for (int il = 0; il < 32; ++il) {
+        int* mt = &meta[((size_t)b * 32 + il) * 5];
+        const int cnt = hs.bp_ptr[b + 1] - hs.bp_ptr[b];
+        if (il >= cnt || cnt > 32) {
+          mt[0] = -1;
+          continue;
+        }
+        const int prow = hs.bp_rows[hs.bp_ptr[b] + il];
+        mt[0] = prow;
+        mt[1] = J.rp[prow];
+        mt[2] = J.rp[prow + 1];
+        mt[3] = with_sy ? hs.sy_rp[hs.nv + prow] : 0;
+        mt[4] = with_sy ? hs.sy_rp[hs.nv + prow + 1] : 0;
+        // (the kernel clamps its index loads to the row's last entry: an empty row must not point behind the arrays)
+        if (mt[2] == mt[1]) mt[1] = mt[2] = 0;
+        if (mt[4] == mt[3]) mt[3] = mt[4] = 0;
+      }
+    c->ps_meta.upload(meta, st);
+  }
   c->sy_A.upload(hs.sy_A, st);
   c->sy_E.upload(hs.sy_E, st);
   c->sy_J.upload(hs.sy_J, st);

@@ -329,13 +329,11 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       const _Float16* rp16 = sy && r16 ? r16 + (size_t)nv * m : nullptr;
       const size_t gsrp = sy ? gsr : gsrr;
       if (c->precond32)
-        launch_pressure_step_b(st, gt, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->J.rp.p, c->J.ci.p, c->J.v.p, z,
-                               bt.gs, sy ? c->sy_rp.p + nv : nullptr, c->sy_ci.p, bt.syval, c->ec.p, bt.gsc, rp64, rp16,
-                               gsrp, zp, bt.gs, ppro);
+        launch_pressure_step_b(st, gt, c->nbp, c->ps_meta.p, bt.bpinvf, c->J.ci.p, c->J.v.p, z, bt.gs, sy, c->sy_ci.p,
+                               bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro);
       else
-        launch_pressure_step_b(st, gt, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinv, c->J.rp.p, c->J.ci.p, c->J.v.p, z,
-                               bt.gs, sy ? c->sy_rp.p + nv : nullptr, c->sy_ci.p, bt.syval, c->ec.p, bt.gsc, rp64, rp16,
-                               gsrp, zp, bt.gs, ppro);
+        launch_pressure_step_b(st, gt, c->nbp, c->ps_meta.p, bt.bpinv, c->J.ci.p, c->J.v.p, z, bt.gs, sy, c->sy_ci.p,
+                               bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro);
     } else if (c->precond32)
       launch_block_apply_b(st, gt, c->bs, c->nbp, c->bp_ptr.p, c->bp_rows.p, bt.bpinvf, c->tp.p, m,
                            bt.gsp, zp, m, bt.gs, m, 0, ppro);
