@@ -1,4 +1,4 @@
-"""Copy the files of a tools/r3_final.sh run (gpurun_out/TAG) into profiles/ under their round-3 names and
+"""Copy the files of a tools/r4_final.sh run (gpurun_out/TAG) into profiles/ under their round-4 names and
 derive the two summaries that are not plain copies (K1 kernel statistics, K1 traffic).
 python tools/install_record.py TAG"""
 import csv
@@ -11,10 +11,13 @@ import sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", tag)
 dst = "profiles"
-plain = {"bench.json": "r03_bench_line.json", "bench_kernel_stats.csv": "r03_bench_kernel_stats.csv",
-         "classes58_kernel_stats.csv": "r03_kernel_classes_cfg2_g16_stats.csv",
-         "bench_2ranks_one_gpu.json": "r03_bench_2ranks_one_gpu_rehearsal.json", "cfg3.json": "r03_bench_cfg3.json",
-         "cfg4.json": "r03_bench_cfg4.json", "cfg5.json": "r03_bench_cfg5.json", "cfg4_dre.json": "r03_bench_cfg4_dre.json"}
+plain = {"bench.json": "r04_bench_line.json", "bench_kernel_stats.csv": "r04_bench_kernel_stats.csv",
+         "classes58_kernel_stats.csv": "r04_kernel_classes_cfg2_g16_stats.csv",
+         "bench_2ranks_one_gpu.json": "r04_bench_2ranks_one_gpu_rehearsal.json", "cfg3.json": "r04_bench_cfg3.json",
+         "cfg3-cycle.json": "r04_bench_cfg3_cycle.json", "cfg4.json": "r04_bench_cfg4.json", "cfg5.json": "r04_bench_cfg5.json",
+         "cfg4_dre.json": "r04_bench_cfg4_dre.json", "dre2_kernel_stats.csv": "r04_cfg4_dre_kernel_stats.csv",
+         "bench_4ranks_one_gpu.json": "r04_bench_4ranks_one_gpu_rehearsal.json",
+         "bench_5ranks_one_gpu.json": "r04_bench_5ranks_one_gpu_rehearsal.json"}
 for a, b in plain.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
@@ -30,12 +33,15 @@ def stats_block(csvf, logf, title, cmd):
     return "\n".join(out)
 
 
-txt = ["rocprofv3 --kernel-trace --stats, MI355X, round 3 (tools/r3_final.sh)",
+if not os.path.exists(os.path.join(src, "spmm58_kernel_stats.csv")):
+    print("installed", tag, "(part b: plain copies only)")
+    sys.exit(0)
+txt = ["rocprofv3 --kernel-trace --stats, MI355X, round 4 (tools/r4_final.sh)",
        stats_block(os.path.join(src, "spmm58_kernel_stats.csv"), os.path.join(src, "spmm58.log"),
                    "cfg2 (n=29 930), 16 groups, m=16", "python tools/spmm_batch_pmc.py 58 16 200"), "",
        stats_block(os.path.join(src, "spmm236_kernel_stats.csv"), os.path.join(src, "spmm236.log"),
                    "cfg5 (n=499 850), 16 groups, m=16", "python tools/spmm_batch_pmc.py 236 16 50"), ""]
-open(os.path.join(dst, "r03_spmm_kernel_stats.txt"), "w").write("\n".join(txt))
+open(os.path.join(dst, "r04_spmm_kernel_stats.txt"), "w").write("\n".join(txt))
 
 
 def mean_of(f):
@@ -44,10 +50,12 @@ def mean_of(f):
 
 
 old = json.load(open(os.path.join(dst, "r03_spmm_traffic.json")))
+for e in old.values():
+    e["note"] = "round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a); other fields as in round 3"
 for key, n in (("16x29930x16", "58"), ("16x499850x16", "236")):
     fk = mean_of(os.path.join(src, "spmm%s_FETCH_SIZE.txt" % n))
     wk = mean_of(os.path.join(src, "spmm%s_WRITE_SIZE.txt" % n))
     old[key].update(FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, hbm_bytes=int((2 * fk + wk) * 1024),
                     hbm_bytes_lower=int((fk + wk) * 1024))
-json.dump(old, open(os.path.join(dst, "r03_spmm_traffic.json"), "w"), indent=1)
+json.dump(old, open(os.path.join(dst, "r04_spmm_traffic.json"), "w"), indent=1)
 print("installed", tag)
