@@ -1,6 +1,7 @@
 """Batched vs per-shift solves at cfg2: wall time of one sweep of G shifts.  python tools/batch_probe.py [N]"""
 import os, sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from optconpy_amd import _lib, problems as pb
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 58

@@ -50,8 +50,7 @@ def mean_of(f):
 
 
 old = json.load(open(os.path.join(dst, "r03_spmm_traffic.json")))
-for e in old.values():
-    e["note"] = "round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a); other fields as in round 3"
+old["_note"] = "round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a); other fields as in round 3"
 for key, n in (("16x29930x16", "58"), ("16x499850x16", "236")):
     fk = mean_of(os.path.join(src, "spmm%s_FETCH_SIZE.txt" % n))
     wk = mean_of(os.path.join(src, "spmm%s_WRITE_SIZE.txt" % n))

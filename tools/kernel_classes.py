@@ -2,7 +2,8 @@
 N given) -- the workload behind bench.py's `roofline_kernels`, for rocprofv3 --kernel-trace --stats.
 python tools/kernel_classes.py [N] [G] [reps]"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from optconpy_amd import _lib, problems as pb
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 58

@@ -18,7 +18,8 @@ pmc() { tag=$1; ctr=$2; shift; shift
   f=$(find $O/${tag}_$ctr -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/tools/pmc_avg.py "$f" spmm_blocked > $O/${tag}_$ctr.txt
   rm -rf $O/${tag}_$ctr; }
-if [ "${2:-a}" = a ]; then
+if [ "${2:-a}" = a ] || [ "${2:-a}" = p ]; then
+  if [ "${2:-a}" = a ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1
   echo "pytest rc=$?" >> $O/gputests.log; tail -3 $O/gputests.log
   python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1
@@ -27,6 +28,7 @@ if [ "${2:-a}" = a ]; then
   timeout -k 10 600 python bench.py --gpus 2 --rehearse-one-gpu --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks.err
   echo "2-rank rehearsal rc=$?"; cut -c1-200 $O/bench_2ranks_one_gpu.json; echo
   stats bench $R/bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1
+  fi
   stats classes58 $R/tools/kernel_classes.py 58 16 100
   stats spmm58 $R/tools/spmm_batch_pmc.py 58 16 200
   stats spmm236 $R/tools/spmm_batch_pmc.py 236 16 50

@@ -1,7 +1,8 @@
 """Only batched tile-SpMM launches (for rocprofv3 --pmc passes).
 python tools/spmm_batch_pmc.py N G [reps]"""
 import sys
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from optconpy_amd import _lib, problems as pb
 N, G = int(sys.argv[1]), int(sys.argv[2])
