@@ -386,9 +386,22 @@ class Context:
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0,
                                            group=group)
             torch.cuda.synchronize()
-            _chk(self._lib.ricadi_set_exchange_rccl(self._h, rank, world, ident[0], None, count * 8))
-            self._xchg = ("rccl", None, None, group, count)
-            return
+            rc = self._lib.ricadi_set_exchange_rccl(self._h, rank, world, ident[0], None, count * 8)
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device="cuda")
+            if world > 1:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)       # all ranks take the same transport
+            if int(ok.item()) == 1:
+                self._xchg = ("rccl", None, None, group, count)
+                return
+            import warnings
+            warnings.warn("ricadi: the library's own RCCL communicator could not be set up ({0}); the all-gather of the "
+                          "sharded sweeps goes through torch.distributed instead".format(
+                              self._lib.ricadi_last_error().decode() if rc != 0 else "another rank failed"),
+                          RuntimeWarning)
+            _chk(self._lib.ricadi_set_exchange(self._h, 0, 1, None, None, None, None, 0))
+            if world == 1:
+                self._xchg = None
+                return
         dev = torch.device("cuda", torch.cuda.current_device())
         send = torch.zeros(count, dtype=torch.float64, device=dev)
         recv = torch.zeros(count * world, dtype=torch.float64, device=dev)

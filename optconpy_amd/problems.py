@@ -425,8 +425,8 @@ def logshifts(pmin, pmax, s, interleave=False):
     (the reference takes ``ms`` as given, ``run_optcont.py:18-19``: an unsorted list); after every complete pass over
     the list the iterate is the same for every order, but the sweep form of the ADI -- G consecutive shifts solved
     against one residual factor, recombined with their G x G Cauchy matrix -- needs the shifts of a sweep well
-    separated: 16 neighbours of a 128-shift list over 3.5 decades have a numerically singular Cauchy matrix (the
-    sweeps then shrink to 4 shifts), 16 interleaved ones are as far apart as the 16 shifts of cfg2."""
+    separated: 16 neighbours of a 128-shift list over 3.5 decades have a Cauchy matrix of condition > 1e13 (the
+    library then shrinks the sweeps to 2 shifts), 16 interleaved ones are as far apart as the 16 shifts of cfg2."""
     ms = (-np.logspace(np.log10(pmin), np.log10(pmax), int(s))).tolist()
     if interleave and len(ms) > 16:
         k = -(-len(ms) // 16)

@@ -51,6 +51,31 @@ def test_wide_panel_column_groups_against_sparse_lu(cfg1):
         assert np.abs(X[g][:, 65]).max() == 0.0
 
 
+def test_wide_panel_with_the_low_rank_term_inside_the_krylov_operator(cfg1, monkeypatch):
+    """The column groups of a wide panel also carry the closed-loop term when it sits INSIDE the Krylov operator
+    (RICADI_SMW=0: -U (V^T x) in the SpMM epilogue, V^T x per group by the thin GEMM) and through the default
+    Sherman-Morrison-Woodbury route: (S - [U;0][V;0]^T) X = [R;0] for a 40-column panel against the dense solve."""
+    import scipy.sparse as sps
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    MT = pr.M.T.tocsr()
+    rng = np.random.default_rng(40)
+    R = rng.standard_normal((pr.NV, 40))
+    U = 0.05 * rng.standard_normal((pr.NV, 4))
+    V = rng.standard_normal((pr.NV, 4))
+    S = sps.bmat([[calA - 5.0 * MT, pr.J.T], [pr.J, None]], format="csc").toarray()
+    S[:pr.NV, :pr.NV] -= U @ V.T
+    ref = np.linalg.solve(S, np.vstack([R, np.zeros((pr.NP, 40))]))
+    for smw in ("0", "1"):
+        monkeypatch.setenv("RICADI_SMW", smw)
+        with _lib.Context(0) as ctx:
+            ctx.set_operator(calA, MT, pr.J)
+            ctx.set_lowrank(U, V)
+            X, its, rr = ctx.shift_solve(-5.0, 1.0, R)
+            assert rr.max() <= 1e-10, smw
+            assert rel(X, ref) < 1e-8, smw
+
+
 # ------------------------------------------------------------------ coarse inverses: the pivoted route
 def _needs_pivoting(k, seed, eps):
     """Well-conditioned k x k matrix whose leading 128 x 128 block (the first diagonal block of the blocked
@@ -242,3 +267,41 @@ def test_cfg3_continuation_from_lower_reynolds_number():
         assert out["nwtn_steps"] <= int(g["nwtn_steps"][0])
     finally:
         backend.reset()
+
+
+# ------------------------------------------------------------------ storage safety net on a second operator
+def test_storage_escalation_on_the_dre_operator_at_1e5():
+    """The storage safety net of the inner GMRES (FP16 basis + FP32 inverses -> FP32 basis + FP64 inverses -> FP64
+    basis) on a second operator: the time-varying DRE operator -(M^T/2 + tau (A + N)^T) at
+    n = 100 490 with the three-level preconditioner, two sweeps of four shifts.  With the default options every solve
+    converges without an escalation; starved of iterations (gmres_maxit = 50, below what the slow shifts need) the
+    groups are continued with wider storage, everything converges, the escalations are reported, and the factor is
+    the one of the unstarved run."""
+    import warnings
+    import sadptprj_riclyap_adi.proj_ric_utils as pru
+    pr = pb.ricc_problem(106, 0.15 / 60.0)
+    tau = float(np.diff(pb.get_tint(0.0, 1.0, 16, True)).max())
+    MT = pr.M.T.tocsr()
+    ft = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
+    ms = pb.logshifts(0.5, 2e3, 8, interleave=False)
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    backend.reset()
+    # the right-hand side projected beforehand (default options), so that the starved runs below starve the ADI solves only
+    W = lau.app_prj_via_sadpnt(amat=pr.M, jmat=pr.J, rhsv=np.random.default_rng(11).standard_normal((pr.NV, 16)),
+                               transposedprj=True)
+    d = dict(adi_max_steps=8, adi_newZ_reltol=0.0, ms=ms, sweep_width=4, project_w=False)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            a = pru.solve_proj_lyap_stein(amat=ft, mmat=MT, jmat=pr.J, wmat=W, transposed=True, adi_dict=d)
+        assert a["gmres_nonconverged"] == 0 and a["storage_escalations"] == 0
+        assert backend.context().setup_info()["levels"] == 3
+        backend.configure(gmres_maxit=50)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            b = pru.solve_proj_lyap_stein(amat=ft, mmat=MT, jmat=pr.J, wmat=W, transposed=True, adi_dict=d)
+        assert b["gmres_nonconverged"] == 0
+        assert b["storage_escalations"] >= 1, b
+        assert rel(b["zfac"] @ (b["zfac"].T @ W), a["zfac"] @ (a["zfac"].T @ W)) < 1e-7
+    finally:
+        backend.configure()

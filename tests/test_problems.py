@@ -74,3 +74,27 @@ def test_convection_about_a_discrete_velocity():
     Ni, Hi = pb.convection_from_vector(N, vi, ordering="interleaved")
     Nc, Hc = pb.convection_from_vector(N, pb.nodal_interpolant(N))
     assert np.isclose(abs(Ni).sum(), abs(Nc).sum()) and np.isclose(np.linalg.norm(Hi), np.linalg.norm(Hc))
+
+
+def test_interleaved_shift_order_keeps_sweeps_of_sixteen_admissible():
+    """pb.logshifts(..., interleave=True): the same shift SET, ordered so that any 16 consecutive entries span the
+    range -- the sweep form of the ADI can then take 16 at a time (ricadi_host_cauchy accepts every sweep of the cycle),
+    while 16 neighbours of the ascending list are refused (conditioning bound) and 8 / 4 are the widest admissible."""
+    from optconpy_amd import _lib
+
+    def widest(ms):
+        for G in (16, 8, 4, 2):
+            try:
+                for sw in range(len(ms) // G):
+                    _lib.host_cauchy(ms[sw * G:(sw + 1) * G])
+                return G
+            except (RuntimeError, ValueError):
+                continue
+        return 1
+    for lo, hi, n, asc in ((1.0, 3e3, 32, 8), (0.5, 2e3, 64, 4), (1.0, 3e3, 128, 2)):
+        a = pb.logshifts(lo, hi, n)
+        b = pb.logshifts(lo, hi, n, interleave=True)
+        assert sorted(a) == sorted(b) and a != b
+        assert widest(b) == 16
+        assert widest(a) == asc, (n, widest(a))
+    assert pb.logshifts(1.0, 3e3, 16, interleave=True) == pb.logshifts(1.0, 3e3, 16)     # short lists stay as they are
