@@ -365,7 +365,13 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) myl[rr][ch] *= (int)rowbytes;
+    for (int ch = 0; ch < NCH; ++ch) {
+      myl[rr][ch] *= (int)rowbytes;
+      // pinned HERE: sunk by the optimiser into the branches below, the multiply would sit right in front of the
+      // hand-written DPP instruction that reads it (round 4 saw exactly that in a variant of this kernel: all
+      // columns but the first came out wrong)
+      asm volatile("" : "+v"(myl[rr][ch]));
+    }
   // The DPP operands below are read by hand-written DPP instructions: keep the
   // VALU writes above two wait states away from them (hipcc pads nothing for asm).
   __builtin_amdgcn_sched_barrier(0);
