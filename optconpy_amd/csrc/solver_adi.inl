@@ -172,7 +172,6 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
   std::vector<double> be(G, 1.0), coef;
   std::vector<ShiftData*> sds(G);
   std::vector<GmresResult> res(G);
-  const bool sync_recompress = false, narrow_tail = true;
   AsyncRecompress job(c);
   int steps = 0;
   // relative block norm of the last two visits of every position of the shift cycle
@@ -189,7 +188,7 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     // and the sweep is cut there (any run of consecutive, distinct shifts is a valid sweep;
     // its Cauchy data are computed on the spot).
     int g_now = G;
-    if (narrow_tail && prm.adi_newZ_reltol > 0.0) {
+    if (prm.adi_newZ_reltol > 0.0) {
       for (int g = 0; g < G; ++g) {
         const int pos = (steps + g) % ns;
         if (rel_h1[pos] > 0.0 && rel_h2[pos] > rel_h1[pos]) {
@@ -348,18 +347,11 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
       rel_h2[pos] = rel_h1[pos];
       rel_h1[pos] = relj;
       stt.rel = relj;
-      if (narrow_tail && relj < prm.adi_newZ_reltol) {
+      if (relj < prm.adi_newZ_reltol) {
         kept = j + 1;
         stop = true;
         break;
       }
-    }
-    if (!narrow_tail) {
-      // sweep granularity (RICADI_FULL_SWEEPS=1): mean block norm of the sweep
-      double n2 = 0.0;
-      for (int j = 0; j < Gs * m; ++j) n2 += hn[j];
-      stt.rel = znorm2 > 0.0 ? std::sqrt(n2 / Gs / znorm2) : 0.0;
-      stop = stt.rel < prm.adi_newZ_reltol;
     }
     // W <- W + E (U C^-1 1) over the blocks that are KEPT: every U_g was solved against the same W, so
     // the first `kept` solutions are the sweep of the first `kept` shifts, whose Cauchy data differ only
@@ -404,13 +396,9 @@ static bool lyap_adi_sweeps_dev(ricadi_ctx* c, const double* shifts, int ns, dou
     if (stop) break;
     if (steps >= prm.adi_max_steps) break;
     if (prm.compress_cols > 0 && c->zc - zc_last >= prm.compress_cols) {
-      if (sync_recompress) {
-        factor_recompress(c);
-      } else {
-        // splice in what the helper finished during the last sweeps, hand it the next prefix
-        job.finish();
-        job.start();
-      }
+      // splice in what the helper finished during the last sweeps, hand it the next prefix
+      job.finish();
+      job.start();
       zc_last = c->zc;
       lap(c->t_compress);
     }

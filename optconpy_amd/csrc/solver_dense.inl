@@ -119,15 +119,11 @@ static int compress_pchol_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, 
   return k;
 }
 
-// The internal recompressions: pivoted-Cholesky route unless RICADI_RECOMPRESS_EIG=1 (or the factor is too
-// wide for it), then the Gram + eigensolver route.
+// The internal recompressions: pivoted-Cholesky route; the Gram + eigensolver route where the factor is too wide for it.
 static int recompress_exec(ricadi_ctx* c, const Exec& ex, const double* dZ, int cz, int ldz, double rel,
                            double* dOut) {
-  const bool eig = false;
-  if (!eig) {
-    const int k = compress_pchol_exec(c, ex, dZ, cz, ldz, rel, dOut);
-    if (k >= 0) return k;
-  }
+  const int k = compress_pchol_exec(c, ex, dZ, cz, ldz, rel, dOut);
+  if (k >= 0) return k;
   return compress_gram_exec(c, ex, dZ, cz, ldz, rel, 0, true, dOut, nullptr);
 }
 
@@ -268,9 +264,7 @@ static void panel_cholqr2_wide(ricadi_ctx* c, const double* P, int ldp, int n, i
 static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk, double* Q,
                          double* R, int split) {
   hipStream_t st = c->st;
-  const bool hh_only = false;
-  const int pw_env = 128;
-  const int PWF = pw_env <= 32 ? 32 : 128;          // panel width of the fast path
+  const int PWF = 128;                              // panel width of the fast path
   TArr<double> P(c->pool, (size_t)n * PWF), C1(c->pool, (size_t)kk * PWF), C2(c->pool, (size_t)kk * PWF);
   TArr<double> Q1(c->pool), Gw(c->pool), Tw(c->pool);
   if (PWF == 128) {
@@ -278,7 +272,7 @@ static void block_qr_dev(ricadi_ctx* c, const double* D, int ldd, int n, int kk,
     Gw.alloc(128 * 128);
     Tw.alloc(4 * 128 * 128);
   }
-  for (int attempt = hh_only ? 1 : 0; attempt < 2; ++attempt) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
     const bool fast = attempt == 0;
     const int PW = fast ? PWF : 32;
     if (fast) HIPCHK(hipMemsetAsync(c->flag.p + 1, 0, sizeof(int), st));

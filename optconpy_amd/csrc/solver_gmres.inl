@@ -95,8 +95,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   // Cycle length: short cycles keep the Krylov basis (the dominant HBM traffic of an
   // iteration: three passes over it) small; a cycle that gains less than a factor 10
   // on some column lengthens the following ones, up to gmres_restart.
-  const int cyc0 = 10;
-  int cyc = std::min(restart, cyc0);
+  int cyc = std::min(restart, 10);
   std::vector<double> rstart(GM, 0.0);
   Tick tkc;
   auto lapc = [&](double& acc) {
@@ -538,7 +537,6 @@ static int storage_level(const ricadi_ctx* c) {
 static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const double* b,
                               size_t gsb, double* x, int m, bool lowrank, double* relres_host,
                               GmresResult* res) {
-  const bool no_net = false;
   hipStream_t st = c->st;
   const bool plain = !(lowrank && c->q > 0);
   const bool shared = (gsb == 0 || G == 1) && plain && c->rec_depth > 0;
@@ -549,11 +547,11 @@ static void gmres_solve_batch(ricadi_ctx* c, ShiftData* const* sds, int G, const
     c->t_guess += tkg.lap();
   }
   const int lvl0 = storage_level(c);
-  gmres_core_any(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, !no_net && lvl0 < 2);
+  gmres_core_any(c, sds, G, b, gsb, x, m, lowrank, res, guess, nullptr, lvl0 < 2);
   std::vector<int> bad;
   for (int g = 0; g < G; ++g)
     if (!res[g].converged) bad.push_back(g);
-  for (int level = lvl0 + 1; level <= 2 && !bad.empty() && !no_net; ++level) {
+  for (int level = lvl0 + 1; level <= 2 && !bad.empty(); ++level) {
     StorageScope wide(c, level);
     std::vector<GmresResult> r2(G);
     gmres_core_any(c, sds, G, b, gsb, x, m, lowrank, r2.data(), true, &bad, level < 2);

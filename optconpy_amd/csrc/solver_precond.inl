@@ -234,13 +234,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       // velocity sweep instead, like the J^T product below, was measured slower: 249 vs
       // 257 shift-solves/s -- 8 rows x 7.6 dependent gathers per lane.)
       // Tile form: the aggregates a row block touches (a few dozen coarse rows) go to LDS once.
-      const bool sy_csr = false;
-      if (c->syb_ok && !sy_csr && ms_pays(c, gt.ng, c->snnz) &&
+      if (c->syb_ok && ms_pays(c, gt.ng, c->snnz) &&
           spmm_blocked_ms_ok(m, c->syb_max_cols, (size_t)c->kc))
         launch_spmm_blocked_ms(st, gt, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p,
                                c->syb_cols2.p, c->syb_lidx_ms.p, c->sybAJ.p, c->sybE.p, c->ec.p, m,
                                bt.gsc, c->r2.p, m, bt.gs, r, m, gsr, -1.0, 1.0, m, c->syb_max_cols);
-      else if (c->syb_ok && !sy_csr &&
+      else if (c->syb_ok &&
           spmm_blocked_lds_bytes(m, c->syb_max_cols, 0) <= (size_t)40 * 1024)
         launch_spmm_blocked_b(st, gt, c->sb_nblk, c->sb_rows2.p, c->syb_rp2.p, c->syb_cols2.p,
                               c->syb_lidx.p, bt.syvalb, c->ec.p, m, bt.gsc, c->r2.p, m, bt.gs, r, m, gsr,
@@ -301,18 +300,17 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       launch_spmm_b(st, gt, np, c->J.rp.p, c->J.ci.p, jv, z, m, bt.gs, nullptr, c->tp.p, m, bt.gsp,
                     rr + (size_t)nv * m, m, gsrr, 1.0, -1.0, m);
     double* zp = z + (size_t)nv * m;
-    const bool fuse_jt = true, rect = true;
     // Fused variant: the pressure sweep writes z_p already WITH its coarse part and keeps
     // the plain z_p (the operand of the J^T product below) in tp -- in place: a wave
     // reads its block's rows of tp before it writes them, blocks are disjoint.
     ProlongArgs ppro;
-    if (fuse_jt) {
+    {
       ppro.out2 = c->tp.p;
       ppro.gs2 = bt.gsp;
       if (z32) {
         ppro.out32 = z32 + (size_t)nv * m;
         ppro.gs32 = gs32;
-        ppro.only32 = only32 && rect && c->gt_ok;   // the rectangle sweep below completes the FP32 copy
+        ppro.only32 = only32 && c->gt_ok;   // the rectangle sweep below completes the FP32 copy
       }
       if (c->kc > 0) {
         ppro.aggof = c->aggof.p + nv;
@@ -344,7 +342,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     // J^T product is formed inside the sweep, row by row as the blocks gather them
     // (z_p is small and L2 resident), instead of through an intermediate panel
     if (!on(6)) {
-    } else if (fuse_jt && rect && c->gt_ok) {
+    } else if (c->gt_ok) {
       // z_v -= G z_p with the per-shift blocks G_b = Ahat_b^-1 J^T[rows_b, pcols_b] formed at setup
       pro.nextra = 0;            // the pressure rows already carry their coarse part
       pro.out32 = z32;
@@ -357,7 +355,9 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       else
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
                                   c->gt_cols.p, bt.gtm, c->tp.p, m, bt.gsp, z, m, bt.gs, m, 1, pro);
-    } else if (fuse_jt) {
+    } else {
+      // blocks that touch too many pressure dofs for the dense rectangles: the J^T product formed row by row inside
+      // the sweep (CsrInArgs)
       CsrInArgs cin;
       cin.rp = c->JT.rp.p;
       cin.ci = c->JT.ci.p;
@@ -366,11 +366,6 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       cin.gss = bt.gsp;
       pro.nextra = 0;          // the pressure rows already carry their coarse part
       vel_apply(nullptr, 0, 1, true, cin);
-    } else {
-      double* tmp = c->r2.p;   // the corrected residual is no longer needed at this point
-      launch_spmm_b(st, gt, nv, c->JT.rp.p, c->JT.ci.p, jtv, zp, m, bt.gs, nullptr, tmp, m, bt.gs,
-                    nullptr, 0, 0, 1.0, 0.0, m, LowRankArgs(), 8);    // J^T has ~5 entries per row
-      vel_apply(tmp, bt.gs, 1, true);
     }
   }
   if (z32 && !mirrored && c->pc_stage < 0)
