@@ -430,11 +430,13 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
     if (ap == bs) ap = ap + ap / 2;
     kv = aggregate(nv, g_rp, g_ci, av, va.data());
     kp = np > 0 ? aggregate(np, pp_rp.data(), pp_ci.data(), ap, pa.data()) : 0;
-    // Dense inverse of this level's coarse matrix: up to coarse_max without a third level; with one only
-    // up to HALF of it -- the per-shift LU + inversion grows with k^3 (rocSOLVER: 4.7 ms per shift at
-    // k = 3.3k, more than the solve it serves at n = 5e4) while the child level's matrix is about half
-    // as large (cfg3: k 3 046 -> 1 658, 72 -> 79 iterations, 290 -> 208 ms per 32-shift cycle).
-    const int direct_max = max_levels > 2 && np > 0 ? std::max(16, o.coarse_max / 2) : std::max(16, o.coarse_max);
+    // Dense inverse of this level's coarse matrix whenever it fits coarse_max.  (Rounds 2-3 handed the coarse problem
+    // to a child level from HALF of coarse_max on -- the per-shift inversion grows with k^3 and the child's matrix is
+    // half as large -- tuned on the one-solve-per-shift cycle: cfg3, k 3 046 -> 1 658, 72 -> 79 iterations, 188 -> 160 ms
+    // per 32-shift cycle.  The workload the library exists for solves every shift many times per setup: the cfg3
+    // Newton step -- 200 ADI steps over 32 shifts -- takes 955 ms with the dense inverse against 1 003 ms with the
+    // child level (round 4, same-call A/B), so the dense inverse wins wherever it fits.)
+    const int direct_max = std::max(16, o.coarse_max);
     if (kv + kp <= direct_max) break;
     // A third level, only where it can be GENTLE: the coarse problem of these aggregates goes to a
     // child level whose own aggregates are pairs of velocity aggregates and single pressure aggregates
