@@ -421,6 +421,9 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   int av = std::max(1, o.agg_v), ap = std::max(1, o.agg_p);
   std::vector<int> va(nv), pa(std::max(np, 1));
   int kv = 0, kp = 0;
+  // Is this an operator the smoothed prolongation is made for (stiffness-like, symmetric part dominant)?
+  double sa_rs = -1.0, sa_gamma = -1.0;
+  const bool stiff = sa_omega > 0.0 && np > 0 && sa_criterion(A, sa_rs, sa_gamma);
   for (int attempt = 0; attempt < 16; ++attempt) {
     // The coarse pressure aggregates must not coincide with the Schur
     // block-Jacobi blocks (same graph, same greedy rule, same size): with
@@ -436,8 +439,17 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
     // per 32-shift cycle.  The workload the library exists for solves every shift many times per setup: the cfg3
     // Newton step -- 200 ADI steps over 32 shifts -- takes 955 ms with the dense inverse against 1 003 ms with the
     // child level (round 4, same-call A/B), so the dense inverse wins wherever it fits.)
-    const int direct_max = std::max(16, o.coarse_max);
+    // For a stiffness-dominated operator the child level is a poor stand-in at the small shifts (measured at n = 2e5,
+    // nu = 0.05, shift 1, same aggregates (36, 54), k = 5 415: child 229 iterations, dense inverse 175, dense inverse
+    // with the smoothed prolongation 118 -- and the smoothed coarse operator handed to a child: 150 at these aggregates
+    // but 572 against 214 at (81, 121), so smoothing stays a two-level affair).  Such operators keep two levels up to
+    // 1.5 x coarse_max and grow their aggregates up to (121, 182) for it: n = 5e5, (81, 121), k = 5 969: 181 -> 132
+    // iterations per shift-solve, 9.99 -> 8.86 s per pass over 128 shifts with the per-shift inversions inside.  A
+    // convection-dominated or mass-like operator (criterion false) is served as well by the child as by the inverse
+    // (n = 1e5, nu = 0.0025: 182 vs 153 iterations at shift 1, equal from shift 50 on, 219 vs 381 ms per 16 shifts).
+    const int direct_max = std::max(16, stiff ? o.coarse_max + o.coarse_max / 2 : o.coarse_max);
     if (kv + kp <= direct_max) break;
+    const bool grow_first = stiff && av + av / 2 <= 128;
     // A third level, only where it can be GENTLE: the coarse problem of these aggregates goes to a
     // child level whose own aggregates are pairs of velocity aggregates and single pressure aggregates
     // (so that the child's two-level cycle is a near-exact solve).  Coarsening the child harder makes
@@ -445,7 +457,7 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
     // poor a stand-in for the coarse solve: GMRES stagnates (measured at n = 5e5 with every tried
     // pair of level-2 aggregate sizes).  Larger problems therefore still grow the
     // aggregates of THIS level, but only until the gentle child fits (in steps of 1.5, not 2).
-    if (max_levels > 2 && np > 0 && 0.55 * kv + kp <= std::max(16, o.coarse_max)) {
+    if (max_levels > 2 && np > 0 && !grow_first && 0.55 * kv + kp <= std::max(16, o.coarse_max)) {
       hs.multilevel = true;
       break;
     }
@@ -467,11 +479,10 @@ void build_setup(const HostCsr& A, const HostCsr& E, const HostCsr& J, const ric
   // ---- prolongation P (rows): plain aggregation, or smoothed on the velocity rows ----------------
   hs.sa = sa_omega > 0.0 && !hs.multilevel && np > 0 && kv > 0;
   if (hs.sa) {
-    double rs = -1.0, gamma = -1.0;
-    hs.sa = sa_criterion(A, rs, gamma);
+    hs.sa = stiff;
     if (o.verbose)
       fprintf(stderr, "[ricadi] smoothed aggregation %s: row sums / diagonal of sym(cal A) = %.3f, skew / symmetric "
-              "off-diagonal mass %.3f\n", hs.sa ? "on" : "off", rs, gamma);
+              "off-diagonal mass %.3f\n", hs.sa ? "on" : "off", sa_rs, sa_gamma);
   }
   hs.p_rp.clear(); hs.p_ci.clear(); hs.p_v.clear();
   hs.pt_rp.clear(); hs.pt_ci.clear(); hs.pt_v.clear();
