@@ -57,7 +57,9 @@ typedef struct ricadi_opts {
   int bj_block;          /* block-Jacobi block size, <= 64 (default 32)     */
   int agg_v;             /* velocity aggregate size of the coarse level     */
   int agg_p;             /* pressure aggregate size of the coarse level     */
-  int coarse_max;        /* cap on coarse dimension (default 4096)          */
+  int coarse_max;        /* cap on coarse dimension (default 4096); a stiffness-dominated operator
+                            (ricadi_host_sa_criterion true) may use 1.5 x this for its dense inverse:
+                            see max_levels and ricadi_host_plan_levels        */
   int use_coarse;        /* 0: one-level block-Jacobi only                  */
   int max_levels;        /* 2: two-level method only.  3 (default): where the coarse problem of the
                             aggregates exceeds coarse_max, it is handed to a child level (the same
@@ -66,7 +68,11 @@ typedef struct ricadi_opts {
                             instead of growing the aggregates until a dense inverse fits; the
                             aggregates then only grow (x1.5 per step) until that gentle child fits:
                             0.55 k_v + k_p <= coarse_max (n ~ 1e5 keeps agg_v / agg_p).  A harder-
-                            coarsened child makes GMRES stagnate              */
+                            coarsened child makes GMRES stagnate.  Operators the
+                            smoothed prolongation applies to keep TWO levels instead, up to k <= 1.5
+                            coarse_max, and grow their aggregates up to (121, 182) for it: at their small
+                            shifts the child is a poor stand-in for the inverse (n = 2e5: 229 vs 118
+                            iterations), and the smoothed coarse operator does not go with a child      */
   int verbose;
   int compress_qr;       /* ricadi_compress: 1 (default) = thin block QR + SVD of R, the reference's
                             "QR ... SVD" (singular values resolved to eps*s_1), for factors of up to
@@ -458,6 +464,15 @@ int ricadi_host_deal(const double* shifts, int nshifts, int world, int32_t* owne
  * ratios are returned (skew ratio -1 when the first test failed).  Host only; no GPU needed.                       */
 int ricadi_host_sa_criterion(int nv, const int32_t* a_rowptr, const int32_t* a_col, const double* a_val,
                              double* rowsum_ratio_out, double* skew_ratio_out, int* on_out);
+/* The preconditioner hierarchy ricadi_set_operator would choose for (cal A, cal E, J) with these options, computed on
+ * the host (before the device-side fallbacks):  out[5] = { levels (1: block-Jacobi only, 2: dense coarse inverse,
+ * 3: child level), coarse dimension k, its velocity / pressure parts, smoothed prolongation (0/1) }.  A stiffness-
+ * dominated operator (ricadi_host_sa_criterion) keeps two levels up to k <= 1.5 coarse_max and grows its aggregates
+ * up to (121, 182) for it; any other goes to a child level as soon as the gentle child fits coarse_max.             */
+int ricadi_host_plan_levels(int nv, int np, const int32_t* a_rowptr, const int32_t* a_col, const double* a_val,
+                            const int32_t* e_rowptr, const int32_t* e_col, const double* e_val,
+                            const int32_t* j_rowptr, const int32_t* j_col, const double* j_val,
+                            const ricadi_opts* opts, int32_t* out);
 /* Greedy BFS aggregation of the graph of a CSR pattern into blocks of at
  * most bsize rows; blk_out[n]; returns the number of blocks (or <0).        */
 int ricadi_host_aggregate(int n, const int32_t* rowptr, const int32_t* col,

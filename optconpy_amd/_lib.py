@@ -20,7 +20,7 @@ RICADI_ENOCONV = -3
 MAX_M = 128
 # ricadi_version() this mirror was written for: the stats arrays' lengths and the meaning of their slots
 # are part of the ABI and are not covered by the struct handshake below
-ABI_VERSION = 400
+ABI_VERSION = 401
 
 
 class RicadiOpts(C.Structure):
@@ -112,6 +112,8 @@ SIGNATURES = {
     "ricadi_host_deal": (C.c_int, [_dp, C.c_int, C.c_int, _ip]),
     "ricadi_host_sa_criterion": (C.c_int, [C.c_int, _ip, _ip, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_int)]),
+    "ricadi_host_plan_levels": (C.c_int, [C.c_int, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp,
+                                          C.POINTER(RicadiOpts), _ip]),
     "ricadi_host_aggregate": (C.c_int, [C.c_int, _ip, _ip, C.c_int, _ip]),
     "ricadi_host_cauchy": (C.c_int, [_dp, C.c_int, _dp, _dp]),
 }
@@ -791,6 +793,17 @@ def host_cauchy(shifts):
     c1 = np.empty(g)
     _chk(load().ricadi_host_cauchy(_d(sh), g, _d(rinv), _d(c1)))
     return rinv, c1
+
+
+def host_plan_levels(calA, calE, J, **opts):
+    """The preconditioner hierarchy ``set_operator`` would choose (``ricadi_host_plan_levels``; host only):
+    dict(levels, kc, kcv, kcp, smoothed)."""
+    a, e, j = as_csr(calA), as_csr(calE), as_csr(J)
+    o = default_opts(**opts)
+    out = np.zeros(5, dtype=np.int32)
+    _chk(load().ricadi_host_plan_levels(a[3][0], j[3][0], _i(a[0]), _i(a[1]), _d(a[2]), _i(e[0]), _i(e[1]), _d(e[2]),
+                                        _i(j[0]), _i(j[1]), _d(j[2]), C.byref(o), _i(out)))
+    return dict(levels=int(out[0]), kc=int(out[1]), kcv=int(out[2]), kcp=int(out[3]), smoothed=bool(out[4]))
 
 
 def host_sa_criterion(calA):

@@ -895,6 +895,33 @@ int ricadi_host_sa_criterion(int nv, const int32_t* a_rp, const int32_t* a_ci, c
   return RICADI_OK;
 }
 
+int ricadi_host_plan_levels(int nv, int np, const int32_t* a_rp, const int32_t* a_ci, const double* a_v,
+                            const int32_t* e_rp, const int32_t* e_ci, const double* e_v, const int32_t* j_rp,
+                            const int32_t* j_ci, const double* j_v, const ricadi_opts* opts, int32_t* out) {
+  if (nv < 1 || np < 0 || !a_rp || !a_ci || !a_v || !e_rp || !e_ci || !e_v || (np > 0 && (!j_rp || !j_ci || !j_v)) ||
+      !opts || !out) {
+    ricadi::set_error("ricadi_host_plan_levels: bad argument");
+    return RICADI_EINVAL;
+  }
+  try {
+    const ricadi::HostCsr A = ricadi::make_csr(nv, nv, a_rp, a_ci, a_v), E = ricadi::make_csr(nv, nv, e_rp, e_ci, e_v);
+    const int32_t zero = 0;
+    const ricadi::HostCsr J = np > 0 ? ricadi::make_csr(np, nv, j_rp, j_ci, j_v) : ricadi::make_csr(0, nv, &zero, &zero, a_v);
+    ricadi::HostSetup hs;
+    const double sa_omega = (np == 0 || opts->bj_block != 32) ? 0.0 : 0.5;
+    ricadi::build_setup(A, E, J, *opts, hs, std::max(2, opts->max_levels), sa_omega);
+    out[0] = hs.kc == 0 ? 1 : hs.multilevel ? 3 : 2;
+    out[1] = hs.kc;
+    out[2] = hs.kcv;
+    out[3] = hs.kcp;
+    out[4] = hs.sa ? 1 : 0;
+  } catch (...) {
+    ricadi::set_error("ricadi_host_plan_levels: exception");
+    return RICADI_EINVAL;
+  }
+  return RICADI_OK;
+}
+
 int ricadi_host_deal(const double* shifts, int ns, int world, int32_t* owner_out) {
   if (!shifts || !owner_out || ns < 1 || world < 1) {
     ricadi::set_error("ricadi_host_deal: bad argument");

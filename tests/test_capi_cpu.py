@@ -293,3 +293,30 @@ def test_host_sa_criterion_on_the_operator_kinds():
     import scipy.sparse as sps
     off = K - sps.diags(K.diagonal())
     assert abs(sk - np.abs(S.data).sum() / np.abs(off.data).sum()) < 1e-12
+
+
+def test_host_plan_levels_keeps_two_levels_for_stiffness_dominated_operators():
+    """ricadi_host_plan_levels (the hierarchy rule of ricadi_set_operator, host side): an operator the smoothed
+    prolongation is made for keeps two levels up to 1.5 x coarse_max and grows its aggregates for it; a
+    convection-dominated one goes to a child level as soon as the gentle child fits coarse_max (measured on the
+    MI355X at n = 2e5 / 5e5: DESIGN.md section 3)."""
+    pr = pb.ricc_problem(40, 0.05)
+    calA, calE = (-pr.A - pr.Nc).T.tocsr(), pr.M.T.tocsr()
+    assert _lib.host_sa_criterion(calA)[0]
+    full = _lib.host_plan_levels(calA, calE, pr.J)
+    assert full["levels"] == 2 and full["smoothed"] and full["kc"] == full["kcv"] + full["kcp"] <= 4096
+    # coarse_max below the base aggregates' coarse dimension: two levels, k within 1.5 x the cap, coarser aggregates
+    for cm in (400, 150, 60):
+        p = _lib.host_plan_levels(calA, calE, pr.J, coarse_max=cm)
+        assert p["levels"] == 2 and p["smoothed"] and p["kc"] <= cm + cm // 2 and p["kc"] < full["kc"], (cm, p)
+    # the same mesh, convection dominated: three levels at the aggregates whose gentle child fits
+    pc = pb.ricc_problem(40, 0.0005)
+    calAc = (-pc.A - pc.Nc).T.tocsr()
+    assert not _lib.host_sa_criterion(calAc)[0]
+    p = _lib.host_plan_levels(calAc, calE, pc.J, coarse_max=400)
+    assert p["levels"] == 3 and not p["smoothed"] and p["kc"] > 400 and 0.55 * p["kcv"] + p["kcp"] <= 400, p
+    # ... unless the caller asks for two levels only
+    p2 = _lib.host_plan_levels(calAc, calE, pc.J, coarse_max=400, max_levels=2)
+    assert p2["levels"] == 2 and p2["kc"] <= 400, p2
+    # no coarse level at all
+    assert _lib.host_plan_levels(calA, calE, pr.J, use_coarse=0)["levels"] == 1
