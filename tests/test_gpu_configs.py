@@ -170,6 +170,29 @@ def test_third_level_forced_small_problem(monkeypatch):
     print("forced third level: iterations", its3, "two-level", its2)
 
 
+def test_stiff_operator_keeps_two_levels_with_grown_aggregates(monkeypatch):
+    """The hierarchy rule of round 4 (ricadi_host.cpp:build_setup, host side tested in test_capi_cpu.py): the
+    diffusion-dominated operator whose coarse matrix exceeds coarse_max keeps TWO levels -- smoothed prolongation,
+    dense inverse of up to 1.5 x coarse_max, aggregates grown for it -- and the batched solves meet the tolerance in
+    the true residual; the same operator with plain aggregation (RICADI_SA=0) takes the child level and must not
+    need fewer iterations (measured at n = 2e5: 2 142 vs 1 422 over 16 shifts)."""
+    pr = pb.ricc_problem(30, 0.05)
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    ms = [float(p) for p in pb.logshifts(1.0, 1e3, 8)]
+    R = np.random.default_rng(6).standard_normal((pr.NV, 16))
+    i2 = {}
+    its2, w2 = _batched_properties(calA, pr.M.T.tocsr(), pr.J, ms, R, coarse_max=300, info=i2)
+    assert i2["levels"] == 2 and 300 < i2["kc"] <= 450, i2
+    plan = _lib.host_plan_levels(calA, pr.M.T.tocsr(), pr.J, coarse_max=300)
+    assert plan["levels"] == 2 and plan["smoothed"] and plan["kc"] == i2["kc"], (plan, i2)
+    monkeypatch.setenv("RICADI_SA", "0")
+    i3 = {}
+    its3, w3 = _batched_properties(calA, pr.M.T.tocsr(), pr.J, ms, R, coarse_max=300, info=i3)
+    assert i3["levels"] == 3, i3
+    assert sum(its2) <= sum(its3), (its2, its3)
+    print("stiff operator: two levels (smoothed)", its2, "child level (plain)", its3)
+
+
 def test_cfg5_batched_shift_solves_properties():
     """cfg5: N = 236 (NV = 443 682, NP = 56 168, n = 499 850, nnz(S) = 14.4e6), 16 of the
     128 shifts in one batch, m = 16."""
