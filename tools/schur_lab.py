@@ -1,0 +1,149 @@
+"""Developer lab (CPU only): the device preconditioner cycle on a scipy mirror, with variants of the PRESSURE step.
+  base:   z = Y E^-1 Y^T r ;  z += SIMPLE(r - S z)      (plain aggregation (16, 24), 32-blocks; as shipped without smoothing)
+  schur2: the SIMPLE sweep's Schur solve  z_p = B_S t  is two-level: coarse Galerkin of S^ = J A^^-1 J^T on the pressure
+          aggregates first, then the block-Jacobi sweep on the updated t
+python tools/schur_lab.py N nu [dre]"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sps
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optconpy_amd import _lib, problems as pb  # noqa: E402
+
+
+def agg(graph, size):
+    g = sps.csr_matrix(graph)
+    g.sort_indices()
+    blk, nb = _lib.host_aggregate(g, size)
+    return np.asarray(blk), nb
+
+
+def bj_inverse(Mat, blk, nb):
+    """Block-diagonal inverse of Mat for the partition blk (sparse)."""
+    order = np.argsort(blk, kind="stable")
+    cnt = np.bincount(blk, minlength=nb)
+    ptr = np.r_[0, np.cumsum(cnt)]
+    Mp = sps.csr_matrix(Mat)[order][:, order].tocsr()
+    invs = [np.linalg.inv(Mp[ptr[b]:ptr[b + 1], ptr[b]:ptr[b + 1]].toarray()) for b in range(nb)]
+    n = len(order)
+    Pm = sps.csr_matrix((np.ones(n), (np.arange(n), order)), shape=(n, n))
+    return (Pm.T @ sps.block_diag(invs) @ Pm).tocsr()
+
+
+def gmres_right(S, P, b, tol=1e-10, restart=30, maxit=1500):
+    """Right-preconditioned restarted GMRES (MGS), iterations to relative residual tol."""
+    x = np.zeros_like(b)
+    bn = np.linalg.norm(b)
+    its = 0
+    while its < maxit:
+        r = b - S @ x
+        beta = np.linalg.norm(r)
+        if beta <= tol * bn:
+            break
+        V = [r / beta]
+        Z = []
+        H = np.zeros((restart + 1, restart))
+        k = 0
+        for j in range(restart):
+            z = P(V[j])
+            w = S @ z
+            for i in range(j + 1):
+                H[i, j] = V[i] @ w
+                w = w - H[i, j] * V[i]
+            for i in range(j + 1):
+                h = V[i] @ w
+                H[i, j] += h
+                w = w - h * V[i]
+            H[j + 1, j] = np.linalg.norm(w)
+            V.append(w / H[j + 1, j])
+            Z.append(z)
+            its += 1
+            k = j + 1
+            e1 = np.zeros(k + 1)
+            e1[0] = beta
+            y, res, _, _ = np.linalg.lstsq(H[:k + 1, :k], e1, rcond=None)
+            rn = np.linalg.norm(H[:k + 1, :k] @ y - e1)
+            if rn <= tol * bn or its >= maxit:
+                break
+        x = x + np.column_stack(Z[:k]) @ y
+    return x, its
+
+
+def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24):
+    nv, npp = Ap.shape[0], J.shape[0]
+    S = sps.bmat([[Ap, J.T], [J, None]], format="csr")
+    blk, nb = agg(abs(Ap), bs)
+    pp = (abs(J) @ abs(J).T).tocsr()
+    pblk, npb = agg(pp, bs)
+    Ainv = bj_inverse(Ap, blk, nb)
+    Sh = (J @ Ainv @ J.T).tocsr()
+    Sinv = bj_inverse(Sh, pblk, npb)
+    va, kv = agg(gv, av)
+    pa, kp = agg(pp, ap)
+    Yv = sps.csr_matrix((np.ones(nv), (np.arange(nv), va)), shape=(nv, kv))
+    Yp = sps.csr_matrix((np.ones(npp), (np.arange(npp), pa)), shape=(npp, kp))
+    Y = sps.block_diag([Yv, Yp]).tocsr()
+    Einv = np.linalg.inv((Y.T @ S @ Y).toarray())
+    if variant.startswith("schur2"):
+        fine = variant.endswith("f")       # finer pressure aggregates for the Schur coarse space
+        if fine:
+            pa2, kp2 = agg(pp, 8)
+            Yq = sps.csr_matrix((np.ones(npp), (np.arange(npp), pa2)), shape=(npp, kp2))
+        else:
+            Yq = Yp
+        Scinv = np.linalg.inv((Yq.T @ Sh @ Yq).toarray())
+
+    def schur_solve(t):
+        if variant.startswith("schur2"):
+            zc = Yq @ (Scinv @ (Yq.T @ t))
+            return zc + Sinv @ (t - Sh @ zc)
+        return Sinv @ t
+
+    def simple(r):
+        zv = Ainv @ r[:nv]
+        zp = schur_solve(J @ zv - r[nv:])
+        zv = zv - Ainv @ (J.T @ zp)
+        return np.r_[zv, zp]
+
+    def P(r):
+        if variant == "nocoarse":
+            return simple(r)
+        z = Y @ (Einv @ (Y.T @ r))
+        return z + simple(r - S @ z)
+    return S, P, (kv, kp)
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1])
+    nu = float(sys.argv[2])
+    dre = len(sys.argv) > 3 and sys.argv[3] == "dre"
+    pr = pb.ricc_problem(N, nu)
+    MT = pr.M.T.tocsr()
+    if dre:
+        tau = float(np.diff(pb.get_tint(0.0, 1.0, 16, True)).max())
+        calA = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
+    else:
+        calA = (-pr.A - pr.Nc).T.tocsr()
+    rng = np.random.default_rng(1)
+    b = np.r_[rng.standard_normal(pr.NV), np.zeros(pr.NP)]
+    print("N = %d, nu = %g%s, n = %d" % (N, nu, " (DRE operator)" if dre else "", pr.NV + pr.NP))
+    cases = [("mass only", 1.0, 0.0)] + [("p = %g" % p, -p, 1.0) for p in (1.0, 30.0, 300.0, 3000.0)]
+    sel = [a for a in sys.argv[3:] if a != "dre"] or ["base", "schur2", "schur2f"]
+    for variant in sel:
+        row = []
+        t0 = time.time()
+        for name, al, be in cases:
+            Ap = (be * calA + al * MT).tocsr()
+            kw = {}
+            if variant.startswith("ap"):          # "ap8": base cycle with pressure aggregates of 8
+                kw = dict(ap=int(variant[2:]))
+            if variant.startswith("av"):          # "av8": base cycle with velocity aggregates of 8
+                kw = dict(av=int(variant[2:]))
+            S, P, kk = make_precond(Ap, pr.J, MT, "base" if kw else variant, **kw)
+            x, its = gmres_right(S, P, b)
+            row.append(its)
+        print("%-10s %s   coarse (kv, kp) = %s  (%.0f s)" % (variant, "  ".join("%s: %d" % (c[0], i) for c, i in zip(cases, row)), kk,
+                                                          time.time() - t0), flush=True)
