@@ -295,6 +295,7 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx_ms, syb_lidx_ms;
   bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
   int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
+  bool mid32 = true;          // RICADI_MID32=0: the velocity part between the sweeps of a cycle stays an FP64 panel
   // low rank
   int q = 0;
   DArr<double> U, V, lrc, scratch;

@@ -144,6 +144,7 @@ struct ProlongArgs {
   float* out32 = nullptr;   // if set: FP32 copy of what the sweep writes (flexible GMRES keeps Z_j = P^-1 v_j)
   size_t gs32 = 0;
   int only32 = 0;           // with out32: the FP64 result is not stored (the operator reads the FP32 copy)
+  int old32 = 0;            // rectangle sweep: the rows it updates are read from out32 (FP32 intermediate of the cycle)
 };
 
 // Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for
@@ -389,16 +390,17 @@ void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a
 // meta: per (block, row of the block) five ints {pressure-local row or -1, J row range [k0, k1), (S Y) pressure-row
 // range [s0, s1)} at stride 5 (ricadi_ctx::ps_meta); with_sy = false: no coarse term; z is the n x 16 panel whose
 // velocity rows are read, rp_ / rp16 the pressure rows of the residual (FP64 or FP16-stored), out the pressure rows of z.
+// zv32 (optional, group stride gsz32): the velocity rows as the FP32 panel the first sweep left (64-B row gathers).
 void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
                             const GroupPtrsF& inv, const int* jci, const double* jv, const double* z,
                             size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
-                            const ProlongArgs& pa);
+                            const ProlongArgs& pa, const float* zv32 = nullptr, size_t gsz32 = 0);
 void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
                             const GroupPtrs& inv, const int* jci, const double* jv, const double* z,
                             size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
-                            const ProlongArgs& pa);
+                            const ProlongArgs& pa, const float* zv32 = nullptr, size_t gsz32 = 0);
 
 // K3h: last Arnoldi pass + Hessenberg / Givens update in one launch (FP16 basis, m = 16)
 bool update_hess_fused_ok(int m, bool fp16_basis);

@@ -312,14 +312,31 @@ __global__ __launch_bounds__(256) void block_apply_rect_kernel(
     }
     // old output and coarse part: again all loads together, without conditions
     double oldv[NT][4], ecv[NT][4];
+    if (pa.old32) {               // uniform: the FP32 intermediate of the cycle (raw loads first, conversion behind them)
+      const float* __restrict__ o32 = pa.out32 + (size_t)grp * pa.gs32;
+      float oldf[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        oldv[t][e] = out[(size_t)orow[t][e] * ldo + colx];
-        ecv[t][e] = ecp[(size_t)oagg[t][e] * m + colx];
-      }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < 4; ++e) {
+          oldf[t][e] = o32[(size_t)orow[t][e] * ldo + colx];
+          ecv[t][e] = ecp[(size_t)oagg[t][e] * m + colx];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oldv[t][e] = (double)oldf[t][e];
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          oldv[t][e] = out[(size_t)orow[t][e] * ldo + colx];
+          ecv[t][e] = ecp[(size_t)oagg[t][e] * m + colx];
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -504,7 +521,8 @@ __global__ __launch_bounds__(256) void block_apply2_kernel(
           double v = acc1[t][e] - acc2[t][e];
           if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + (size_t)row * ldo + col] = v;
           if (ec) v += ec[(size_t)pa.aggof[row] * m + col];
-          out[(size_t)row * ldo + col] = v;
+          if (!(pa.out32 && pa.only32)) out[(size_t)row * ldo + col] = v;
+          if (pa.out32) pa.out32[(size_t)grp * pa.gs32 + (size_t)row * ldo + col] = (float)v;
         }
       }
   }
@@ -1163,10 +1181,10 @@ void launch_to_f32(hipStream_t st, int nrows, int ncols, const double* src, int 
 // Indices are loaded unconditionally (clamped to the row's last entry, the value zeroed instead): no exec-masked
 // load blocks, cf. the scheduling rule in DESIGN.md.
 // ---------------------------------------------------------------------------
-template <class T, class RT>
+template <class T, class RT, class ZT>
 __global__ __launch_bounds__(512) void pressure_step_kernel(
     GroupTab gt, const int* __restrict__ meta, GroupPtrsT<T> invs,
-    const int* __restrict__ jci, const double* __restrict__ jv, const double* __restrict__ z, size_t gsz,
+    const int* __restrict__ jci, const double* __restrict__ jv, const ZT* __restrict__ z, size_t gsz,
     int with_sy, const int* __restrict__ syci, GroupPtrs syv, const double* __restrict__ ec, size_t gse,
     const RT* __restrict__ rp_, size_t gsr, double* __restrict__ out, size_t gso, ProlongArgs pa) {
   __shared__ double tl[32][17];
@@ -1219,7 +1237,7 @@ __global__ __launch_bounds__(512) void pressure_step_kernel(
   {                                                         \
     const int c0 = bc16i<TT>(myc);                          \
     const double v0 = bc16d<TT>(myv);                       \
-    acc = fma(v0, z[(size_t)c0 * 16 + g], acc);             \
+    acc = fma(v0, (double)z[(size_t)c0 * 16 + g], acc);     \
   }
     RICADI_FOR16(RICADI_PS_STEP)
 #undef RICADI_PS_STEP
@@ -1274,32 +1292,33 @@ static void pressure_step_impl(hipStream_t st, const GroupTab& gt, int nblocks, 
                                const GroupPtrsT<T>& inv, const int* jci, const double* jv, const double* z,
                                size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec,
                                size_t gse, const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
-                               const ProlongArgs& pa) {
+                               const ProlongArgs& pa, const float* zv32, size_t gsz32) {
   if (nblocks <= 0 || gt.ng <= 0) return;
   dim3 grid(nblocks, 1, gt.ng), block(512);
-  if (rp16)
-    hipLaunchKernelGGL((pressure_step_kernel<T, _Float16>), grid, block, 0, st, gt, meta, inv, jci, jv, z, gsz,
-                       with_sy ? 1 : 0, syci, syv, ec, gse, rp16, gsr, out, gso, pa);
-  else
-    hipLaunchKernelGGL((pressure_step_kernel<T, double>), grid, block, 0, st, gt, meta, inv, jci, jv, z, gsz,
-                       with_sy ? 1 : 0, syci, syv, ec, gse, rp_, gsr, out, gso, pa);
+#define RICADI_PS(RT, ZT, rp, zp, gz)                                                                              \
+  hipLaunchKernelGGL((pressure_step_kernel<T, RT, ZT>), grid, block, 0, st, gt, meta, inv, jci, jv, zp, gz,        \
+                     with_sy ? 1 : 0, syci, syv, ec, gse, rp, gsr, out, gso, pa)
+  if (rp16 && zv32) RICADI_PS(_Float16, float, rp16, zv32, gsz32);
+  else if (rp16) RICADI_PS(_Float16, double, rp16, z, gsz);
+  else if (zv32) RICADI_PS(double, float, rp_, zv32, gsz32);
+  else RICADI_PS(double, double, rp_, z, gsz);
+#undef RICADI_PS
 }
 void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
                             const GroupPtrsF& inv, const int* jci, const double* jv, const double* z,
                             size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
-                            const ProlongArgs& pa) {
+                            const ProlongArgs& pa, const float* zv32, size_t gsz32) {
   pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, z, gsz, with_sy, syci, syv, ec, gse, rp_, rp16, gsr, out, gso,
-                     pa);
+                     pa, zv32, gsz32);
 }
 void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
                             const GroupPtrs& inv, const int* jci, const double* jv, const double* z,
                             size_t gsz, bool with_sy, const int* syci, const GroupPtrs& syv, const double* ec, size_t gse,
                             const double* rp_, const _Float16* rp16, size_t gsr, double* out, size_t gso,
-                            const ProlongArgs& pa) {
+                            const ProlongArgs& pa, const float* zv32, size_t gsz32) {
   pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, z, gsz, with_sy, syci, syv, ec, gse, rp_, rp16, gsr, out, gso,
-                     pa);
+                     pa, zv32, gsz32);
 }
-
 
 }  // namespace ricadi

@@ -419,6 +419,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
     c->ms_spmm = e[0] != '0';
     c->ms_force = e[0] == '2';
   }
+  if (const char* e = getenv("RICADI_MID32")) c->mid32 = e[0] != '0';
   // multi-shift kernel operands: vAJ = A part + J part (disjoint supports) and vE in tile
   // order; velocity-velocity flag in bit 15 of the local index
   auto ms_arrays = [&](const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& a,
@@ -1043,9 +1044,9 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         break;
       case 8:
         if (b16 && precond_reads_h16(c, m))
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, false, Vh);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m), Vh);
         else
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m));
         break;
       case 9:
         if (c->kc <= 0) throw HipError{"no coarse level"};
@@ -1057,9 +1058,9 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         Restore<int> keep(c->pc_stage);
         c->pc_stage = which - 10;
         if (b16 && precond_reads_h16(c, m))
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, false, Vh);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m), Vh);
         else
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m));
         break;
       }
       default:

@@ -190,6 +190,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   // the pressure step -- pressure rows of r - (S Y) e, J product, Schur sweep -- as ONE launch (K2p) for
   // 16-column panels (RICADI_PFUSE=0: the three launches of round 2)
   const bool fusedp = np > 0 && m == 16 && c->bs == 32;
+  // The velocity part between the three sweeps (first sweep -> pressure step's J product -> last sweep) as an FP32
+  // panel: where only the FP32 copy of z is wanted anyway (the operator reads Z_j as stored), the first sweep writes
+  // the velocity rows of z32 itself, the pressure step gathers 64-B instead of 128-B rows and the last sweep updates
+  // them in place.  Rounding the intermediate to FP32 perturbs the (flexible) preconditioner by what its FP32
+  // inverses and the FP32-stored Z_j already do.
+  const bool mid32 = c->mid32 && z32 && only32 && fusedp && precond_folds(c) && c->gt_ok && c->precond32;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
@@ -285,9 +291,15 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     s2.kstride = c->ady_ks;
     s2.in = c->ec.p;
     s2.gs = bt.gsc;
+    ProlongArgs fpa;
+    if (mid32) {
+      fpa.out32 = z32;
+      fpa.gs32 = gs32;
+      fpa.only32 = 1;
+    }
     if (c->precond32)
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, s1, bt.adymf, s2, z, m,
-                            bt.gs, m, ProlongArgs());
+                            bt.gs, m, fpa);
     else
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, s1, bt.adym, s2, z, m,
                             bt.gs, m, ProlongArgs());
@@ -328,7 +340,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       const size_t gsrp = sy ? gsr : gsrr;
       if (c->precond32)
         launch_pressure_step_b(st, gt, c->nbp, c->ps_meta.p, bt.bpinvf, c->J.ci.p, c->J.v.p, z, bt.gs, sy, c->sy_ci.p,
-                               bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro);
+                               bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro, mid32 ? z32 : nullptr,
+                               gs32);
       else
         launch_pressure_step_b(st, gt, c->nbp, c->ps_meta.p, bt.bpinv, c->J.ci.p, c->J.v.p, z, bt.gs, sy, c->sy_ci.p,
                                bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro);
@@ -348,6 +361,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       pro.out32 = z32;
       pro.gs32 = gs32;
       pro.only32 = only32;
+      pro.old32 = mid32 ? 1 : 0;
       mirrored = true;
       if (c->precond32)
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,

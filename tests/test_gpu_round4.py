@@ -311,3 +311,35 @@ def test_storage_escalation_on_the_dre_operator_at_1e5():
         assert rel(b["zfac"] @ (b["zfac"].T @ W), a["zfac"] @ (a["zfac"].T @ W)) < 1e-7
     finally:
         backend.configure()
+
+
+# ------------------------------------------------------------------ FP32 intermediate of the preconditioner cycle
+def test_fp32_intermediate_of_the_cycle_against_sparse_lu(cfg1, monkeypatch):
+    """The velocity part between the three sweeps of a preconditioner cycle is an FP32 panel by default (first sweep ->
+    64-B row gathers of the pressure step -> last sweep in place; RICADI_MID32=0: the FP64 panel of rounds 1-3).  It
+    only changes the (flexible) preconditioner: both storages solve three shifts of a 16-column panel to the tolerance,
+    agree with the sparse LU (SuperLU, tests/test_units_compfacres_compress.py:70) and need the same number of
+    iterations within a few."""
+    import torch
+    pr = cfg1[0]
+    calA = (-pr.A - pr.Nc).T.tocsr()
+    MT = pr.M.T.tocsr()
+    rng = np.random.default_rng(32)
+    R = rng.standard_normal((pr.NV, 16))
+    ps = [-1.0, -40.0, -1500.0]
+    refs = [olau.SaddleLU(calA + p * MT, pr.J).solve(R) for p in ps]
+    iters = {}
+    for mid in ("1", "0"):
+        monkeypatch.setenv("RICADI_MID32", mid)
+        with _lib.Context(0) as ctx:
+            ctx.set_operator(calA, MT, pr.J)
+            Rd = torch.from_numpy(R).cuda()
+            Xd = torch.empty((len(ps), pr.NV + pr.NP, 16), dtype=torch.float64, device="cuda")
+            its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), Rd.data_ptr(), 0, 16, Xd.data_ptr())
+            ctx.synchronize()
+            X = Xd.cpu().numpy()
+        assert np.asarray(rr).max() <= 1e-10, mid
+        for g in range(len(ps)):
+            assert rel(X[g][:pr.NV], refs[g][:pr.NV]) < 1e-8, (mid, g)
+        iters[mid] = np.asarray(its, dtype=float)
+    assert np.abs(iters["1"] - iters["0"]).max() <= 3, iters
