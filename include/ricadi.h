@@ -368,7 +368,9 @@ int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_
  *        route the last batch of dense coarse inverses took (0 block Gauss-Jordan without pivoting, 1 rocSOLVER
  *        with partial pivoting; -1 none yet),
  *        kernel of the last saddle SpMM launch (0 CSR, 1 LDS-tiled per group, 2 LDS-tiled multi-shift; +4 with
- *        FP32 x input; -1 none yet)];
+ *        FP32 x input; -1 none yet),
+ *        1 if the last preconditioner application kept the velocity part between its sweeps as an FP32 panel
+ *        (first sweep -> pressure step -> last sweep), 0 for an FP64 panel; -1 none yet];
  * nout >= 8; entries beyond nout are not written.                                   */
 int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
 

@@ -296,6 +296,7 @@ struct ricadi_ctx {
   bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
   int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
   bool mid32 = true;          // RICADI_MID32=0: the velocity part between the sweeps of a cycle stays an FP64 panel
+  int mid32_last = -1;        // what the last preconditioner application did (1 FP32 panel, 0 FP64; -1 none yet)
   // low rank
   int q = 0;
   DArr<double> U, V, lrc, scratch;

@@ -1135,6 +1135,9 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   // group, 2 LDS-tiled multi-shift, +4: FP32 x input; -1 none yet)
   if (nout > 17) out[17] = lc->coarse_route;
   if (nout > 18) out[18] = c->k1_variant;
+  // [19]: the last preconditioner application kept the velocity part between its sweeps as an FP32 panel (1) or as
+  // an FP64 panel (0); -1 none yet
+  if (nout > 19) out[19] = c->mid32_last;
   return RICADI_OK;
 }
 

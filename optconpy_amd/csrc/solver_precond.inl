@@ -196,6 +196,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   // them in place.  Rounding the intermediate to FP32 perturbs the (flexible) preconditioner by what its FP32
   // inverses and the FP32-stored Z_j already do.
   const bool mid32 = c->mid32 && z32 && only32 && fusedp && precond_folds(c) && c->gt_ok && c->precond32;
+  c->mid32_last = mid32 ? 1 : 0;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
