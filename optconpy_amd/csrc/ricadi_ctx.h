@@ -252,6 +252,9 @@ struct ricadi_ctx {
   DevCsr A, E, J, JT;
   DArr<int> bv_ptr, bv_rows, bp_ptr, bp_rows, jd_ptr, jd_vblk;
   DArr<int> ps_meta;          // fused pressure step: {row, J range, (S Y) range} per (Schur block, row), stride 5
+  // velocity sweeps: fixed-stride record per block (layout: ProlongArgs::bmeta); offsets of the two input lists
+  DArr<int> sw_meta;
+  int sw_stride = 0, sw_in_rect = 0, sw_in_two = 0;
   DArr<double> bvA, bvE, jd_val;
   DArr<int> agg_ptr, agg_rows, aggof;
   // last velocity sweep in rectangular form: per velocity block the pressure dofs its rows touch

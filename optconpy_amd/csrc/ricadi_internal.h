@@ -145,6 +145,12 @@ struct ProlongArgs {
   size_t gs32 = 0;
   int only32 = 0;           // with out32: the FP64 result is not stored (the operator reads the FP32 copy)
   int old32 = 0;            // rectangle sweep: the rows it updates are read from out32 (FP32 intermediate of the cycle)
+  // Fixed-stride record per 32-row block (ricadi_ctx::sw_meta): {nb, ni of the rectangle sweep, ni of the two-term
+  // sweep, 0 | rows[32] | aggregate of every row [32] | input rows of the rectangle sweep | of the two-term sweep},
+  // lists padded with their last entry.  With it a wave has every index after ONE load round (block pointers ->
+  // row lists -> aggregate map were three dependent ones); bm_in = offset of the launched sweep's input list.
+  const int* bmeta = nullptr;
+  int bm_stride = 0, bm_in = 0, bm_ni = 0;   // bm_ni: which header word holds ni (1 or 2)
 };
 
 // Low-rank term fused into an SpMM epilogue:  y[row, :] -= U[row, :] * c  for

@@ -214,6 +214,236 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
 }
 
 // ---------------------------------------------------------------------------
+// K2, the two velocity sweeps of the folded cycle for THE hot shape (32-row blocks, 16-column panels), round 4.
+// The generic kernels above spend their time in dependent load rounds, not in bytes: block pointers -> row / input
+// lists -> aggregate map -> gathers -> rows to update -> stores is five round trips per wave at 2-4 waves per SIMD
+// (with the FP32 intermediate the last sweep moved 40 % fewer bytes in the same 738 us at n = 5e5).  Here
+//   * every index of a block comes out of ONE fixed-stride record (ricadi_ctx::sw_meta, layout at
+//     ProlongArgs::bmeta: lists padded with their last entry, the aggregate of every row stored with it);
+//   * the gathers, the matrix tiles AND the rows the wave updates are requested together (the old rows do not
+//     depend on the products);
+//   * addresses are 32-bit byte offsets from uniform bases (one VGPR per load in flight instead of two), no column
+//     loop, no column masks.
+// So a wave needs two rounds (record, data) before its MFMAs.
+// ---------------------------------------------------------------------------
+template <class V>
+__device__ __forceinline__ V ld_off(const V* base, unsigned byteoff) {
+  return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byteoff);
+}
+template <int KS, class T, bool OLD32>
+__global__ __launch_bounds__(256) void block_rect32_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ meta, int mstride, int in_off, GroupPtrsT<T> mats,
+    const double* __restrict__ in, size_t gsi, double* __restrict__ out, size_t gso, int subtract, ProlongArgs pa) {
+  const int grp = gt.gid[blockIdx.z];
+  const T* __restrict__ mat = mats.p[grp];
+  in += (size_t)grp * gsi;
+  out += (size_t)grp * gso;
+  const double* __restrict__ ec = pa.aggof ? pa.ec + (size_t)grp * pa.gse : nullptr;
+  float* __restrict__ o32 = pa.out32 ? pa.out32 + (size_t)grp * pa.gs32 : nullptr;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  if (wave >= nblocks) {
+    // surplus waves: coarse-level prolongation of the rows outside the blocks
+    const int e0 = (wave - nblocks) * 32;
+    for (int rr = e0 + q; rr < min(e0 + 32, pa.nextra); rr += 4) {
+      const int row = pa.row0 + rr;
+      const double v = out[(size_t)row * 16 + r] + ec[(size_t)pa.aggof[row] * 16 + r];
+      out[(size_t)row * 16 + r] = v;
+      if (o32) o32[(size_t)row * 16 + r] = (float)v;
+    }
+    return;
+  }
+  constexpr int NK = KS / 16;
+  const int* __restrict__ mt = meta + (size_t)wave * mstride;
+  const T* __restrict__ Gi = mat + (size_t)wave * 32 * KS;
+  // round 1: the record
+  const int nb = mt[0], ni = mt[1];
+  int xrow[NK][4], orow[2][4], oagg[2][4];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) xrow[kc][s2] = mt[in_off + kc * 16 + 4 * q + s2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      orow[t][e] = mt[4 + 16 * t + q + 4 * e];
+      oagg[t][e] = mt[36 + 16 * t + q + 4 * e];
+    }
+  // round 2: gathers, tiles, old rows, coarse part -- raw values, converted behind the barrier
+  const double* __restrict__ ecp = ec ? ec : in;         // a readable dummy when there is no coarse part
+  double xb[NK][4], ecv[2][4], oldv[2][4];
+  float oldf[2][4];
+  typename Raw4<T>::type graw[2][NK];
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) xb[kc][s2] = ld_off(in, (unsigned)(xrow[kc][s2] * 16 + r) * 8u);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kc = 0; kc < NK; ++kc) graw[t][kc] = Raw4<T>::load(Gi + (16 * t + r) * KS + kc * 16 + 4 * q);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (OLD32) oldf[t][e] = ld_off(o32, (unsigned)(orow[t][e] * 16 + r) * 4u);
+      else oldv[t][e] = ld_off(out, (unsigned)(orow[t][e] * 16 + r) * 8u);
+      ecv[t][e] = ld_off(ecp, (unsigned)(oagg[t][e] * 16 + r) * 8u);
+    }
+  // pinned: the optimiser otherwise sinks the gathers (and their index loads) into the conditional chunks below,
+  // behind the barrier -- one more dependent round per chunk
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) asm volatile("" : "+v"(xb[kc][s2]));
+  __builtin_amdgcn_sched_barrier(0);
+  d4 acc[2];
+  acc[0] = acc[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kc = 0; kc < NK; ++kc) {
+    if (kc * 16 >= ni) break;                 // wave-uniform: chunks beyond the block's inputs
+    double xm[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) xm[s2] = (kc * 16 + 4 * q + s2 < ni) ? xb[kc][s2] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double a4[4];
+      Raw4<T>::unpack(graw[t][kc], a4);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[0], xm[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[1], xm[1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[2], xm[2], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[3], xm[3], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = 16 * t + q + 4 * e;
+      if (il < nb) {
+        const unsigned at = (unsigned)(orow[t][e] * 16 + r);
+        const double old = OLD32 ? (double)oldf[t][e] : oldv[t][e];
+        double v = subtract ? old - acc[t][e] : acc[t][e];
+        if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + at] = v;        // the result before the coarse part
+        if (ec) v += ecv[t][e];
+        if (!(o32 && pa.only32)) out[at] = v;
+        if (o32) o32[at] = (float)v;
+      }
+    }
+}
+
+// first sweep:  out[rows_b] = M1_b * in1[rows_b] - M2_b * in2[list2_b]   (block_apply2_kernel for the hot shape)
+template <int K2, class T, bool H1>
+__global__ __launch_bounds__(256) void block_two32_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ meta, int mstride, int in_off, GroupPtrsT<T> m1s, Seg2 s1,
+    GroupPtrsT<T> m2s, Seg2 s2, double* __restrict__ out, size_t gso, ProlongArgs pa) {
+  const int grp = gt.gid[blockIdx.z];
+  out += (size_t)grp * gso;
+  float* __restrict__ o32 = pa.out32 ? pa.out32 + (size_t)grp * pa.gs32 : nullptr;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= nblocks) return;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  constexpr int N2 = K2 / 16;
+  const T* __restrict__ M1 = m1s.p[grp] + (size_t)wave * 32 * 32;
+  const T* __restrict__ M2 = m2s.p[grp] + (size_t)wave * 32 * K2;
+  const double* __restrict__ in1 = s1.in ? s1.in + (size_t)grp * s1.gs : nullptr;
+  const _Float16* __restrict__ in1h = s1.in16 ? s1.in16 + (size_t)grp * s1.gs : nullptr;
+  const double* __restrict__ in2 = s2.in + (size_t)grp * s2.gs;
+  const int* __restrict__ mt = meta + (size_t)wave * mstride;
+  // round 1: the record (lists padded with valid rows: no condition on any address)
+  const int nb = mt[0], ni = mt[2];
+  int r1[2][4], r2[N2][4], orow[2][4];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) r1[kc][s4] = mt[4 + kc * 16 + 4 * q + s4];
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) r2[kc][s4] = mt[in_off + kc * 16 + 4 * q + s4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) orow[t][e] = mt[4 + 16 * t + q + 4 * e];
+  // round 2: both input panels and the four / six matrix tiles, raw
+  _Float16 h1[2][4];
+  double x1[2][4], x2[N2][4];
+  typename Raw4<T>::type a1[2][2], a2[2][N2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if (H1) h1[kc][s4] = ld_off(in1h, (unsigned)(r1[kc][s4] * 16 + r) * 2u);
+      else x1[kc][s4] = ld_off(in1, (unsigned)(r1[kc][s4] * 16 + r) * 8u);
+    }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x2[kc][s4] = ld_off(in2, (unsigned)(r2[kc][s4] * 16 + r) * 8u);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) a1[t][kc] = Raw4<T>::load(M1 + (16 * t + r) * 32 + kc * 16 + 4 * q);
+#pragma unroll
+    for (int kc = 0; kc < N2; ++kc) a2[t][kc] = Raw4<T>::load(M2 + (16 * t + r) * K2 + kc * 16 + 4 * q);
+  }
+  // pinned (see block_rect32_kernel): the second segment's gathers are used under a wave-uniform condition
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(x2[kc][s4]));
+  __builtin_amdgcn_sched_barrier(0);
+  d4 acc[2];
+  acc[0] = acc[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    double xm[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double v = H1 ? (double)h1[kc][s4] : x1[kc][s4];
+      xm[s4] = (kc * 16 + 4 * q + s4 < nb) ? v : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double a4[4];
+      Raw4<T>::unpack(a1[t][kc], a4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], xm[s4], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc) {
+    if (kc * 16 >= ni) break;                 // wave-uniform
+    double xm[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xm[s4] = (kc * 16 + 4 * q + s4 < ni) ? -x2[kc][s4] : 0.0;     // minus: one accumulator
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      double a4[4];
+      Raw4<T>::unpack(a2[t][kc], a4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[s4], xm[s4], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = 16 * t + q + 4 * e;
+      if (il < nb) {
+        const unsigned at = (unsigned)(orow[t][e] * 16 + r);
+        const double v = acc[t][e];
+        if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + at] = v;
+        if (!(o32 && pa.only32)) out[at] = v;
+        if (o32) o32[at] = (float)v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K2, rectangular form: the last velocity sweep of the SIMPLE cycle,
 //     z_v[rows_b] -= G_b * z_p[pcols_b],      G_b = Ahat_b^-1 * J^T[rows_b, pcols_b]   (BS x KS)
 // with the per-shift product G_b formed once at setup (gt_blocks_kernel) from the block-Jacobi
@@ -361,6 +591,16 @@ static void block_apply_rect_impl(hipStream_t st, const GroupTab& gt, int bs, in
   if (nblocks <= 0 || gt.ng <= 0) return;
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
+  if (pa.bmeta && bs == 32 && m == 16 && ldi == 16 && ldo == 16 && (ks == 32 || ks == 64) &&
+      std::max(gsi, gso) * 8 < ((size_t)1 << 32) && !(pa.old32 && !pa.out32)) {
+#define RICADI_RECT32(K, O)                                                                                  \
+  hipLaunchKernelGGL((block_rect32_kernel<K, T, O>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
+                     pa.bm_in, mats, in, gsi, out, gso, subtract, pa)
+    if (ks == 32) { if (pa.old32) RICADI_RECT32(32, true); else RICADI_RECT32(32, false); }
+    else { if (pa.old32) RICADI_RECT32(64, true); else RICADI_RECT32(64, false); }
+#undef RICADI_RECT32
+    return;
+  }
 #define RICADI_RECT(B, K)                                                                           \
   hipLaunchKernelGGL((block_apply_rect_kernel<B, K, T>), grid, block, 0, st, gt, nblocks, bptr, rows, \
                      iptr, irows, mats, in, ldi, gsi, out, ldo, gso, m, subtract, pa)
@@ -536,6 +776,16 @@ static void block_apply2_impl(hipStream_t st, const GroupTab& gt, int bs, int nb
   if (nblocks <= 0 || gt.ng <= 0) return;
   const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
   dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
+  if (pa.bmeta && bs == 32 && m == 16 && ldo == 16 && !pa.aggof && (s2.kstride == 32 || s2.kstride == 64) &&
+      std::max(std::max(gso, s1.gs), s2.gs) * 8 < ((size_t)1 << 32)) {
+#define RICADI_TWO32(K, H)                                                                                  \
+  hipLaunchKernelGGL((block_two32_kernel<K, T, H>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
+                     pa.bm_in, m1, s1, m2, s2, out, gso, pa)
+    if (s2.kstride == 32) { if (s1.in16) RICADI_TWO32(32, true); else RICADI_TWO32(32, false); }
+    else { if (s1.in16) RICADI_TWO32(64, true); else RICADI_TWO32(64, false); }
+#undef RICADI_TWO32
+    return;
+  }
   // H = first-segment rows read from an FP16 panel (s1.in16): its own instantiation -- both paths in one
   // kernel cost 148 instead of 128 VGPRs, i.e. one wave per SIMD less
 #define RICADI_BA2(B, K, H)                                                                              \

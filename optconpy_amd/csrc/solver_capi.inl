@@ -221,6 +221,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   c->J.upload(J, st);
   HostCsr JT = transpose(J);
   c->JT.upload(JT, st);
+  std::vector<int> sw_gptr, sw_gcols, sw_cptr, sw_ccols;      // host copies for the sweeps' fixed-stride records
   {
     // rectangular last sweep: pressure dofs touched by every velocity block, dense J^T slices
     c->gt_ok = false;
@@ -256,6 +257,8 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
         }
         c->gt_ptr.upload(gptr, st);
         c->gt_cols.upload(gcols, st);
+        sw_gptr = gptr;
+        sw_gcols = gcols;
         c->gt_jtd.upload(jtd, st);
         c->gt_ks = ks;
         c->gt_ok = true;
@@ -362,11 +365,51 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
         if (hs.sa) c->cy_dT.upload(dT, st);
         c->cy_ptr.upload(cptr, st);
         c->cy_cols.upload(ccols, st);
+        sw_cptr = cptr;
+        sw_ccols = ccols;
         c->cy_dA.upload(dA, st);
         c->cy_dE.upload(dE, st);
         c->cy_dJ.upload(dJ, st);
         c->ady_ks = ks;
         c->ady_ok = true;
+      }
+    }
+  }
+  {
+    // fixed-stride records of the velocity sweeps (block_apply2_kernel, block_apply_rect_kernel; ProlongArgs::bmeta)
+    c->sw_stride = 0;
+    if (hs.bs == 32 && hs.nbv > 0 && (c->gt_ok || c->ady_ok)) {
+      const int kr = c->gt_ok ? c->gt_ks : 0, k2 = c->ady_ok ? c->ady_ks : 0;
+      const int stride = 68 + kr + k2;
+      const std::vector<int>&gptr = sw_gptr, &gcols = sw_gcols, &cptr = sw_cptr, &ccols = sw_ccols;
+      std::vector<int> meta((size_t)hs.nbv * stride, 0);
+      bool ok = true;
+      for (int b = 0; b < hs.nbv && ok; ++b) {
+        int* mt = &meta[(size_t)b * stride];
+        const int b0 = hs.bv_ptr[b], nb = hs.bv_ptr[b + 1] - b0;
+        if (nb > 32 || nb <= 0) { ok = false; break; }
+        mt[0] = nb;
+        for (int i = 0; i < 32; ++i) {
+          const int row = hs.bv_rows[b0 + std::min(i, nb - 1)];
+          mt[4 + i] = row;
+          mt[36 + i] = hs.kc > 0 ? hs.aggof[row] : 0;
+        }
+        if (c->gt_ok) {
+          const int i0 = gptr[b], ni = gptr[b + 1] - i0;
+          mt[1] = ni;
+          for (int i = 0; i < kr; ++i) mt[68 + i] = ni > 0 ? gcols[i0 + std::min(i, ni - 1)] : 0;
+        }
+        if (c->ady_ok) {
+          const int i0 = cptr[b], ni = cptr[b + 1] - i0;
+          mt[2] = ni;
+          for (int i = 0; i < k2; ++i) mt[68 + kr + i] = ni > 0 ? ccols[i0 + std::min(i, ni - 1)] : 0;
+        }
+      }
+      if (ok && getenv("RICADI_SWEEP_META") == nullptr) {
+        c->sw_meta.upload(meta, st);
+        c->sw_stride = stride;
+        c->sw_in_rect = 68;
+        c->sw_in_two = 68 + kr;
       }
     }
   }

@@ -298,12 +298,18 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       fpa.gs32 = gs32;
       fpa.only32 = 1;
     }
+    if (c->sw_stride > 0 && c->bs == 32) {
+      fpa.bmeta = c->sw_meta.p;
+      fpa.bm_stride = c->sw_stride;
+      fpa.bm_in = c->sw_in_two;
+      fpa.bm_ni = 2;
+    }
     if (c->precond32)
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, s1, bt.adymf, s2, z, m,
                             bt.gs, m, fpa);
     else
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinv, s1, bt.adym, s2, z, m,
-                            bt.gs, m, ProlongArgs());
+                            bt.gs, m, fpa);
   } else {
     vel_apply(rr, gsrr, 0, np == 0);
   }
@@ -363,6 +369,12 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       pro.gs32 = gs32;
       pro.only32 = only32;
       pro.old32 = mid32 ? 1 : 0;
+      if (c->sw_stride > 0 && c->bs == 32) {
+        pro.bmeta = c->sw_meta.p;
+        pro.bm_stride = c->sw_stride;
+        pro.bm_in = c->sw_in_rect;
+        pro.bm_ni = 1;
+      }
       mirrored = true;
       if (c->precond32)
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
