@@ -216,24 +216,29 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=1)
     mid = ctx.setup_info().get("fp32_intermediate", 0) == 1
     zb = 4.0 if mid else 8.0
+    hot = m == 16 and info["bs"] == 32 and os.environ.get("RICADI_SWEEP_META") is None   # record-driven sweep kernels
     w64 = 0.0 if (mid or ctx.setup_info().get("k1_variant", 0) >= 4) else 8.0    # FP64 z stored by the last sweep?
     stages = {
-        "pc_restrict": ("ricadi::spmm_kernel_v2 (rows of P^T: smoothed aggregation, %.1f entries per dof)"
-                        % (info.get("nnz_restriction", n) / max(n, 1)) if info.get("nnz_restriction", n) > n
-                        else "ricadi::spmm_kernel_v2 (unit values, aggregate lists)",
+        "pc_restrict": (("ricadi::spmm_rowwave_kernel" if m == 16 and info.get("nnz_restriction", n) >= 32 * max(kc0, 1)
+                         else "ricadi::spmm_kernel_v2")
+                        + (" (rows of P^T: smoothed aggregation, %.1f entries per dof)"
+                           % (info.get("nnz_restriction", n) / max(n, 1)) if info.get("nnz_restriction", n) > n
+                           else " (unit values, aggregate lists)"),
                         G * (vin * n * m + 8.0 * kc0 * m) + (12.0 if info.get("nnz_restriction", n) > n else 4.0)
                         * info.get("nnz_restriction", n)),
         "pc_coarse": (models["coarse"][0] if info["levels"] <= 2 else "child level: one full cycle of its own stages",
                       models["coarse"][1] if info["levels"] <= 2 else None),
         "pc_sy_prows": ("ricadi::spmm_kernel_v2 (pressure rows of S*Y)", None),
-        "pc_two_term": ("ricadi::block_apply2_kernel<32,%d,%s,%s>" % (tk, fl, "true" if h16 else "false") if tk else
-                        "ricadi::block_apply_kernel<32,%s>" % fl,
+        "pc_two_term": (("ricadi::block_two32_kernel<%d,%s,%s>" if hot else "ricadi::block_apply2_kernel<32,%d,%s,%s>")
+                        % (tk, fl, "true" if h16 else "false") if tk else "ricadi::block_apply_kernel<32,%s>" % fl,
                         G * (pb_ * nb * 32.0 * (32 + tk) + (vin + zb) * nv * m + 8.0 * kc0 * m)),
         "pc_jprod": ("ricadi::spmm_kernel_v2 (J)", 12.0 * info.get("nnz_j", 0) + G * (8.0 * nv * m + 16.0 * npn * m)),
         "pc_schur": (("ricadi::block_apply_rect_kernel<32,32,%s> (block's own rows as input list)" % fl)
                      if info["nbp"] * G <= 8192 else "ricadi::block_apply_kernel<32,%s>" % fl,
                      G * (pb_ * info["nbp"] * 1024.0 + (8.0 + 8.0 + 8.0 + 4.0) * npn * m)),
-        "pc_rect": ("ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl) if rk else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
+        "pc_rect": (("ricadi::block_rect32_kernel<%d,%s,%s>" % (rk, fl, "true" if mid else "false") if hot else
+                     "ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl)) if rk
+                    else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
                     G * (pb_ * nb * 32.0 * max(rk, 32) + (zb + w64) * nv * m + 4.0 * n * m + 8.0 * npn * m
                          + 8.0 * kc0 * m)),
     }

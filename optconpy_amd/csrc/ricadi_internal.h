@@ -193,6 +193,14 @@ struct Seg2 {
   const _Float16* in16 = nullptr;   // segment 1 only: read the input rows from an FP16 panel instead of `in`
 };
 
+// y = A x for a CSR matrix with LONG rows (the restriction: one row per aggregate), one wave per row
+// (spmm_rowwave_kernel); x FP64 or FP16-stored (x16), panels of m = 16 columns (leading dimension 16), group strides
+// gsx / gsy.  spmm_rowwave_pays: rows long enough on average (>= 32 entries) for it to beat the 16-lane-per-row kernel.
+bool spmm_rowwave_pays(int nrows, size_t nnz);
+void launch_spmm_rowwave(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                         const GroupPtrs& vals, const double* x, const _Float16* x16, size_t gsx, double* y, size_t gsy,
+                         int m);
+
 // ---- kernel launchers (ricadi_kernels.hip) ---------------------------------
 // The *_b launchers are the batched forms (GroupTab + group strides `gs*`, in
 // doubles); the plain ones run a single panel.

@@ -262,6 +262,126 @@ void launch_spmm_h(hipStream_t st, const GroupTab& gt, int nrows, const int* rp,
 }
 
 // ---------------------------------------------------------------------------
+// K1b for LONG rows (the restriction P^T r of the preconditioner: one row per aggregate, 90 entries at cfg2, 390 at
+// n = 5e5): ONE WAVE per row.  spmm_kernel_v2 gives a row to a 16-lane group, which walks its chunks one after the
+// other -- index load, then 16 gathers, per chunk: two dependent rounds x 6 ... 24 chunks (17.5 us at cfg2, 201 us at
+// n = 5e5 = 0.18 of the HBM roofline).  Here the four 16-lane groups of the wave take every fourth chunk, the next
+// chunk's (index, value) pair travels while the current chunk's 16 gathers do, and the four partial sums meet in two
+// cross-row shuffles (first form of round 4: 201 -> 155 us at n = 5e5, nothing at cfg2; the form below replaced it).
+// Panels of 16 columns; no residual / scaling / low-rank terms.
+// ---------------------------------------------------------------------------
+typedef _Float16 rw_half8 __attribute__((ext_vector_type(8)));
+template <int CTRL>
+__device__ __forceinline__ double rw_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// Lane = (entry slot e = lane & 31, column half h = lane >> 5): per step a lane takes ONE entry and gathers the 8
+// columns of its half of the x row with 16-byte loads (FP16 x: one load; FP64 x: four) -- 32 entries per wave step and
+// one or four gather instructions, where the 16-lanes-per-row form issues 16 two-byte gathers per 16 entries and runs
+// at the rate of the address path (20 cycles per gather instruction and CU at cfg2), not of the bytes.  The next step's
+// (index, value) pair travels during the current gather; the 32 slots of a half are summed by four DPP exchanges and
+// one cross-row shuffle.  m = 16 only.
+template <class XT>
+__global__ __launch_bounds__(256) void spmm_rowwave_kernel(
+    GroupTab gt, int nrows, const int* __restrict__ rp, const int* __restrict__ ci, GroupPtrs vals,
+    const XT* __restrict__ x, size_t gsx, double* __restrict__ y, size_t gsy) {
+  const int grp = gt.gid[blockIdx.z];
+  const double* __restrict__ val = vals.p[grp];
+  x += (size_t)grp * gsx;
+  y += (size_t)grp * gsy;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;                                  // wave-uniform
+  const int lane = threadIdx.x & 63, e = lane & 31, h = lane >> 5;
+  const int k0 = rp[row], k1 = rp[row + 1];
+  const int klast = max(k1 - 1, k0);
+  double acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = 0.0;
+  // batches of 4 steps (128 entries): the four (index, value) pairs are one load round, the four gathers the next --
+  // a wave is a chain of dependent rounds (pointer -> pairs -> gathers -> ...), and with one step per round the launch
+  // ran at that chain's latency whatever the instruction mix (18 us at cfg2 for 17 MB)
+  constexpr int NB = 4;
+  const int nbatch = (k1 - k0 + 32 * NB - 1) / (32 * NB);
+  int cn[NB];
+  double vn[NB];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int k = kb + 32 * u + e;
+      cn[u] = ci[min(k, klast)];
+      const double v = val[min(k, klast)];
+      vn[u] = k < k1 ? v : 0.0;
+    }
+  };
+  if (nbatch > 0) fetch(k0);
+  for (int bi = 0; bi < nbatch; ++bi) {
+    int myc[NB];
+    double myv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      myc[u] = cn[u];
+      myv[u] = vn[u];
+    }
+    if constexpr (sizeof(XT) == 2) {
+      rw_half8 xv[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) xv[u] = *reinterpret_cast<const rw_half8*>(x + (size_t)myc[u] * 16 + h * 8);
+      if (bi + 1 < nbatch) fetch(k0 + (bi + 1) * 32 * NB);         // uniform; travels with the gathers
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = fma(myv[u], (double)xv[u][t], acc[t]);
+    } else {
+      if (bi + 1 < nbatch) fetch(k0 + (bi + 1) * 32 * NB);
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const double2* xp = reinterpret_cast<const double2*>(x + (size_t)myc[u] * 16 + h * 8);
+        const double2 a = xp[0], b = xp[1], c2 = xp[2], d = xp[3];
+        acc[0] = fma(myv[u], a.x, acc[0]);
+        acc[1] = fma(myv[u], a.y, acc[1]);
+        acc[2] = fma(myv[u], b.x, acc[2]);
+        acc[3] = fma(myv[u], b.y, acc[3]);
+        acc[4] = fma(myv[u], c2.x, acc[4]);
+        acc[5] = fma(myv[u], c2.y, acc[5]);
+        acc[6] = fma(myv[u], d.x, acc[6]);
+        acc[7] = fma(myv[u], d.y, acc[7]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    double v = acc[t];
+    v += rw_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += rw_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += rw_dpp<0x141>(v);    // row_half_mirror
+    v += rw_dpp<0x140>(v);    // row_mirror: all 16 lanes of the DPP row hold the row's sum
+    v += __shfl_xor(v, 16, 64);
+    acc[t] = v;
+  }
+  if (e == 0) {
+    double2* o = reinterpret_cast<double2*>(y + (size_t)row * 16 + h * 8);
+    o[0] = make_double2(acc[0], acc[1]);
+    o[1] = make_double2(acc[2], acc[3]);
+    o[2] = make_double2(acc[4], acc[5]);
+    o[3] = make_double2(acc[6], acc[7]);
+  }
+}
+bool spmm_rowwave_pays(int nrows, size_t nnz) { return nrows > 0 && nnz >= (size_t)32 * nrows; }
+void launch_spmm_rowwave(hipStream_t st, const GroupTab& gt, int nrows, const int* rp, const int* ci,
+                         const GroupPtrs& vals, const double* x, const _Float16* x16, size_t gsx, double* y, size_t gsy,
+                         int m) {
+  if (nrows <= 0 || m != 16 || gt.ng <= 0) return;
+  dim3 grid((nrows + 3) / 4, 1, gt.ng), block(256);
+  if (x16)
+    hipLaunchKernelGGL((spmm_rowwave_kernel<_Float16>), grid, block, 0, st, gt, nrows, rp, ci, vals, x16, gsx, y, gsy);
+  else
+    hipLaunchKernelGGL((spmm_rowwave_kernel<double>), grid, block, 0, st, gt, nrows, rp, ci, vals, x, gsx, y, gsy);
+}
+
+// ---------------------------------------------------------------------------
 // K1, LDS-tiled variant for the saddle operator.
 //
 // Rows are processed in blocks of <= 64 rows that form a compact patch of the

@@ -206,8 +206,11 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
     const int* rci = c->sa ? c->pt_ci.p : c->agg_rows.p;
     const GroupPtrs rvals = c->sa ? same_ptr((const double*)c->pt_v.p) : ones;
     if (c->sa && !folded) throw HipError{"smoothed aggregation needs the folded preconditioner cycle"};
+    const size_t rnnz = c->sa ? c->pt_ci.n : (size_t)c->n;
     if (!on(0)) {
-    } else if (r16)
+    } else if (m == 16 && c->rowwave && spmm_rowwave_pays(c->kc, rnnz))
+      launch_spmm_rowwave(st, gt, c->kc, rrp, rci, rvals, r16 ? nullptr : r, r16, gsr, c->rc.p, bt.gsc, m);
+    else if (r16)
       launch_spmm_h(st, gt, c->kc, rrp, rci, rvals, nullptr, r16, m, gsr, c->rc.p, m, bt.gsc,
                     nullptr, 0, 0, 1.0, 0.0, m, 16);
     else
