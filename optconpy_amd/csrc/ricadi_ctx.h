@@ -188,6 +188,8 @@ struct ShiftData {
   // Ahat_b^-1 D_b (D_b: dense slice of S*Y) of the first velocity sweep with the coarse residual folded in
   DArr<double> adym;
   DArr<float> adymf;
+  // BF16 copies (bit patterns) of the four block operands above for the record-driven sweeps of the FP32 cycle
+  DArr<uint16_t> bvinvh, bpinvh, gtmh, adymh;
   // Sherman-Morrison-Woodbury data for the current low-rank term (ctx->lr_epoch):
   // smw_w = S^-1 [U;0] (I - V^T S^-1 U)^-1, n x q
   DArr<double> smw_w;
@@ -298,6 +300,7 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx_ms, syb_lidx_ms;
   bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
   int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
+  bool blocks16 = true;       // RICADI_BLOCKS16=0: the sweeps apply the FP32 copies of the per-shift blocks
   bool rowwave = true;        // RICADI_ROWWAVE=0: the restriction through the 16-lanes-per-row CSR kernel
   bool mid32 = true;          // RICADI_MID32=0: the velocity part between the sweeps of a cycle stays an FP64 panel
   int mid32_last = -1;        // what the last preconditioner application did (1 FP32 panel, 0 FP64; -1 none yet)

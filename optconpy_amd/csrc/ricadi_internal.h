@@ -111,6 +111,7 @@ struct GroupPtrsT {
 };
 typedef GroupPtrsT<double> GroupPtrs;
 typedef GroupPtrsT<float> GroupPtrsF;   // FP32-stored preconditioner operands
+typedef GroupPtrsT<uint16_t> GroupPtrsH;   // BF16-stored block operands of the sweeps (bit patterns; round 4)
 struct GroupInts {            // one small integer per group id (by value)
   int v[RICADI_MAX_GROUPS];
 };
@@ -398,6 +399,20 @@ void launch_gj_diag(hipStream_t st, int nb, double* D, int nbe, int* flag);
 void launch_gj_rows(hipStream_t st, int nb, double* const* mats, int k, int k0, int nbe, const double* Rb);
 void launch_combine3(hipStream_t st, size_t n, const double* a0, const double* a1,
                      const double* a2, double alpha, double beta, double* out);
+
+// dst (BF16 bit patterns, round to nearest even) = src (FP64), n entries
+void launch_to_bf16(hipStream_t st, size_t n, const double* src, uint16_t* dst);
+// The hot-shape sweeps (32-row blocks, 16 columns, fixed-stride records in pa.bmeta) on BF16-stored blocks: same
+// contracts as launch_block_apply2_b / launch_block_apply_rect_b / launch_pressure_step_b with the FP32 panel; return
+// false (nothing launched) when the shape is not the hot one.
+bool launch_block_two32_h(hipStream_t st, const GroupTab& gt, int nblocks, const GroupPtrsH& m1, const Seg2& s1,
+                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa);
+bool launch_block_rect32_h(hipStream_t st, const GroupTab& gt, int ks, int nblocks, const GroupPtrsH& mats,
+                           const double* in, size_t gsi, double* out, size_t gso, int subtract, const ProlongArgs& pa);
+void launch_pressure_step_h(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrsH& inv, const int* jci, const double* jv, bool with_sy, const int* syci,
+                            const GroupPtrs& syv, const double* ec, size_t gse, const double* rp_, const _Float16* rp16,
+                            size_t gsr, double* out, size_t gso, const ProlongArgs& pa, const float* zv32, size_t gsz32);
 
 // K2p: the pressure step of the SIMPLE cycle fused into one launch (m = 16, 32 x 32 Schur blocks):
 //   out[rows_b] = inv_b (J z + (S Y)_p ec - r_p)[rows_b]  with the epilogue options of the Schur sweep (pa).

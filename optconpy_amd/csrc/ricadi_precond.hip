@@ -59,6 +59,22 @@ struct Raw4<double> {
     a[0] = u.lo.x; a[1] = u.lo.y; a[2] = u.hi.x; a[3] = u.hi.y;
   }
 };
+// BF16 bit patterns (uint16_t): widening is a 16-bit shift into the FP32 encoding
+__device__ __forceinline__ double bf16_to_f64(unsigned bits16) { return (double)__uint_as_float(bits16 << 16); }
+template <>
+struct Raw4<uint16_t> {
+  typedef uint2 type;
+  static __device__ __forceinline__ uint2 load(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void unpack(const uint2& u, double (&a)[4]) {
+    a[0] = bf16_to_f64(u.x & 0xffffu);
+    a[1] = bf16_to_f64(u.x >> 16);
+    a[2] = bf16_to_f64(u.y & 0xffffu);
+    a[3] = bf16_to_f64(u.y >> 16);
+  }
+};
+__device__ __forceinline__ void load4(const uint16_t* p, double (&a)[4]) {
+  Raw4<uint16_t>::unpack(Raw4<uint16_t>::load(p), a);
+}
 template <int BS, class T>
 __global__ __launch_bounds__(256) void block_apply_kernel(
     GroupTab gt, int nblocks, const int* __restrict__ bptr, const int* __restrict__ rows,
@@ -1569,6 +1585,59 @@ void launch_pressure_step_b(hipStream_t st, const GroupTab& gt, int nblocks, con
                             const ProlongArgs& pa, const float* zv32, size_t gsz32) {
   pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, z, gsz, with_sy, syci, syv, ec, gse, rp_, rp16, gsr, out, gso,
                      pa, zv32, gsz32);
+}
+
+// ---- BF16 copies of the per-shift blocks (round 4): the two velocity sweeps are bandwidth bound on exactly these
+// operands since they take their indices from one record (0.7 of the HBM roofline), and a block-Jacobi smoother does
+// not feel an 8-bit mantissa (scipy mirror, N = 30 / 58, NSE and DRE operators: iteration counts unchanged to the
+// last digit with BF16- or FP16-rounded blocks).  BF16 rather than FP16: FP32's exponent range, no per-block scale.
+__global__ void to_bf16_kernel(size_t n, const double* __restrict__ src, uint16_t* __restrict__ dst) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned u = __float_as_uint((float)src[i]);
+    dst[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  }
+}
+void launch_to_bf16(hipStream_t st, size_t n, const double* src, uint16_t* dst) {
+  if (!n) return;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, st, n, src, dst);
+}
+bool launch_block_two32_h(hipStream_t st, const GroupTab& gt, int nblocks, const GroupPtrsH& m1, const Seg2& s1,
+                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa) {
+  if (nblocks <= 0 || gt.ng <= 0) return true;
+  if (!(pa.bmeta && !pa.aggof && (s2.kstride == 32 || s2.kstride == 64) &&
+        std::max(std::max(gso, s1.gs), s2.gs) * 8 < ((size_t)1 << 32)))
+    return false;
+  dim3 grid((nblocks + 3) / 4, 1, gt.ng), block(256);
+#define RICADI_TWO32(K, H)                                                                                         \
+  hipLaunchKernelGGL((block_two32_kernel<K, uint16_t, H>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
+                     pa.bm_in, m1, s1, m2, s2, out, gso, pa)
+  if (s2.kstride == 32) { if (s1.in16) RICADI_TWO32(32, true); else RICADI_TWO32(32, false); }
+  else { if (s1.in16) RICADI_TWO32(64, true); else RICADI_TWO32(64, false); }
+#undef RICADI_TWO32
+  return true;
+}
+bool launch_block_rect32_h(hipStream_t st, const GroupTab& gt, int ks, int nblocks, const GroupPtrsH& mats,
+                           const double* in, size_t gsi, double* out, size_t gso, int subtract, const ProlongArgs& pa) {
+  if (nblocks <= 0 || gt.ng <= 0) return true;
+  if (!(pa.bmeta && (ks == 32 || ks == 64) && std::max(gsi, gso) * 8 < ((size_t)1 << 32) && !(pa.old32 && !pa.out32)))
+    return false;
+  const int nwaves = nblocks + (pa.aggof ? (pa.nextra + 31) / 32 : 0);
+  dim3 grid((nwaves + 3) / 4, 1, gt.ng), block(256);
+#define RICADI_RECT32(K, O)                                                                                         \
+  hipLaunchKernelGGL((block_rect32_kernel<K, uint16_t, O>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
+                     pa.bm_in, mats, in, gsi, out, gso, subtract, pa)
+  if (ks == 32) { if (pa.old32) RICADI_RECT32(32, true); else RICADI_RECT32(32, false); }
+  else { if (pa.old32) RICADI_RECT32(64, true); else RICADI_RECT32(64, false); }
+#undef RICADI_RECT32
+  return true;
+}
+void launch_pressure_step_h(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,
+                            const GroupPtrsH& inv, const int* jci, const double* jv, bool with_sy, const int* syci,
+                            const GroupPtrs& syv, const double* ec, size_t gse, const double* rp_, const _Float16* rp16,
+                            size_t gsr, double* out, size_t gso, const ProlongArgs& pa, const float* zv32, size_t gsz32) {
+  pressure_step_impl(st, gt, nblocks, meta, inv, jci, jv, (const double*)nullptr, 0, with_sy, syci, syv, ec, gse, rp_,
+                     rp16, gsr, out, gso, pa, zv32, gsz32);
 }
 
 }  // namespace ricadi

@@ -464,6 +464,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   }
   if (const char* e = getenv("RICADI_MID32")) c->mid32 = e[0] != '0';
   if (const char* e = getenv("RICADI_ROWWAVE")) c->rowwave = e[0] != '0';
+  if (const char* e = getenv("RICADI_BLOCKS16")) c->blocks16 = e[0] != '0';
   // multi-shift kernel operands: vAJ = A part + J part (disjoint supports) and vE in tile
   // order; velocity-velocity flag in bit 15 of the local index
   auto ms_arrays = [&](const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& a,

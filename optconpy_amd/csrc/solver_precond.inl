@@ -14,6 +14,8 @@ struct Batch {
   GroupPtrsF bvinvf, bpinvf, einvf;
   GroupPtrs gtm, adym;
   GroupPtrsF gtmf, adymf;
+  GroupPtrsH bvinvh, bpinvh, gtmh, adymh;     // BF16 copies (null where a shift has none)
+  bool blocks16 = false;                       // every group of the batch has them
   size_t gs = 0, gsp = 0, gsc = 0, gsq = 0;   // strides: n*m, np*m, kc*m, q*m
   std::shared_ptr<Batch> sub;                 // the same groups on the child level
 
@@ -40,6 +42,8 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
   bt.bvinvf = bt.bpinvf = bt.einvf = same_ptr((const float*)nullptr);
   bt.gtm = bt.adym = same_ptr((const double*)nullptr);
   bt.gtmf = bt.adymf = same_ptr((const float*)nullptr);
+  bt.bvinvh = bt.bpinvh = bt.gtmh = bt.adymh = same_ptr((const uint16_t*)nullptr);
+  bt.blocks16 = c->blocks16 && G > 0;
   for (int g = 0; g < RICADI_MAX_GROUPS; ++g) bt.alpha[g] = bt.beta[g] = 0.0;
   for (int g = 0; g < G; ++g) {
     bt.alpha[g] = sds[g]->alpha;
@@ -47,6 +51,11 @@ static Batch make_batch(ricadi_ctx* c, ShiftData* const* sds, int G, int m) {
     bt.bvinvf.p[g] = sds[g]->bvinvf.p;
     bt.bpinvf.p[g] = sds[g]->bpinvf.p;
     bt.einvf.p[g] = sds[g]->einvf.p;
+    bt.bvinvh.p[g] = sds[g]->bvinvh.p;
+    bt.bpinvh.p[g] = sds[g]->bpinvh.p;
+    bt.gtmh.p[g] = sds[g]->gtmh.p;
+    bt.adymh.p[g] = sds[g]->adymh.p;
+    if (!sds[g]->bvinvh.p || !sds[g]->bpinvh.p || !sds[g]->gtmh.p || !sds[g]->adymh.p) bt.blocks16 = false;
     bt.gtm.p[g] = sds[g]->gtm.p;
     bt.gtmf.p[g] = sds[g]->gtmf.p;
     bt.adym.p[g] = sds[g]->adym.p;
@@ -197,6 +206,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
   // inverses and the FP32-stored Z_j already do.
   const bool mid32 = c->mid32 && z32 && only32 && fusedp && precond_folds(c) && c->gt_ok && c->precond32;
   c->mid32_last = mid32 ? 1 : 0;
+  // ... and on BF16-stored blocks where every shift of the batch has them (record-driven sweeps only)
+  const bool b16 = mid32 && bt.blocks16 && c->sw_stride > 0 && c->bs == 32;
   if (c->kc > 0) {
     // restriction Y^T r = CSR product with unit values (aggregate lists as rows)
     folded = precond_folds(c);
@@ -307,7 +318,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       fpa.bm_in = c->sw_in_two;
       fpa.bm_ni = 2;
     }
-    if (c->precond32)
+    if (b16 && launch_block_two32_h(st, gt, c->nbv, bt.bvinvh, s1, bt.adymh, s2, z, bt.gs, fpa)) {
+    } else if (c->precond32)
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, s1, bt.adymf, s2, z, m,
                             bt.gs, m, fpa);
     else
@@ -348,7 +360,10 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       const double* rp64 = sy ? (r16 ? nullptr : r + (size_t)nv * m) : rr + (size_t)nv * m;
       const _Float16* rp16 = sy && r16 ? r16 + (size_t)nv * m : nullptr;
       const size_t gsrp = sy ? gsr : gsrr;
-      if (c->precond32)
+      if (b16)
+        launch_pressure_step_h(st, gt, c->nbp, c->ps_meta.p, bt.bpinvh, c->J.ci.p, c->J.v.p, sy, c->sy_ci.p, bt.syval,
+                               c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro, z32, gs32);
+      else if (c->precond32)
         launch_pressure_step_b(st, gt, c->nbp, c->ps_meta.p, bt.bpinvf, c->J.ci.p, c->J.v.p, z, bt.gs, sy, c->sy_ci.p,
                                bt.syval, c->ec.p, bt.gsc, rp64, rp16, gsrp, zp, bt.gs, ppro, mid32 ? z32 : nullptr,
                                gs32);
@@ -379,7 +394,8 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
         pro.bm_ni = 1;
       }
       mirrored = true;
-      if (c->precond32)
+      if (b16 && launch_block_rect32_h(st, gt, c->gt_ks, c->nbv, bt.gtmh, c->tp.p, bt.gsp, z, bt.gs, 1, pro)) {
+      } else if (c->precond32)
         launch_block_apply_rect_b(st, gt, c->bs, c->gt_ks, c->nbv, c->bv_ptr.p, c->bv_rows.p, c->gt_ptr.p,
                                   c->gt_cols.p, bt.gtmf, c->tp.p, m, bt.gsp, z, m, bt.gs, m, 1, pro);
       else

@@ -322,6 +322,17 @@ static void get_shifts(ricadi_ctx* c, const double* alphas, const double* betas,
         if (sd->einvf.n != kp * kp * 256) sd->einvf.alloc(kp * kp * 256);
         launch_to_f32_tiled(st, k, sd->einv.p, sd->einvf.p);
       }
+      if (c->blocks16 && c->sw_stride > 0 && c->gt_ok && c->ady_ok && k > 0 && c->nbp > 0) {
+        // BF16 copies for the record-driven sweeps (all four or none: the cycle switches as a whole)
+        if (sd->bvinvh.n != sd->bvinv.n) sd->bvinvh.alloc(sd->bvinv.n);
+        if (sd->bpinvh.n != sd->bpinv.n) sd->bpinvh.alloc(sd->bpinv.n);
+        if (sd->gtmh.n != sd->gtm.n) sd->gtmh.alloc(sd->gtm.n);
+        if (sd->adymh.n != sd->adym.n) sd->adymh.alloc(sd->adym.n);
+        launch_to_bf16(st, sd->bvinv.n, sd->bvinv.p, sd->bvinvh.p);
+        launch_to_bf16(st, sd->bpinv.n, sd->bpinv.p, sd->bpinvh.p);
+        launch_to_bf16(st, sd->gtm.n, sd->gtm.p, sd->gtmh.p);
+        launch_to_bf16(st, sd->adym.n, sd->adym.p, sd->adymh.p);
+      }
     }
     HIPCHK(hipStreamSynchronize(st));
   }
