@@ -216,7 +216,7 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     ctx.time_kernel_dev("precond", al, be, m, nvec=nvec, reps=1)
     mid = ctx.setup_info().get("fp32_intermediate", 0) == 1
     zb = 4.0 if mid else 8.0
-    hot = m == 16 and info["bs"] == 32 and os.environ.get("RICADI_SWEEP_META") is None   # record-driven sweep kernels
+    hot = m == 16 and info["bs"] == 32 and os.environ.get("RICADI_SWEEP_META", "1") != "0"   # record-driven sweep kernels
     w64 = 0.0 if (mid or ctx.setup_info().get("k1_variant", 0) >= 4) else 8.0    # FP64 z stored by the last sweep?
     stages = {
         "pc_restrict": (("ricadi::spmm_rowwave_kernel" if m == 16 and info.get("nnz_restriction", n) >= 32 * max(kc0, 1)
@@ -951,8 +951,12 @@ def main():
                 "K_rel_diff_vs_oracle": k_orc,
                 "K_rel_diff_vs_converged": k_conv,
                 "storage": "arithmetic and all residual checks FP64; Krylov basis stored in %s, "
-                           "preconditioner inverses in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage)"
-                           % (basis, prec),
+                           "preconditioner: coarse inverse in %s, block operands of the sweeps in %s, the velocity part "
+                           "between its sweeps in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage)"
+                           % (basis, prec,
+                              "BF16" if prec == "FP32" and os.environ.get("RICADI_BLOCKS16", "1") != "0"
+                              and os.environ.get("RICADI_MID32", "1") != "0" else prec,
+                              "FP32" if prec == "FP32" and os.environ.get("RICADI_MID32", "1") != "0" else "FP64"),
             },
         }
         if k_orc is not None and k_orc > 1e-6:

@@ -405,7 +405,8 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
           for (int i = 0; i < k2; ++i) mt[68 + kr + i] = ni > 0 ? ccols[i0 + std::min(i, ni - 1)] : 0;
         }
       }
-      if (ok && getenv("RICADI_SWEEP_META") == nullptr) {
+      const char* swe = getenv("RICADI_SWEEP_META");        // =0: the generic sweep kernels
+      if (ok && !(swe && swe[0] == '0')) {
         c->sw_meta.upload(meta, st);
         c->sw_stride = stride;
         c->sw_in_rect = 68;

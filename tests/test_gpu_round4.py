@@ -313,13 +313,15 @@ def test_storage_escalation_on_the_dre_operator_at_1e5():
         backend.configure()
 
 
-# ------------------------------------------------------------------ FP32 intermediate of the preconditioner cycle
-def test_fp32_intermediate_of_the_cycle_against_sparse_lu(cfg1, monkeypatch):
-    """The velocity part between the three sweeps of a preconditioner cycle is an FP32 panel by default (first sweep ->
-    64-B row gathers of the pressure step -> last sweep in place; RICADI_MID32=0: the FP64 panel of rounds 1-3).  It
-    only changes the (flexible) preconditioner: both storages solve three shifts of a 16-column panel to the tolerance,
-    agree with the sparse LU (SuperLU, tests/test_units_compfacres_compress.py:70) and need the same number of
-    iterations within a few."""
+# ------------------------------------------------------------------ storage and kernel forms of the preconditioner cycle
+def test_cycle_forms_of_round4_against_sparse_lu(cfg1, monkeypatch):
+    """Round 4 changed how the cycle's sweeps run, not what they compute: the velocity part between the sweeps is an
+    FP32 panel (RICADI_MID32=0: FP64), the per-shift blocks are BF16-stored (RICADI_BLOCKS16=0: FP32), the sweeps
+    take their indices from one fixed-stride record per block (RICADI_SWEEP_META=0: the generic kernels), the
+    restriction of long aggregate rows runs one wave per row (RICADI_ROWWAVE=0: 16 lanes per row).  Every form solves
+    three shifts of a 16-column panel to the tolerance, agrees with the sparse LU (SuperLU,
+    tests/test_units_compfacres_compress.py:70) and needs the default's number of iterations within a few; the
+    library reports which intermediate it used."""
     import torch
     pr = cfg1[0]
     calA = (-pr.A - pr.Nc).T.tocsr()
@@ -329,8 +331,11 @@ def test_fp32_intermediate_of_the_cycle_against_sparse_lu(cfg1, monkeypatch):
     ps = [-1.0, -40.0, -1500.0]
     refs = [olau.SaddleLU(calA + p * MT, pr.J).solve(R) for p in ps]
     iters = {}
-    for mid in ("1", "0"):
-        monkeypatch.setenv("RICADI_MID32", mid)
+    forms = [("default", None), ("RICADI_MID32", "0"), ("RICADI_BLOCKS16", "0"), ("RICADI_SWEEP_META", "0"),
+             ("RICADI_ROWWAVE", "0")]
+    for name, val in forms:
+        if val is not None:
+            monkeypatch.setenv(name, val)
         with _lib.Context(0) as ctx:
             ctx.set_operator(calA, MT, pr.J)
             Rd = torch.from_numpy(R).cuda()
@@ -338,8 +343,13 @@ def test_fp32_intermediate_of_the_cycle_against_sparse_lu(cfg1, monkeypatch):
             its, rr = ctx.shift_solve_batch_dev(ps, [1.0] * len(ps), Rd.data_ptr(), 0, 16, Xd.data_ptr())
             ctx.synchronize()
             X = Xd.cpu().numpy()
-        assert np.asarray(rr).max() <= 1e-10, mid
+            mid = ctx.setup_info()["fp32_intermediate"]
+        if val is not None:
+            monkeypatch.delenv(name)
+        assert mid == (0 if name == "RICADI_MID32" else 1), (name, mid)
+        assert np.asarray(rr).max() <= 1e-10, name
         for g in range(len(ps)):
-            assert rel(X[g][:pr.NV], refs[g][:pr.NV]) < 1e-8, (mid, g)
-        iters[mid] = np.asarray(its, dtype=float)
-    assert np.abs(iters["1"] - iters["0"]).max() <= 3, iters
+            assert rel(X[g][:pr.NV], refs[g][:pr.NV]) < 1e-8, (name, g)
+        iters[name] = np.asarray(its, dtype=float)
+    for name, _ in forms[1:]:
+        assert np.abs(iters[name] - iters["default"]).max() <= 3, iters
