@@ -217,6 +217,9 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     mid = ctx.setup_info().get("fp32_intermediate", 0) == 1
     zb = 4.0 if mid else 8.0
     hot = m == 16 and info["bs"] == 32 and os.environ.get("RICADI_SWEEP_META", "1") != "0"   # record-driven sweep kernels
+    # ... which read BF16-stored blocks (2 B per entry) in the FP32 cycle
+    pbb = 2.0 if (hot and mid and pb_ == 4 and os.environ.get("RICADI_BLOCKS16", "1") != "0") else pb_
+    bl = "unsigned short (BF16)" if pbb == 2.0 else fl
     w64 = 0.0 if (mid or ctx.setup_info().get("k1_variant", 0) >= 4) else 8.0    # FP64 z stored by the last sweep?
     stages = {
         "pc_restrict": (("ricadi::spmm_rowwave_kernel" if m == 16 and info.get("nnz_restriction", n) >= 32 * max(kc0, 1)
@@ -230,16 +233,16 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
                       models["coarse"][1] if info["levels"] <= 2 else None),
         "pc_sy_prows": ("ricadi::spmm_kernel_v2 (pressure rows of S*Y)", None),
         "pc_two_term": (("ricadi::block_two32_kernel<%d,%s,%s>" if hot else "ricadi::block_apply2_kernel<32,%d,%s,%s>")
-                        % (tk, fl, "true" if h16 else "false") if tk else "ricadi::block_apply_kernel<32,%s>" % fl,
-                        G * (pb_ * nb * 32.0 * (32 + tk) + (vin + zb) * nv * m + 8.0 * kc0 * m)),
+                        % (tk, bl if hot else fl, "true" if h16 else "false") if tk else "ricadi::block_apply_kernel<32,%s>" % fl,
+                        G * (pbb * nb * 32.0 * (32 + tk) + (vin + zb) * nv * m + 8.0 * kc0 * m)),
         "pc_jprod": ("ricadi::spmm_kernel_v2 (J)", 12.0 * info.get("nnz_j", 0) + G * (8.0 * nv * m + 16.0 * npn * m)),
         "pc_schur": (("ricadi::block_apply_rect_kernel<32,32,%s> (block's own rows as input list)" % fl)
                      if info["nbp"] * G <= 8192 else "ricadi::block_apply_kernel<32,%s>" % fl,
                      G * (pb_ * info["nbp"] * 1024.0 + (8.0 + 8.0 + 8.0 + 4.0) * npn * m)),
-        "pc_rect": (("ricadi::block_rect32_kernel<%d,%s,%s>" % (rk, fl, "true" if mid else "false") if hot else
+        "pc_rect": (("ricadi::block_rect32_kernel<%d,%s,%s>" % (rk, bl, "true" if mid else "false") if hot else
                      "ricadi::block_apply_rect_kernel<32,%d,%s>" % (rk, fl)) if rk
                     else "ricadi::block_apply_kernel<32,%s> (+ CSR J^T input)" % fl,
-                    G * (pb_ * nb * 32.0 * max(rk, 32) + (zb + w64) * nv * m + 4.0 * n * m + 8.0 * npn * m
+                    G * (pbb * nb * 32.0 * max(rk, 32) + (zb + w64) * nv * m + 4.0 * n * m + 8.0 * npn * m
                          + 8.0 * kc0 * m)),
     }
     if m == 16 and info["bs"] == 32 and npn > 0:
@@ -248,9 +251,9 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
         # copy for the J^T product and the FP32 copy)
         stages["pc_sy_prows"] = ("(fused into pc_schur: ricadi::pressure_step_kernel)", None)
         stages["pc_jprod"] = ("(fused into pc_schur: ricadi::pressure_step_kernel)", None)
-        stages["pc_schur"] = ("ricadi::pressure_step_kernel<%s,%s,%s>" % (fl, "_Float16" if h16 else "double",
+        stages["pc_schur"] = ("ricadi::pressure_step_kernel<%s,%s,%s>" % (bl, "_Float16" if h16 else "double",
                                                                            "float" if mid else "double"),
-                              12.0 * info.get("nnz_j", 0) + G * (pb_ * info["nbp"] * 1024.0 + zb * nv * m +
+                              12.0 * info.get("nnz_j", 0) + G * (pbb * info["nbp"] * 1024.0 + zb * nv * m +
                                                                    (vin + 20.0) * npn * m + 8.0 * kc0 * m))
     tot = 0.0
     for key, (kname, nbytes) in stages.items():

@@ -300,6 +300,7 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx_ms, syb_lidx_ms;
   bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
   int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
+  bool x32_always = true;     // RICADI_X32=0: the operator reads the FP32 Z_j only where the multi-shift SpMM runs
   bool blocks16 = true;       // RICADI_BLOCKS16=0: the sweeps apply the FP32 copies of the per-shift blocks
   bool rowwave = true;        // RICADI_ROWWAVE=0: the restriction through the 16-lanes-per-row CSR kernel
   bool mid32 = true;          // RICADI_MID32=0: the velocity part between the sweeps of a cycle stays an FP64 panel

@@ -466,6 +466,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   if (const char* e = getenv("RICADI_MID32")) c->mid32 = e[0] != '0';
   if (const char* e = getenv("RICADI_ROWWAVE")) c->rowwave = e[0] != '0';
   if (const char* e = getenv("RICADI_BLOCKS16")) c->blocks16 = e[0] != '0';
+  if (const char* e = getenv("RICADI_X32")) c->x32_always = e[0] != '0';
   // multi-shift kernel operands: vAJ = A part + J part (disjoint supports) and vE in tile
   // order; velocity-velocity flag in bit 15 of the local index
   auto ms_arrays = [&](const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& a,
@@ -943,7 +944,7 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* c, int ng, const double* alphas, cons
   // the saddle SpMM exactly as the batched GMRES launches it (no low-rank term; on the FP32-stored vector
   // when the iteration does so)
   DArr<float> x32;
-  if (operator_reads_x32(c, m) && ms_pays(c, ng, c->snnz)) {
+  if (iteration_reads_x32(c, m, ng)) {
     x32.alloc(bt.gs * ng);
     for (int g = 0; g < ng; ++g)
       launch_to_f32(c->st, c->n, m, dX + (size_t)g * bt.gs, m, x32.p + (size_t)g * bt.gs, m);
@@ -1018,7 +1019,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
     switch (which) {
       case 0:
         saddle_spmm(c, bt, c->zv.p, nm, nullptr, c->wv.p, nm, nullptr, 0, 1.0, 0.0, LowRankArgs(),
-                    operator_reads_x32(c, m) && ms_pays(c, ng, c->snnz) && c->zbasisf.p ? c->zbasisf.p : nullptr);
+                    iteration_reads_x32(c, m, ng) && c->zbasisf.p ? c->zbasisf.p : nullptr);
         break;
       case 1:
         if (c->precond32)
@@ -1090,9 +1091,9 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         break;
       case 8:
         if (b16 && precond_reads_h16(c, m))
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m), Vh);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, iteration_reads_x32(c, m, ng), Vh);
         else
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m));
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, iteration_reads_x32(c, m, ng));
         break;
       case 9:
         if (c->kc <= 0) throw HipError{"no coarse level"};
@@ -1104,9 +1105,9 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
         Restore<int> keep(c->pc_stage);
         c->pc_stage = which - 10;
         if (b16 && precond_reads_h16(c, m))
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m), Vh);
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, iteration_reads_x32(c, m, ng), Vh);
         else
-          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, operator_reads_x32(c, m));
+          precond_apply(c, bt, c->wv.p, nm, c->zv.p, c->zbasisf.p, nm, iteration_reads_x32(c, m, ng));
         break;
       }
       default:

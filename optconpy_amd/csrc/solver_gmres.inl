@@ -54,7 +54,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
     ~NoStoreScope() { set_update_dots_nostore(false); }
   } nostore_scope(keepw);
   const size_t h2buf = (size_t)(restart + 2) * c->wcols;        // doubles between the two second-pass buffers
-  const bool x32 = operator_reads_x32(c, m) && ms_pays(c, G, c->snnz) && !(lowrank && c->q > 0);
+  const bool x32 = iteration_reads_x32(c, m, G) && !(lowrank && c->q > 0);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;

@@ -141,9 +141,15 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
                   m, gsr, alpha, beta_r, m, lr);
 }
 
-// Does the GMRES iteration apply the operator to the FP32-stored Z_j (RICADI_X32=0: to the FP64 z)?
+// Does the GMRES iteration apply the operator to the FP32-stored Z_j?
 static bool operator_reads_x32(const ricadi_ctx* c, int m) {
   return c->flex && saddle_tiled(c, m);
+}
+// ... for a batch of ng groups: always with the multi-shift kernel; with one workgroup per (row block, group) the FP32
+// input by itself measured 1.4 % slower at cfg2 in round 3, but it is what lets the cycle keep its velocity part in
+// FP32 and its blocks in BF16 (round 4), which more than pays for it (RICADI_X32=0: only with the multi-shift kernel)
+static bool iteration_reads_x32(const ricadi_ctx* c, int m, int ng) {
+  return operator_reads_x32(c, m) && (c->x32_always || ms_pays(c, ng, c->snnz));
 }
 
 // y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
