@@ -199,10 +199,13 @@ __device__ __forceinline__ void chunk_dots16(const _Float16* __restrict__ basis,
 }
 
 // ATOMIC: `partial` is the result array itself (group stride gsp), zeroed beforehand
-template <bool ATOMIC = false>
+// WT: storage type of the panel w (round 4: the operator's output of the hot path is an FP32 panel -- the basis it is
+// orthogonalised against is FP16-stored, so its rounding of 6e-8 is far inside what the iteration already carries;
+// the arithmetic stays FP64)
+template <bool ATOMIC = false, class WT = double>
 __global__ __launch_bounds__(256) void cols_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
-    const double* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
+    const WT* __restrict__ w, size_t gsw, int want_self, double* __restrict__ partial, size_t gsp) {
   __shared__ __attribute__((aligned(16))) double wl[DOT_ROWS * WLS];
   const int grp = gt.gid[blockIdx.z];
   basis += (size_t)grp * gsb;
@@ -210,7 +213,21 @@ __global__ __launch_bounds__(256) void cols_dots16_kernel(
   partial += (size_t)grp * gsp;
   const int r0 = blockIdx.x * DOT_ROWS;
   const int nr = min(DOT_ROWS, nrows - r0);
-  {
+  if constexpr (sizeof(WT) == 4) {
+    const float2* src = reinterpret_cast<const float2*>(w + (size_t)r0 * 16);
+    float2 raw[DOT_ROWS * 8 / 256];
+#pragma unroll
+    for (int k = 0; k < DOT_ROWS * 8 / 256; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      raw[k] = src[e < nr * 8 ? e : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < DOT_ROWS * 8 / 256; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      *reinterpret_cast<double2*>(wl + (e >> 3) * WLS + (e & 7) * 2) =
+          e < nr * 8 ? make_double2((double)raw[k].x, (double)raw[k].y) : make_double2(0.0, 0.0);
+    }
+  } else {
     const double2* src = reinterpret_cast<const double2*>(w + (size_t)r0 * 16);
     for (int e = threadIdx.x; e < DOT_ROWS * 8; e += 256)
       *reinterpret_cast<double2*>(wl + (e >> 3) * WLS + (e & 7) * 2) = e < nr * 8 ? src[e] : make_double2(0.0, 0.0);
@@ -224,10 +241,10 @@ __global__ __launch_bounds__(256) void cols_dots16_kernel(
 // is cache resident by then, so the LDS side decides: with unpadded rows this phase was 2x slower)
 // STORE = false: w' is only staged in LDS for the dots, the panel w keeps the vector BEFORE the first projection (the
 // final update then subtracts the basis with the SUM of both passes' coefficients: one 8-byte store per element less)
-template <bool ATOMIC = false, bool STORE = true>
+template <bool ATOMIC = false, bool STORE = true, class WT = double>
 __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
     GroupTab gt, int nrows, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
-    const double* __restrict__ h, size_t gsh, double* __restrict__ w, size_t gsw,
+    const double* __restrict__ h, size_t gsh, WT* __restrict__ w, size_t gsw,
     double* __restrict__ partial, size_t gsp) {
   extern __shared__ __attribute__((aligned(16))) double sm16[];
   double* wl = sm16;                       // DOT_ROWS rows, stride WLS
@@ -281,13 +298,13 @@ __global__ __launch_bounds__(256) void cols_update_dots16_kernel(
 #pragma unroll
       for (int k = 0; k < NE; ++k) sacc[k] = fma(h0, (double)b0[k], sacc[k]);
     }
-    double wv[NE];
+    WT wv[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) wv[k] = w[base + (ok[k] ? e[k] : 0)];
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
-      const double v = ok[k] ? wv[k] - sacc[k] : 0.0;
-      if (STORE && ok[k]) w[base + e[k]] = v;
+      const double v = ok[k] ? (double)wv[k] - sacc[k] : 0.0;
+      if (STORE && ok[k]) w[base + e[k]] = (WT)v;
       wl[(e[k] >> 4) * WLS + c] = v;
     }
   }
@@ -586,7 +603,7 @@ static void cols_dots_impl(hipStream_t st, const GroupTab& gt, int nrows, int m,
       return;
     }
     if (m == 16 && arnoldi16(1)) {
-      hipLaunchKernelGGL(cols_dots16_kernel<false>, dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
+      hipLaunchKernelGGL((cols_dots16_kernel<false, double>), dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
                          vstride, gsb, w, gsw, want_self, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
                          nblk, nout, partial, gsp, out, gso, 0);
@@ -724,11 +741,11 @@ static void cols_update_dots_impl(hipStream_t st, const GroupTab& gt, int nrows,
     }
     if (m == 16 && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double) <= 48 * 1024) {
       if (g_update_dots_nostore)
-        hipLaunchKernelGGL((cols_update_dots16_kernel<false, false>), dim3(nblk, 1, gt.ng), dim3(256),
+        hipLaunchKernelGGL((cols_update_dots16_kernel<false, false, double>), dim3(nblk, 1, gt.ng), dim3(256),
                            (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
                            gsb, h, gsh, w, gsw, partial, gsp);
       else
-        hipLaunchKernelGGL((cols_update_dots16_kernel<false, true>), dim3(nblk, 1, gt.ng), dim3(256),
+        hipLaunchKernelGGL((cols_update_dots16_kernel<false, true, double>), dim3(nblk, 1, gt.ng), dim3(256),
                            (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride,
                            gsb, h, gsh, w, gsw, partial, gsp);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt,
@@ -1111,10 +1128,11 @@ void launch_gmres_start_b(hipStream_t st, const GroupTab& gt, int m, int restart
 //   use_sum = 1: w is the vector BEFORE the first projection, coefficients h1 + h2 (cols_update_dots16<.., false>);
 //   use_sum = 0: w has been projected once, coefficients h2.
 // ---------------------------------------------------------------------------
+template <class WT = double>
 __global__ __launch_bounds__(256) void cols_update16_hess_kernel(
     GroupTab gt, size_t nhalf, int nvec, const _Float16* __restrict__ basis, size_t vstride, size_t gsb,
     const double* __restrict__ h1, const double* __restrict__ h2, size_t gsh, int use_sum,
-    const double* __restrict__ w, size_t gsw, double* __restrict__ out, size_t gso, _Float16* __restrict__ outf,
+    const WT* __restrict__ w, size_t gsw, double* __restrict__ out, size_t gso, _Float16* __restrict__ outf,
     size_t gsf, int j, int restart, double* __restrict__ H, double* __restrict__ cs, double* __restrict__ sn,
     double* __restrict__ g, const double* __restrict__ resid_in, double* __restrict__ resid_out,
     const double* __restrict__ bnorm, double tol, double* __restrict__ host_resid) {
@@ -1200,12 +1218,20 @@ __global__ __launch_bounds__(256) void cols_update16_hess_kernel(
 #pragma unroll
       for (int t = 0; t < 8; ++t) a[t] = fma(hl[i * m + c0 + t], (double)x[t], a[t]);
     }
-    const double2* wp = reinterpret_cast<const double2*>(w + e);
+    if constexpr (sizeof(WT) == 4) {
+      const float4* wp = reinterpret_cast<const float4*>(w + e);
+      const float4 w0 = wp[0], w1 = wp[1];
+      const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const double2 ww = wp[t];
-      a[2 * t] = (ww.x - a[2 * t]) * scl[c0 + 2 * t];
-      a[2 * t + 1] = (ww.y - a[2 * t + 1]) * scl[c0 + 2 * t + 1];
+      for (int t = 0; t < 8; ++t) a[t] = ((double)wf[t] - a[t]) * scl[c0 + t];
+    } else {
+      const double2* wp = reinterpret_cast<const double2*>(w + e);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double2 ww = wp[t];
+        a[2 * t] = (ww.x - a[2 * t]) * scl[c0 + 2 * t];
+        a[2 * t + 1] = (ww.y - a[2 * t + 1]) * scl[c0 + 2 * t + 1];
+      }
     }
     half8_t f;
 #pragma unroll
@@ -1229,13 +1255,48 @@ void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, 
                                  size_t vstride, size_t gsb, const double* h1, const double* h2, size_t gsh, int use_sum,
                                  const double* w, size_t gsw, double* out, size_t gso, _Float16* outf, size_t gsf, int j,
                                  int restart, double* H, double* cs, double* sn, double* g, const double* resid_in,
-                                 double* resid_out, const double* bnorm, double tol, double* host_resid) {
+                                 double* resid_out, const double* bnorm, double tol, double* host_resid,
+                                 const float* w32) {
   if (gt.ng <= 0) return;
   const size_t nhalf = (size_t)nrows * 2;
   const int grid = (int)std::min<size_t>((nhalf + 255) / 256, 8192);
-  hipLaunchKernelGGL(cols_update16_hess_kernel, dim3(grid, 1, gt.ng), dim3(256), (size_t)(nvec * 16 + 16) * sizeof(double),
-                     st, gt, nhalf, nvec, basis, vstride, gsb, h1, h2, gsh, use_sum, w, gsw, out, gso, outf, gsf, j, restart,
-                     H, cs, sn, g, resid_in, resid_out, bnorm, tol, host_resid);
+  if (w32)
+    hipLaunchKernelGGL(cols_update16_hess_kernel<float>, dim3(grid, 1, gt.ng), dim3(256),
+                       (size_t)(nvec * 16 + 16) * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb, h1, h2, gsh,
+                       use_sum, w32, gsw, out, gso, outf, gsf, j, restart, H, cs, sn, g, resid_in, resid_out, bnorm, tol,
+                       host_resid);
+  else
+    hipLaunchKernelGGL(cols_update16_hess_kernel<double>, dim3(grid, 1, gt.ng), dim3(256),
+                       (size_t)(nvec * 16 + 16) * sizeof(double), st, gt, nhalf, nvec, basis, vstride, gsb, h1, h2, gsh,
+                       use_sum, w, gsw, out, gso, outf, gsf, j, restart, H, cs, sn, g, resid_in, resid_out, bnorm, tol,
+                       host_resid);
+}
+
+// The first two Arnoldi passes on an FP32 panel w (16 columns, FP16-stored basis; the second pass in its
+// "w kept" form: nothing is written back): same partial / reduce structure as the FP64-panel launches.
+bool arnoldi16_w32_ok(int nvec_max) {
+  return arnoldi16(1) && arnoldi16(2) && (size_t)(DOT_ROWS * 18 + nvec_max * 16) * sizeof(double) <= 48 * 1024;
+}
+void launch_cols_dots16_w32(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                            size_t vstride, size_t gsb, const float* w32, size_t gsw, double* partial, size_t gsp,
+                            double* out, size_t gso) {
+  if (gt.ng <= 0 || nvec <= 0) return;
+  const int nblk = dots_num_blocks(nrows), nout = nvec * 16;
+  hipLaunchKernelGGL((cols_dots16_kernel<false, float>), dim3(nblk, 1, gt.ng), dim3(256), 0, st, gt, nrows, nvec, basis,
+                     vstride, gsb, w32, gsw, 0, partial, gsp);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt, nblk, nout, partial,
+                     gsp, out, gso, 0);
+}
+void launch_cols_update_dots16_w32(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                   size_t vstride, size_t gsb, const double* h, size_t gsh, float* w32, size_t gsw,
+                                   double* partial, size_t gsp, double* out, size_t gso) {
+  if (gt.ng <= 0) return;
+  const int nblk = dots_num_blocks(nrows), nout = (nvec + 1) * 16;
+  hipLaunchKernelGGL((cols_update_dots16_kernel<false, false, float>), dim3(nblk, 1, gt.ng), dim3(256),
+                     (size_t)(DOT_ROWS * 18 + nvec * 16) * sizeof(double), st, gt, nrows, nvec, basis, vstride, gsb, h,
+                     gsh, w32, gsw, partial, gsp);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((nout + 15) / 16, 1, gt.ng), dim3(256), 0, st, gt, nblk, nout, partial,
+                     gsp, out, gso, 0);
 }
 
 

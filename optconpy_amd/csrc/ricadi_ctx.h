@@ -300,6 +300,7 @@ struct ricadi_ctx {
   DArr<uint16_t> sb_lidx_ms, syb_lidx_ms;
   bool ms_spmm = true;        // RICADI_MS_SPMM=0: one assembled value array per shift instead
   int ms_force = 0;           // RICADI_MS_SPMM=2: multi-shift kernel for every launch it can serve
+  bool w32 = true;            // RICADI_W32=0: the operator's output inside the Arnoldi iteration stays an FP64 panel
   bool x32_always = true;     // RICADI_X32=0: the operator reads the FP32 Z_j only where the multi-shift SpMM runs
   bool blocks16 = true;       // RICADI_BLOCKS16=0: the sweeps apply the FP32 copies of the per-shift blocks
   bool rowwave = true;        // RICADI_ROWWAVE=0: the restriction through the 16-lanes-per-row CSR kernel
@@ -319,6 +320,7 @@ struct ricadi_ctx {
   int wcols = 0, wrestart = 0;   // total columns (width x groups) and restart length the workspace holds
   DArr<double> basis, vcur, wv, zv, r2, tp, rc, ec, xs, bvec, pw1, pw2;
   DArr<float> basisf, zbasisf;   // zbasisf: Z_j = P^-1 v_j of the flexible GMRES, FP32
+  DArr<float> wv32;              // w = S z_j of the hot path as an FP32 panel (round 4; the FP64 wv serves the restarts)
   bool flex = true;              // RICADI_FGMRES=0: plain right preconditioning (x += P^-1 (V y) per cycle)
   bool basis32 = true;
   bool basis16 = true;        // FP16-stored Krylov basis (default for n <= 2^21)

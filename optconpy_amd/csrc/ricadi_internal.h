@@ -225,11 +225,11 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows);
 void launch_spmm_blocked_x32(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2, const int* rp2,
                              const int* cols2, const uint16_t* lidx, const GroupPtrs& vals, const float* x, int ldx,
-                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols);
+                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols, float* y32 = nullptr);
 void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
                                 int nblk, const int* rows2, const int* rp2, const int* cols2, const uint16_t* lidx,
                                 const double* vAJ, const double* vE, const float* x, int ldx, size_t gsx, double* y,
-                                int ldy, size_t gsy, double alpha, int m, int max_cols);
+                                int ldy, size_t gsy, double alpha, int m, int max_cols, float* y32 = nullptr);
 void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
                             int nblk, const int* rows2, const int* rp2, const int* cols2,
                             const uint16_t* lidx, const double* vAJ, const double* vE,
@@ -437,7 +437,19 @@ void launch_cols_update16_hess_b(hipStream_t st, const GroupTab& gt, int nrows, 
                                  size_t vstride, size_t gsb, const double* h1, const double* h2, size_t gsh, int use_sum,
                                  const double* w, size_t gsw, double* out, size_t gso, _Float16* outf, size_t gsf, int j,
                                  int restart, double* H, double* cs, double* sn, double* g, const double* resid_in,
-                                 double* resid_out, const double* bnorm, double tol, double* host_resid);
+                                 double* resid_out, const double* bnorm, double tol, double* host_resid,
+                                 const float* w32 = nullptr);
+
+// First two Arnoldi passes of a 16-column panel against the FP16-stored basis with the panel w stored in FP32 (the
+// operator's output on the hot path, round 4); the second pass leaves w as it is ("w kept" form).  launch_cols_update16_
+// hess_b takes the same panel through its w32 argument.
+bool arnoldi16_w32_ok(int nvec_max);
+void launch_cols_dots16_w32(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                            size_t vstride, size_t gsb, const float* w32, size_t gsw, double* partial, size_t gsp,
+                            double* out, size_t gso);
+void launch_cols_update_dots16_w32(hipStream_t st, const GroupTab& gt, int nrows, int nvec, const _Float16* basis,
+                                   size_t vstride, size_t gsb, const double* h, size_t gsh, float* w32, size_t gsw,
+                                   double* partial, size_t gsp, double* out, size_t gso);
 
 // K5c: pivoted Cholesky of a (possibly augmented) symmetric matrix, 8 / 16 / 32 pivots per launch pair --
 // the eigensolver-free recompression (ricadi_kernels.hip).  State lives on the device so that the host can

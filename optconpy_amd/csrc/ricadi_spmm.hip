@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupPtrs vals,
     const XT* __restrict__ x, int ldx, size_t gsx,
     double* __restrict__ y, int ldy, size_t gsy, const double* __restrict__ r, int ldr,
-    size_t gsr, double alpha, double beta_r, int m, int max_cols, LowRankArgs lr) {
+    size_t gsr, double alpha, double beta_r, int m, int max_cols, LowRankArgs lr, float* __restrict__ y32) {
   extern __shared__ double xs[];                             // max_cols x m
   // Groups ride in grid.z (group-major dispatch: consecutive workgroups are
   // neighbouring row blocks of ONE panel, whose gathered x rows overlap -- walking
@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   const double* __restrict__ val = vals.p[grp];
   x += (size_t)grp * gsx;
   y += (size_t)grp * gsy;
+  if (y32) y32 += (size_t)grp * gsy;          // the product as an FP32 panel instead (same layout; Arnoldi reads it)
   if (HAS_R) r += (size_t)grp * gsr;
   const double* __restrict__ lrc = HAS_LR ? lr.c + (size_t)grp * lr.gsc : nullptr;
   // XCD-contiguous block ranges (bijective remap, cdna guide T1)
@@ -558,7 +559,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
         double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (HAS_R) out += beta_r * r[(size_t)row * ldr + cc];
         if (HAS_LR && row < lr.nrows) out -= lowrank_term(lr, lrc, row, cc, m);
-        y[(size_t)row * ldy + cc] = out;
+        if (y32) y32[(size_t)row * ldy + cc] = (float)out;
+        else y[(size_t)row * ldy + cc] = out;
       }
     }
   }
@@ -578,7 +580,7 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
   const size_t lds = spmm_blocked_lds_bytes(m, max_cols, 0);
 #define RICADI_TILE_LAUNCH(R, L)                                                                  \
   hipLaunchKernelGGL((spmm_blocked_kernel<R, L>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt, \
-                     vals, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, lr)
+                     vals, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, lr, (float*)nullptr)
   const bool has_lr = lr.q > 0 && lr.nrows > 0;
   if (r && has_lr) RICADI_TILE_LAUNCH(true, true);
   else if (r) RICADI_TILE_LAUNCH(true, false);
@@ -591,13 +593,13 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 // is converted while it is staged, the inner loop is the same
 void launch_spmm_blocked_x32(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2, const int* rp2,
                              const int* cols2, const uint16_t* lidx, const GroupPtrs& vals, const float* x, int ldx,
-                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols) {
+                             size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols, float* y32) {
   if (nblk <= 0 || gt.ng <= 0) return;
   const dim3 grid(nblk, 1, gt.ng), block(256);
   const size_t lds = spmm_blocked_lds_bytes(m, max_cols, 0);
   hipLaunchKernelGGL((spmm_blocked_kernel<false, false, float>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
                      vals, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0, (size_t)0, alpha, 0.0, m, max_cols,
-                     LowRankArgs());
+                     LowRankArgs(), y32);
 }
 
 // ---------------------------------------------------------------------------
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
     const double* __restrict__ vAJ, const double* __restrict__ vE,
     const XT* __restrict__ x, int ldx, size_t gsx, double* __restrict__ y, int ldy, size_t gsy,
     const double* __restrict__ r, int ldr, size_t gsr, double alpha, double beta_r, int m,
-    int max_cols) {
+    int max_cols, float* __restrict__ y32) {
   extern __shared__ double xs[];                             // 2 tiles of max_cols x 16
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int qd = nwg >> 3, rm = nwg & 7, xcd = orig & 7;
@@ -772,7 +774,8 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
         const int row = grow[rr];
         double out = alpha * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (HAS_R) out += beta_r * rg[(size_t)row * ldr + g];
-        yg[(size_t)row * ldy + g] = out;
+        if (y32) y32[(size_t)grp * gsy + (size_t)row * ldy + g] = (float)out;
+        else yg[(size_t)row * ldy + g] = out;
       }
     }
     if (more) {
@@ -787,7 +790,7 @@ size_t spmm_blocked_ms_lds_bytes(int max_cols) { return (size_t)2 * max_cols * 1
 void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double* alphas, const double* betas,
                                 int nblk, const int* rows2, const int* rp2, const int* cols2, const uint16_t* lidx,
                                 const double* vAJ, const double* vE, const float* x, int ldx, size_t gsx, double* y,
-                                int ldy, size_t gsy, double alpha, int m, int max_cols) {
+                                int ldy, size_t gsy, double alpha, int m, int max_cols, float* y32) {
   if (nblk <= 0 || gt.ng <= 0) return;
   GroupCoefs cf;
   for (int i = 0; i < RICADI_MAX_GROUPS; ++i) {
@@ -800,7 +803,7 @@ void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double
   const dim3 grid(nblk, ysplit, 1), block(256);
   hipLaunchKernelGGL((spmm_blocked_ms_kernel<false, float>), grid, block, spmm_blocked_ms_lds_bytes(max_cols), st,
                      rows2, rp2, cols2, lidx, gt, cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0,
-                     (size_t)0, alpha, 0.0, m, max_cols);
+                     (size_t)0, alpha, 0.0, m, max_cols, y32);
 }
 // max_cols <= 160 (tile slots per thread: 16 x XP x XJ), m <= 16, panel offsets in 31 bits
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows) {
@@ -829,10 +832,10 @@ void launch_spmm_blocked_ms(hipStream_t st, const GroupTab& gt, const double* al
   const size_t lds = spmm_blocked_ms_lds_bytes(max_cols);
   if (r)
     hipLaunchKernelGGL((spmm_blocked_ms_kernel<true>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
-                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols);
+                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, (float*)nullptr);
   else
     hipLaunchKernelGGL((spmm_blocked_ms_kernel<false>), grid, block, lds, st, rows2, rp2, cols2, lidx, gt,
-                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols);
+                       cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, r, ldr, gsr, alpha, beta_r, m, max_cols, (float*)nullptr);
 }
 
 // dst[k] = src[perm[k]]  (assembled CSR values -> block order)

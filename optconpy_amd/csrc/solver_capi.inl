@@ -467,6 +467,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   if (const char* e = getenv("RICADI_ROWWAVE")) c->rowwave = e[0] != '0';
   if (const char* e = getenv("RICADI_BLOCKS16")) c->blocks16 = e[0] != '0';
   if (const char* e = getenv("RICADI_X32")) c->x32_always = e[0] != '0';
+  if (const char* e = getenv("RICADI_W32")) c->w32 = e[0] != '0';
   // multi-shift kernel operands: vAJ = A part + J part (disjoint supports) and vE in tile
   // order; velocity-velocity flag in bit 15 of the local index
   auto ms_arrays = [&](const std::vector<int>& rp, const std::vector<int>& ci, const std::vector<double>& a,
@@ -1015,11 +1016,14 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
   double* V = c->basis.p;
   const GroupTab& gt = bt.tab;
   const GroupPtrs ones = same_ptr(c->ones.p);
+  // the operator's output and the Arnoldi passes on the FP32 panel where the iteration uses it
+  const bool tw32 = b16 && c->zbasisf.p &&
+                    iteration_w32(c, m, ng, b16, update_hess_fused_ok(m, b16), update_dots_keeps_w(m, b16, restart), restart);
   auto launch = [&]() {
     switch (which) {
       case 0:
         saddle_spmm(c, bt, c->zv.p, nm, nullptr, c->wv.p, nm, nullptr, 0, 1.0, 0.0, LowRankArgs(),
-                    iteration_reads_x32(c, m, ng) && c->zbasisf.p ? c->zbasisf.p : nullptr);
+                    iteration_reads_x32(c, m, ng) && c->zbasisf.p ? c->zbasisf.p : nullptr, tw32 ? c->wv32.p : nullptr);
         break;
       case 1:
         if (c->precond32)
@@ -1068,13 +1072,15 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
                               -1.0, 1.0, m, c->syb_max_cols);
         break;
       case 5:
-        if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
+        if (tw32) launch_cols_dots16_w32(st, gt, n, nvec, Vh, vs, nm, c->wv32.p, nm, c->partial.p, gspart, c->h1.p, gsh);
+        else if (b16) launch_cols_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else if (b32) launch_cols_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         else launch_cols_dots_b(st, gt, n, m, nvec, V, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart, c->h1.p, gsh);
         break;
       case 6:
         set_update_dots_nostore(update_dots_keeps_w(m, b16, restart));   // as the iteration launches it
-        if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        if (tw32) launch_cols_update_dots16_w32(st, gt, n, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv32.p, nm, c->partial.p, gspart, c->h2.p, gsh);
+        else if (b16) launch_cols_update_dots_b(st, gt, n, m, nvec, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else if (b32) launch_cols_update_dots_b(st, gt, n, m, nvec, Vf, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         else launch_cols_update_dots_b(st, gt, n, m, nvec, V, vs, nm, c->h1.p, gsh, c->wv.p, nm, c->partial.p, gspart, c->h2.p, gsh);
         set_update_dots_nostore(false);
@@ -1084,7 +1090,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
           launch_cols_update16_hess_b(st, gt, n, nvec, Vh, vs, nm, c->h1.p, c->h2.p, gsh, update_dots_keeps_w(m, b16, restart) ? 1 : 0,
                                       c->wv.p, nm, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm,
                                       nvec - 1, restart, c->H.p, c->cs.p, c->sn.p, c->g.p, c->resid.p, c->resid.p + c->wcols,
-                                      c->bnorm2.p, c->opts.gmres_tol, nullptr);
+                                      c->bnorm2.p, c->opts.gmres_tol, nullptr, tw32 ? c->wv32.p : nullptr);
         else if (b16) launch_cols_update_b(st, gt, n, m, nvec, Vh, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, precond_reads_h16(c, m) ? nullptr : c->vcur.p, nm, Vh + (size_t)nvec * vs, nm);
         else if (b32) launch_cols_update_b(st, gt, n, m, nvec, Vf, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, c->vcur.p, nm, Vf + (size_t)nvec * vs, nm);
         else launch_cols_update_b(st, gt, n, m, nvec, V, vs, nm, c->h2.p, gsh, -1.0, c->wv.p, nm, c->scale.p, V + (size_t)nvec * vs, nm);

@@ -55,6 +55,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   } nostore_scope(keepw);
   const size_t h2buf = (size_t)(restart + 2) * c->wcols;        // doubles between the two second-pass buffers
   const bool x32 = iteration_reads_x32(c, m, G) && !(lowrank && c->q > 0);
+  const bool w32 = x32 && iteration_w32(c, m, G, b16, fuseh, keepw, restart);
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;
@@ -177,9 +178,13 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
       // holds for exactly the vectors the correction uses), so the sweeps need not store the FP64 z at all
       float* zj = flex ? c->zbasisf.p + (size_t)j * vs : nullptr;
       precond_apply(c, bt, vj, nm, c->zv.p, zj, nm, x32, h16 ? Vh + (size_t)j * vs : nullptr);
-      op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr);
+      op_apply(c, bt, c->zv.p, nm, c->wv.p, lowrank, x32 ? zj : nullptr, w32 ? c->wv32.p : nullptr);
       double* h2cur = c->h2.p;
-      if (b16) {
+      if (w32) {
+        launch_cols_dots16_w32(st, bt.tab, n, j + 1, Vh, vs, nm, c->wv32.p, nm, c->partial.p, gspart, c->h1.p, gsh);
+        launch_cols_update_dots16_w32(st, bt.tab, n, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv32.p, nm, c->partial.p,
+                                      gspart, c->h2.p, gsh);
+      } else if (b16) {
         launch_cols_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->wv.p, nm, 0, c->partial.p, gspart,
                            c->h1.p, gsh);
         launch_cols_update_dots_b(st, bt.tab, n, m, j + 1, Vh, vs, nm, c->h1.p, gsh, c->wv.p, nm,
@@ -203,7 +208,8 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
         launch_cols_update16_hess_b(st, bt.tab, n, j + 1, Vh, vs, nm, c->h1.p, h2cur, gsh, keepw ? 1 : 0, c->wv.p, nm,
                                     h16 ? nullptr : c->vcur.p, nm, Vh + (size_t)(j + 1) * vs, nm, j, restart, c->H.p,
                                     c->cs.p, c->sn.p, c->g.p, c->resid.p + (size_t)(j & 1) * resbuf,
-                                    c->resid.p + (size_t)((j + 1) & 1) * resbuf, c->bnorm2.p, tol, cur);
+                                    c->resid.p + (size_t)((j + 1) & 1) * resbuf, c->bnorm2.p, tol, cur,
+                                    w32 ? c->wv32.p : nullptr);
       else
         launch_gmres_hess_b(st, bt.tab, m, j, restart, c->h1.p, h2cur, c->H.p, c->cs.p, c->sn.p,
                             c->g.p, c->scale.p, c->resid.p, c->bnorm2.p, tol, cur, nullptr, nullptr,

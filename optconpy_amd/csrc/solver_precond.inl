@@ -109,7 +109,7 @@ static bool saddle_tiled(const ricadi_ctx* c, int m) {
 static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx,
                         const int* xmap, double* y, size_t gsy, const double* r, size_t gsr,
                         double alpha, double beta_r, const LowRankArgs& lr = LowRankArgs(),
-                        const float* x32 = nullptr) {
+                        const float* x32 = nullptr, float* y32 = nullptr) {
   const int m = bt.m;
   const bool fits = saddle_tiled(c, m);
   const bool has_lr = lr.q > 0 && lr.nrows > 0;
@@ -119,12 +119,13 @@ static void saddle_spmm(ricadi_ctx* c, const Batch& bt, const double* x, size_t 
     if (ms)
       launch_spmm_blocked_ms_x32(c->st, bt.tab, bt.alpha, bt.beta, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p,
                                  c->sb_cols2.p, c->sb_lidx_ms.p, c->sbAJ.p, c->sbE.p, x32, m, gsx, y, m, gsy, alpha,
-                                 m, c->sb_max_cols);
+                                 m, c->sb_max_cols, y32);
     else
       launch_spmm_blocked_x32(c->st, bt.tab, c->sb_nblk, c->sb_rows2.p, c->sb_rp2.p, c->sb_cols2.p, c->sb_lidx.p,
-                              bt.svalb, x32, m, gsx, y, m, gsy, alpha, m, c->sb_max_cols);
+                              bt.svalb, x32, m, gsx, y, m, gsy, alpha, m, c->sb_max_cols, y32);
     return;
   }
+  if (y32) throw HipError{"FP32 operator output asked for outside the FP32-input tile kernels"};
   const bool ms = fits && ms_pays(c, bt.tab.ng, c->snnz) && !xmap && !has_lr &&
                   spmm_blocked_ms_ok(m, c->sb_max_cols, (size_t)c->n);
   if (!xmap) c->k1_variant = ms ? 2 : fits ? 1 : 0;
@@ -154,8 +155,9 @@ static bool iteration_reads_x32(const ricadi_ctx* c, int m, int ng) {
 
 // y = S(alpha,beta) x for every active group (n x m panels, ld = m, group stride gsx /
 // bt.gs); optional low-rank  - U V^T x_v  (U, V shared by the groups)
+// y32 (optional, with x32 only): the product goes to this FP32 panel (stride bt.gs) and y is not written
 static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx, double* y,
-                     bool lowrank, const float* x32 = nullptr) {
+                     bool lowrank, const float* x32 = nullptr, float* y32 = nullptr) {
   hipStream_t st = c->st;
   const int m = bt.m;
   LowRankArgs lr;
@@ -169,7 +171,12 @@ static void op_apply(ricadi_ctx* c, const Batch& bt, const double* x, size_t gsx
     lr.q = c->q;
     lr.nrows = c->nv;
   }
-  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0, lr, x32);
+  saddle_spmm(c, bt, x, gsx, nullptr, y, bt.gs, nullptr, 0, 1.0, 0.0, lr, x32, y32);
+}
+// Does the Arnoldi iteration of a batch keep w = S z_j as an FP32 panel?  (the tile kernels with FP32 input write it,
+// the three 16-column passes on the FP16-stored basis read it; RICADI_W32=0: FP64 panel)
+static bool iteration_w32(const ricadi_ctx* c, int m, int ng, bool b16, bool fuseh, bool keepw, int restart) {
+  return c->w32 && m == 16 && b16 && fuseh && keepw && iteration_reads_x32(c, m, ng) && arnoldi16_w32_ok(restart);
 }
 
 // z = P^-1 r for every active group: multiplicative two-level, coarse correction

@@ -53,6 +53,7 @@ static void ensure_work(ricadi_ctx* c, int m, int groups = 1, int extra = -1) {
   if (c->flex) c->zbasisf.alloc((size_t)restart * nm);
   else c->zbasisf.release();
   c->wv.alloc(nm);
+  c->wv32.alloc(nm);
   c->zv.alloc(nm);
   c->r2.alloc(nm);
   c->xs.alloc(nm);
