@@ -123,7 +123,10 @@ def spmm_roofline(ctx, nnz_k, nnz_j, n, m, shifts, reps=200):
     al, be = [float(p) for p in shifts], [1.0] * G
     ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), 20)          # warm-up
     med, best = trials(lambda: ctx.time_spmm_batch_dev(al, be, x.data_ptr(), m, y.data_ptr(), reps))
-    variant = ctx.setup_info().get("k1_variant", -1)          # kernel of the batched launch (the library's own record)
+    sinfo = ctx.setup_info()
+    variant = sinfo.get("k1_variant", -1)          # kernel of the batched launch (the library's own record)
+    xb = 4.0 if variant >= 4 else 8.0               # panel bytes per entry as the launch moved them: FP32 Z_j in ...
+    yb = 4.0 if sinfo.get("fp32_operator_output", 0) == 1 else 8.0     # ... FP32 w out (round 4), else FP64
     med1, best1 = trials(lambda: ctx.time_spmm_dev(al[0], 1.0, x.data_ptr(), m, y.data_ptr(), reps))
     unit = 12.0 * nnz_s + 4.0 * (n + 1) + 16.0 * n * m
     nbytes = unit * G
@@ -154,6 +157,11 @@ def spmm_roofline(ctx, nnz_k, nnz_j, n, m, shifts, reps=200):
                 algorithmic_bytes_per_panel_model=int(nbytes),
                 algorithmic_bytes_batched_form=int(b_batch),
                 frac_batched_form=round(b_batch / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                panels_as_stored="x %s in, y %s out (the algorithmic bytes count FP64 panels, SURVEY.md 8d)"
+                                 % ("FP32" if xb == 4.0 else "FP64", "FP32" if yb == 4.0 else "FP64"),
+                bytes_batched_form_as_stored=int(b_batch - (16.0 - xb - yb) * n * m * G),
+                frac_batched_form_as_stored=round((b_batch - (16.0 - xb - yb) * n * m * G) / (med * 1e-3) / 1e9
+                                                  / HBM_PEAK_GBS, 4),
                 traffic_over_batched_form=(round(traffic / b_batch, 3) if traffic else None),
                 n=int(n), m=int(m), nnz=int(nnz_s),
                 single_panel_us_per_launch=round(med1 * 1e3, 2),
@@ -178,6 +186,8 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
     b = 8 if os.environ.get("RICADI_BASIS64") else (4 if os.environ.get("RICADI_BASIS32") else 2)
     pb_ = 8 if os.environ.get("RICADI_PRECOND64") else 4
     kp = 16 * ((kc + 15) // 16)
+    ctx.time_kernel_dev("dots", al, be, m, nvec=nvec, reps=1)       # the library then knows which panel the passes read
+    wb = 4.0 if ctx.setup_info().get("fp32_operator_output", 0) == 1 else 8.0
     models = {
         # a plain velocity-sized sweep: not launched by the folded cycle (see pc_two_term / pc_rect below); kept as the
         # reference point of the block-Jacobi apply itself
@@ -185,12 +195,16 @@ def kernel_rooflines(ctx, shifts, m, nvec=7, reps=100):
                     % ("double" if pb_ == 8 else "float"), G * (pb_ * nb * 1024.0 + 16.0 * nv * m)),
         "coarse": ("ricadi::dense_apply_tiled_kernel" if pb_ == 4 else "ricadi::dense_apply_kernel<double>",
                    G * (pb_ * float(kp) * kp + 16.0 * kc * m)),
-        "dots": ("ricadi::cols_dots_kernel (+reduce_partials)", G * ((nvec * b + 8.0) * n * m)),
-        "update_dots": ("ricadi::cols_update_dots_kernel (+reduce_partials)", G * ((nvec * b + 16.0) * n * m)),
+        # w: 4 B per entry where the operator writes the FP32 panel (round 4), read once per pass; the second pass keeps
+        # w as it is on the FP16 16-column path (nothing written back), else it writes the projected w
+        "dots": ("ricadi::cols_dots%s_kernel (+reduce_partials)" % ("16" if b == 2 and m == 16 else ""),
+                 G * ((nvec * b + wb) * n * m)),
+        "update_dots": ("ricadi::cols_update_dots%s_kernel (+reduce_partials)" % ("16" if b == 2 and m == 16 else ""),
+                        G * ((nvec * b + wb + (0.0 if b == 2 and m == 16 else 8.0)) * n * m)),
         # ... + w read + the new vector in storage precision (+ its FP64 copy unless the preconditioner reads the FP16 one)
         "update": ("ricadi::cols_update16_hess_kernel (last Arnoldi pass + Hessenberg / Givens update)" if b == 2 and m == 16
                    else "ricadi::cols_update_kernel",
-                   G * ((nvec * b + 8.0 + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
+                   G * ((nvec * b + wb + b + (0.0 if b == 2 and info.get("fp16_vector_input") else 8.0)) * n * m)),
     }
     out = {}
     for key, (kname, nbytes) in models.items():
@@ -954,9 +968,11 @@ def main():
                 "K_rel_diff_vs_oracle": k_orc,
                 "K_rel_diff_vs_converged": k_conv,
                 "storage": "arithmetic and all residual checks FP64; Krylov basis stored in %s, "
+                           "Z_j = P^-1 v_j in FP32, the operator's output w inside the iteration in %s, "
                            "preconditioner: coarse inverse in %s, block operands of the sweeps in %s, the velocity part "
-                           "between its sweeps in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage)"
-                           % (basis, prec,
+                           "between its sweeps in %s (RICADI_BASIS64=1 RICADI_PRECOND64=1: FP64 storage of basis, w and "
+                           "preconditioner)"
+                           % (basis, "FP32" if ctx.setup_info().get("fp32_operator_output", 0) == 1 else "FP64", prec,
                               "BF16" if prec == "FP32" and os.environ.get("RICADI_BLOCKS16", "1") != "0"
                               and os.environ.get("RICADI_MID32", "1") != "0" else prec,
                               "FP32" if prec == "FP32" and os.environ.get("RICADI_MID32", "1") != "0" else "FP64"),

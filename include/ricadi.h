@@ -370,7 +370,9 @@ int ricadi_qr(ricadi_ctx* ctx, const double* Z, int c, double* Q_out, double* R_
  *        kernel of the last saddle SpMM launch (0 CSR, 1 LDS-tiled per group, 2 LDS-tiled multi-shift; +4 with
  *        FP32 x input; -1 none yet),
  *        1 if the last preconditioner application kept the velocity part between its sweeps as an FP32 panel
- *        (first sweep -> pressure step -> last sweep), 0 for an FP64 panel; -1 none yet];
+ *        (first sweep -> pressure step -> last sweep), 0 for an FP64 panel; -1 none yet,
+ *        1 if the operator launch of the last iteration (or timing call) wrote w = S z as an FP32 panel for the
+ *        Arnoldi passes, 0 for FP64; -1 none yet];
  * nout >= 8; entries beyond nout are not written.                                   */
 int ricadi_setup_info(ricadi_ctx* ctx, int* out, int nout);
 

@@ -679,11 +679,12 @@ class Context:
         return ms.value
 
     def setup_info(self):
-        a = (C.c_int * 20)()
-        _chk(self._lib.ricadi_setup_info(self._h, a, 20))
+        a = (C.c_int * 21)()
+        _chk(self._lib.ricadi_setup_info(self._h, a, 21))
         return dict(zip(("nv", "np", "nbv", "nbp", "bs", "kc", "spmm_row_blocks", "spmm_max_cols", "levels",
                          "dense_coarse", "fp16_vector_input", "rect_ks", "two_term_ks", "np_", "nnz_j",
-                         "nnz_sy", "nnz_restriction", "coarse_route", "k1_variant", "fp32_intermediate"), list(a)))
+                         "nnz_sy", "nnz_restriction", "coarse_route", "k1_variant", "fp32_intermediate", "fp32_operator_output"),
+                        list(a)))
 
     def dense_inverse_batch(self, mats):
         """In-place inverses of a batch of dense matrices by the setup's coarse-matrix routine; returns

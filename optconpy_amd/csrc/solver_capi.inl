@@ -950,10 +950,17 @@ int ricadi_time_spmm_batch_dev(ricadi_ctx* c, int ng, const double* alphas, cons
     for (int g = 0; g < ng; ++g)
       launch_to_f32(c->st, c->n, m, dX + (size_t)g * bt.gs, m, x32.p + (size_t)g * bt.gs, m);
   }
-  saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p);
+  // ... and into an FP32 panel when the iteration's Arnoldi passes read one (dY is then left alone)
+  DArr<float> y32;
+  const bool b16t = getenv("RICADI_BASIS64") == nullptr && getenv("RICADI_BASIS32") == nullptr && c->n <= (1 << 21);
+  if (x32.p && iteration_w32(c, m, ng, b16t, update_hess_fused_ok(m, b16t),
+                             update_dots_keeps_w(m, b16t, c->opts.gmres_restart), c->opts.gmres_restart))
+    y32.alloc(bt.gs * ng);
+  c->w32_last = y32.p ? 1 : 0;
+  saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p, y32.p);
   HIPCHK(hipEventRecord(e0, c->st));
   for (int i = 0; i < reps; ++i)
-    saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p);
+    saddle_spmm(c, bt, dX, bt.gs, nullptr, dY, bt.gs, nullptr, 0, 1.0, 0.0, LowRankArgs(), x32.p, y32.p);
   HIPCHK(hipEventRecord(e1, c->st));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -1019,6 +1026,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
   // the operator's output and the Arnoldi passes on the FP32 panel where the iteration uses it
   const bool tw32 = b16 && c->zbasisf.p &&
                     iteration_w32(c, m, ng, b16, update_hess_fused_ok(m, b16), update_dots_keeps_w(m, b16, restart), restart);
+  c->w32_last = tw32 ? 1 : 0;
   auto launch = [&]() {
     switch (which) {
       case 0:
@@ -1191,6 +1199,8 @@ int ricadi_setup_info(ricadi_ctx* c, int* out, int nout) {
   // [19]: the last preconditioner application kept the velocity part between its sweeps as an FP32 panel (1) or as
   // an FP64 panel (0); -1 none yet
   if (nout > 19) out[19] = c->mid32_last;
+  // [20]: the operator launch of the last iteration / timing call wrote w as an FP32 panel (1) or FP64 (0); -1 none yet
+  if (nout > 20) out[20] = c->w32_last;
   return RICADI_OK;
 }
 

@@ -56,6 +56,7 @@ static void gmres_core(ricadi_ctx* c, ShiftData* const* sds, int G, const double
   const size_t h2buf = (size_t)(restart + 2) * c->wcols;        // doubles between the two second-pass buffers
   const bool x32 = iteration_reads_x32(c, m, G) && !(lowrank && c->q > 0);
   const bool w32 = x32 && iteration_w32(c, m, G, b16, fuseh, keepw, restart);
+  c->w32_last = w32 ? 1 : 0;
   _Float16* Vh = reinterpret_cast<_Float16*>(c->basisf.p);   // FP16 storage shares the FP32 buffer
   double* hb = c->h_resid;
   const size_t slot = (size_t)RICADI_MAX_M * RICADI_MAX_GROUPS;

@@ -50,16 +50,22 @@ def mean_of(f):
 
 
 old = json.load(open(os.path.join(dst, "r03_spmm_traffic.json")))
-old["_note"] = ("round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a).  FETCH_SIZE counts requests x 64 B "
-                "(profiles/r04_pmc_calibration.txt): cfg2 2 x FETCH + WRITE; cfg5 (FP32 x rows in full, 18-B matrix stream doubled)")
+old["_note"] = ("round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a) on the launch as the iteration issues it "
+                "(FP32 Z_j in, FP32 w out).  FETCH_SIZE counts requests x 64 B (profiles/r04_pmc_calibration.txt): "
+                "hbm_bytes = (FETCH - matrix/2) + matrix + WRITE, matrix = the value / index stream of the kernel")
 for key, n in (("16x29930x16", "58"), ("16x499850x16", "236")):
     fk = mean_of(os.path.join(src, "spmm%s_FETCH_SIZE.txt" % n))
     wk = mean_of(os.path.join(src, "spmm%s_WRITE_SIZE.txt" % n))
     old[key].update(FETCH_SIZE_KB=fk, WRITE_SIZE_KB=wk, hbm_bytes=int((2 * fk + wk) * 1024),
                     hbm_bytes_lower=int((fk + wk) * 1024))
-    if n == "236":      # multi-shift kernel with FP32 x gathers: 64-B requests are counted in full, the matrix stream at half
-        matrix = 18.0 * 14369733
-        old[key].update(hbm_bytes_uncalibrated_2x_fetch=old[key]["hbm_bytes"],
-                        hbm_bytes=int((fk * 1024 - matrix / 2) + matrix + wk * 1024))
+    # FP32 x gathers (64-B requests) are counted in full, the matrix stream (>= 128-B requests) at half
+    # (profiles/r04_pmc_calibration.txt).  cfg5: multi-shift kernel, 18 B per non-zero once; cfg2 (second half of
+    # round 4: the per-group kernel also reads the FP32 Z_j and writes the FP32 w): 10 B per non-zero and group
+    matrix = 18.0 * 14369733 if n == "236" else 10.0 * 847488 * 16
+    old[key].update(hbm_bytes_uncalibrated_2x_fetch=old[key]["hbm_bytes"],
+                    hbm_bytes=int((fk * 1024 - matrix / 2) + matrix + wk * 1024))
+    old[key]["kernel"] = ("ricadi::spmm_blocked_ms_kernel<false, float> (multi-shift: values of all groups from one read)"
+                          if n == "236" else "ricadi::spmm_blocked_kernel<false, false, float> (one value array per group)") \
+        + "; x gathered from the FP32-stored Z_j, w written as an FP32 panel" 
 json.dump(old, open(os.path.join(dst, "r04_spmm_traffic.json"), "w"), indent=1)
 print("installed", tag)
