@@ -68,4 +68,18 @@ for key, n in (("16x29930x16", "58"), ("16x499850x16", "236")):
                           if n == "236" else "ricadi::spmm_blocked_kernel<false, false, float> (one value array per group)") \
         + "; x gathered from the FP32-stored Z_j, w written as an FP32 panel" 
 json.dump(old, open(os.path.join(dst, "r04_spmm_traffic.json"), "w"), indent=1)
+# the bench line of the record was printed before these PMC passes were installed: its traffic fields are refreshed
+# from them (same arithmetic as bench.py: traffic = hbm_bytes of the launch, ratio to the batched-form bytes)
+line_f = os.path.join(dst, "r04_bench_line.json")
+if os.path.exists(line_f):
+    line = json.load(open(line_f))
+    for obj, key in (("roofline", "16x29930x16"), ("roofline_cfg5", "16x499850x16")):
+        if obj in line and key in old:
+            line[obj]["traffic"] = old[key]["hbm_bytes"]
+            line[obj]["traffic_source"] = "r04_spmm_traffic.json (PMC passes of this record, installed by tools/install_record.py)"
+            line[obj]["traffic_over_batched_form"] = round(old[key]["hbm_bytes"] / line[obj]["algorithmic_bytes_batched_form"], 3)
+            if "bytes_batched_form_as_stored" in line[obj]:
+                line[obj]["traffic_over_batched_form_as_stored"] = round(
+                    old[key]["hbm_bytes"] / line[obj]["bytes_batched_form_as_stored"], 3)
+    json.dump(line, open(line_f, "w"))
 print("installed", tag)
