@@ -459,6 +459,36 @@ __global__ __launch_bounds__(256) void spmm_blocked_kernel(
   // LDS stores -- so that the loads are in flight together (a load followed by
   // its own ds_write makes hipcc wait vmcnt(0) per row).
   constexpr int XJ = 5;                        // 16 groups x 5 = 80 tile rows per pass
+  if (sizeof(XT) == 4 && m == 16) {
+    // FP32 rows of 16 columns are 64 B: a lane takes FOUR columns (16-byte load), a 16-lane group four rows per load
+    // -- a quarter of the gather instructions of the one-column form.  (That form made the FP32-input kernel 10 %
+    // slower than the FP64-input one -- same number of row requests, nothing gained from the smaller rows; two columns
+    // per lane: 80.8 -> 65.5 us per 16-group launch at cfg2.)
+    constexpr int XQ = 3;                      // 16 groups x 4 rows x 3 = 192 tile rows per pass
+    const int sub = g >> 2, c4 = (g & 3) * 4;
+    for (int jb = 0; jb < max_cols; jb += 64 * XQ) {
+      int cidx[XQ];
+      float4 xv[XQ];
+#pragma unroll
+      for (int t = 0; t < XQ; ++t) {
+        const int j = jb + 4 * gq + sub + 64 * t;
+        cidx[t] = (j < max_cols) ? bcols[j] : -1;
+      }
+#pragma unroll
+      for (int t = 0; t < XQ; ++t)
+        xv[t] = (cidx[t] >= 0) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)cidx[t] * 16 + c4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < XQ; ++t) {
+        const int j = jb + 4 * gq + sub + 64 * t;
+        if (cidx[t] >= 0) {
+          double2* d = reinterpret_cast<double2*>(xs + j * 16 + c4);
+          d[0] = make_double2((double)xv[t].x, (double)xv[t].y);
+          d[1] = make_double2((double)xv[t].z, (double)xv[t].w);
+        }
+      }
+    }
+  } else
   for (int cc = g; cc < m; cc += 16) {
     for (int jb = 0; jb < max_cols; jb += 16 * XJ) {
       int cidx[XJ];
@@ -626,7 +656,7 @@ struct GroupCoefs {
 //     value = alpha_g * vE + (entry in the velocity-velocity block ? beta_g : 1) * vAJ,
 // the block membership riding in bit 15 of the 16-bit local column index (tiles have at
 // most 160 columns).
-template <bool HAS_R, class XT = double>
+template <bool HAS_R, class XT = double, bool F4 = false>
 __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
     const int* __restrict__ rows2, const int* __restrict__ rp2, const int* __restrict__ cols2,
     const uint16_t* __restrict__ lidx, GroupTab gt, GroupCoefs cf,
@@ -655,14 +685,16 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
   const int gc = g < m ? g : 0;                // lanes beyond m shadow column 0 (kept in the broadcasts)
   // tile slots of this thread (the same for every group): byte offsets into a panel, -1 = none
   int xoff[XP][XJ];
+  if constexpr (!F4) {
 #pragma unroll
-  for (int pp = 0; pp < XP; ++pp)
+    for (int pp = 0; pp < XP; ++pp)
 #pragma unroll
-    for (int t = 0; t < XJ; ++t) {
-      const int j = pp * 16 * XJ + gq + 16 * t;
-      const int ci = (j < max_cols) ? bcols[j] : -1;
-      xoff[pp][t] = ci >= 0 ? (ci * ldx + gc) * (int)sizeof(XT) : -1;
-    }
+      for (int t = 0; t < XJ; ++t) {
+        const int j = pp * 16 * XJ + gq + 16 * t;
+        const int ci = (j < max_cols) ? bcols[j] : -1;
+        xoff[pp][t] = ci >= 0 ? (ci * ldx + gc) * (int)sizeof(XT) : -1;
+      }
+  }
 #pragma unroll
   for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
@@ -677,8 +709,29 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
   int gi = blockIdx.y;
   if (gi >= gt.ng) return;
   XT xv[XP][XJ];             // raw loads (converted when they go to the LDS tile)
+  // FP32 rows of 16 columns (64 B): four columns per lane, 64 tile rows per pass of the workgroup -- three 16-byte
+  // loads per thread and group instead of ten 4-byte ones (the per-group kernel gained 27 % from the same change)
+  constexpr int XQ = 3;
+  constexpr bool f4 = F4;                    // launcher: XT = float, m = ldx = 16
+  const int j4 = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+  int xoff4[XQ];
+  float4 xv4[XQ];
+  if constexpr (f4) {
+#pragma unroll
+    for (int t = 0; t < XQ; ++t) {
+      const int j = j4 + 64 * t;
+      const int ci = (j < max_cols) ? bcols[j] : -1;
+      xoff4[t] = ci >= 0 ? (ci * 16 + c4) * 4 : -1;
+    }
+  }
   auto fetch = [&](int grp) {
     const char* __restrict__ xg = reinterpret_cast<const char*>(x + (size_t)grp * gsx);
+    if constexpr (f4) {
+#pragma unroll
+      for (int t = 0; t < XQ; ++t)
+        xv4[t] = (xoff4[t] >= 0) ? *reinterpret_cast<const float4*>(xg + (unsigned)xoff4[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
 #pragma unroll
     for (int pp = 0; pp < XP; ++pp)
 #pragma unroll
@@ -687,6 +740,18 @@ __global__ __launch_bounds__(256) void spmm_blocked_ms_kernel(
   };
   auto stash = [&](int buf) {
     double* __restrict__ tile = xs + (size_t)buf * max_cols * 16;
+    if constexpr (f4) {
+#pragma unroll
+      for (int t = 0; t < XQ; ++t) {
+        const int j = j4 + 64 * t;
+        if (j < max_cols) {
+          double2* d = reinterpret_cast<double2*>(tile + j * 16 + c4);
+          d[0] = make_double2((double)xv4[t].x, (double)xv4[t].y);
+          d[1] = make_double2((double)xv4[t].z, (double)xv4[t].w);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int pp = 0; pp < XP; ++pp)
 #pragma unroll
@@ -801,9 +866,14 @@ void launch_spmm_blocked_ms_x32(hipStream_t st, const GroupTab& gt, const double
   while (ysplit < gt.ng && (long)nblk * ysplit < 900 && ysplit < 8) ysplit *= 2;
   ysplit = std::min(ysplit, gt.ng);
   const dim3 grid(nblk, ysplit, 1), block(256);
-  hipLaunchKernelGGL((spmm_blocked_ms_kernel<false, float>), grid, block, spmm_blocked_ms_lds_bytes(max_cols), st,
-                     rows2, rp2, cols2, lidx, gt, cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0,
-                     (size_t)0, alpha, 0.0, m, max_cols, y32);
+  if (m == 16 && ldx == 16 && max_cols <= 192)
+    hipLaunchKernelGGL((spmm_blocked_ms_kernel<false, float, true>), grid, block, spmm_blocked_ms_lds_bytes(max_cols), st,
+                       rows2, rp2, cols2, lidx, gt, cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0,
+                       (size_t)0, alpha, 0.0, m, max_cols, y32);
+  else
+    hipLaunchKernelGGL((spmm_blocked_ms_kernel<false, float, false>), grid, block, spmm_blocked_ms_lds_bytes(max_cols), st,
+                       rows2, rp2, cols2, lidx, gt, cf, vAJ, vE, x, ldx, gsx, y, ldy, gsy, (const double*)nullptr, 0,
+                       (size_t)0, alpha, 0.0, m, max_cols, y32);
 }
 // max_cols <= 160 (tile slots per thread: 16 x XP x XJ), m <= 16, panel offsets in 31 bits
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows) {
