@@ -408,10 +408,10 @@ def cpu_baseline(pr, ms, m, adi_steps, full=False):
     out = dict(value=round(ns * per_shift / step_time, 3), unit="shift-solves/s", cores=1, kind="port",
                sample=("the full step: %d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each)"
                        % (ns, lu_s, ns * per_shift, m, sol_s)) if full else
-                      ("%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) of the cfg2 "
-                       "saddle matrices, scipy SuperLU single-threaded; priced up to one step = %d LUs + "
-                       "%d shift-solves (%.0f s)" % (len(pick), lu_s, len(pick) * nsol_each, m, sol_s, ns,
-                                                    ns * per_shift, step_time)),
+                      ("%d sparse LUs (%.2f s each) + %d panel solves of m=%d (%.3f s each) of this workload's "
+                       "saddle matrices (n = %d), scipy SuperLU single-threaded; priced up to one step = %d LUs + "
+                       "%d shift-solves (%.0f s)" % (len(pick), lu_s, len(pick) * nsol_each, m, sol_s,
+                                                    pr.NV + pr.J.shape[0], ns, ns * per_shift, step_time)),
                lu_seconds=round(lu_s, 3), solve_seconds=round(sol_s, 4), step_seconds=round(step_time, 2))
     try:
         ncore = len(os.sched_getaffinity(0))

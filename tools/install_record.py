@@ -50,6 +50,11 @@ def mean_of(f):
 
 
 old = json.load(open(os.path.join(dst, "r03_spmm_traffic.json")))
+old["_comment"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/r4_final.sh: python "
+                   "tools/spmm_batch_pmc.py N 16), mean per dispatch of the batched K1 launch (16 groups, m = 16), MI355X round 4. "
+                   "hbm_bytes_uncalibrated_2x_fetch = (2*FETCH_SIZE + WRITE_SIZE)*1024 is round 3's reading (the guide's factor 2 "
+                   "for 16-B/lane streams); hbm_bytes is the calibrated reading of _note; hbm_bytes_lower uses 1x FETCH_SIZE. "
+                   "Infinity-cache hits are counted, not excluded.")
 old["_note"] = ("round 4: FETCH_SIZE / WRITE_SIZE re-collected (tools/r4_final.sh a) on the launch as the iteration issues it "
                 "(FP32 Z_j in, FP32 w out).  FETCH_SIZE counts requests x 64 B (profiles/r04_pmc_calibration.txt): "
                 "hbm_bytes = (FETCH - matrix/2) + matrix + WRITE, matrix = the value / index stream of the kernel")
@@ -64,7 +69,7 @@ for key, n in (("16x29930x16", "58"), ("16x499850x16", "236")):
     matrix = 18.0 * 14369733 if n == "236" else 10.0 * 847488 * 16
     old[key].update(hbm_bytes_uncalibrated_2x_fetch=old[key]["hbm_bytes"],
                     hbm_bytes=int((fk * 1024 - matrix / 2) + matrix + wk * 1024))
-    old[key]["kernel"] = ("ricadi::spmm_blocked_ms_kernel<false, float> (multi-shift: values of all groups from one read)"
+    old[key]["kernel"] = ("ricadi::spmm_blocked_ms_kernel<false, float, true> (multi-shift: values of all groups from one read; 16-byte tile fill)"
                           if n == "236" else "ricadi::spmm_blocked_kernel<false, false, float> (one value array per group)") \
         + "; x gathered from the FP32-stored Z_j, w written as an FP32 panel" 
 json.dump(old, open(os.path.join(dst, "r04_spmm_traffic.json"), "w"), indent=1)

@@ -72,12 +72,12 @@ def gmres_right(S, P, b, tol=1e-10, restart=30, maxit=1500):
     return x, its
 
 
-def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24):
+def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None):
     nv, npp = Ap.shape[0], J.shape[0]
     S = sps.bmat([[Ap, J.T], [J, None]], format="csr")
     blk, nb = agg(abs(Ap), bs)
     pp = (abs(J) @ abs(J).T).tocsr()
-    pblk, npb = agg(pp, bs)
+    pblk, npb = agg(pp, pbs or bs)      # pbs: pressure (Schur) blocks of their own size
     Ainv = bj_inverse(Ap, blk, nb)
     Sh = (J @ Ainv @ J.T).tocsr()
     Sinv = bj_inverse(Sh, pblk, npb)
@@ -96,21 +96,50 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24):
             Yq = Yp
         Scinv = np.linalg.inv((Yq.T @ Sh @ Yq).toarray())
 
+    if variant.startswith("cc") and cc is not None:
+        # Cahouet-Chabard form of the Schur inverse: -(c nu Mp^-1 + p [J Mb^-1 J^T]_b^-1), Mp ~ h^2 I (lumped P1 mass)
+        MTm, pshift, nu_, h_ = cc
+        cfac = float(variant[2:] or 1.0)
+        Minv_b = bj_inverse(MTm, blk, nb)
+        Lb_inv = bj_inverse((J @ Minv_b @ J.T).tocsr(), pblk, npb)
+        Sinv = (-(cfac * nu_ / h_ ** 2) * sps.identity(npp) - pshift * Lb_inv).tocsr()
+    om_p = float(variant[3:]) if variant.startswith("omp") else 1.0     # "omp0.8": damped pressure update
+    om_v = float(variant[3:]) if variant.startswith("omv") else 1.0     # "omv0.8": damped velocity correction
+    if variant.startswith("oms"):                                       # "oms0.9": the whole sweep damped
+        om_s = float(variant[3:])
+    else:
+        om_s = 1.0
+
     def schur_solve(t):
+        if om_p != 1.0:
+            return om_p * (Sinv @ t)
         if variant.startswith("schur2"):
             zc = Yq @ (Scinv @ (Yq.T @ t))
             return zc + Sinv @ (t - Sh @ zc)
         return Sinv @ t
 
+    import re as _re
+    _m = _re.search(r"oma([0-9.]+)", variant)        # "oma0.7", "post2oma0.7": damped velocity predictor
+    om_a = float(_m.group(1)) if _m else 1.0
+
     def simple(r):
-        zv = Ainv @ r[:nv]
+        zv = om_a * (Ainv @ r[:nv])
         zp = schur_solve(J @ zv - r[nv:])
-        zv = zv - Ainv @ (J.T @ zp)
-        return np.r_[zv, zp]
+        zv = zv - om_v * (Ainv @ (J.T @ zp))
+        return om_s * np.r_[zv, zp]
 
     def P(r):
         if variant == "nocoarse":
             return simple(r)
+        if variant.startswith("v11"):               # pre-sweep, coarse correction, post-sweep
+            z = simple(r)
+            r1 = r - S @ z
+            z = z + Y @ (Einv @ (Y.T @ r1))
+            return z + simple(r - S @ z)
+        if variant.startswith("post2"):             # coarse correction, two post-sweeps
+            z = Y @ (Einv @ (Y.T @ r))
+            z = z + simple(r - S @ z)
+            return z + simple(r - S @ z)
         z = Y @ (Einv @ (Y.T @ r))
         return z + simple(r - S @ z)
     return S, P, (kv, kp)
@@ -140,9 +169,17 @@ if __name__ == "__main__":
             kw = {}
             if variant.startswith("ap"):          # "ap8": base cycle with pressure aggregates of 8
                 kw = dict(ap=int(variant[2:]))
+            if variant.startswith("bs"):          # "bs64": base cycle with 64-row smoother blocks
+                kw = dict(bs=int(variant[2:]))
+            if variant.startswith("pb"):          # "pb128": Schur blocks of 128 pressure rows, velocity blocks of 32
+                kw = dict(pbs=int(variant[2:]))
             if variant.startswith("av"):          # "av8": base cycle with velocity aggregates of 8
                 kw = dict(av=int(variant[2:]))
-            S, P, kk = make_precond(Ap, pr.J, MT, "base" if kw else variant, **kw)
+            if variant.startswith("cc"):
+                kw = dict(cc=(MT, -al if be else 0.0, nu if be else 0.0, 1.0 / N))
+                if not be:      # mass only: Ap = M, Schur inverse = [J Mb^-1 J^T]_b^-1 (as base)
+                    kw = {}
+            S, P, kk = make_precond(Ap, pr.J, MT, "base" if (kw and "cc" not in kw) or (variant.startswith("cc") and not kw) else variant, **kw)
             x, its = gmres_right(S, P, b)
             row.append(its)
         print("%-10s %s   coarse (kv, kp) = %s  (%.0f s)" % (variant, "  ".join("%s: %d" % (c[0], i) for c, i in zip(cases, row)), kk,
