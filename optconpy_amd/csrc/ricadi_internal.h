@@ -223,6 +223,8 @@ void launch_spmm_blocked_b(hipStream_t st, const GroupTab& gt, int nblk, const i
 // all active groups; lidx carries the velocity-velocity flag in bit 15; alphas / betas:
 // RICADI_MAX_GROUPS coefficients indexed by group id
 bool spmm_blocked_ms_ok(int m, int max_cols, size_t panel_rows);
+// FP32 input panel: with m == 16 the kernel fills its tile with 16-byte loads and addresses x rows as 16 packed floats
+// -- the panel must be packed (ldx == 16, 16-byte aligned); the one caller (saddle_spmm) passes ldx = m
 void launch_spmm_blocked_x32(hipStream_t st, const GroupTab& gt, int nblk, const int* rows2, const int* rp2,
                              const int* cols2, const uint16_t* lidx, const GroupPtrs& vals, const float* x, int ldx,
                              size_t gsx, double* y, int ldy, size_t gsy, double alpha, int m, int max_cols, float* y32 = nullptr);

@@ -72,7 +72,7 @@ def gmres_right(S, P, b, tol=1e-10, restart=30, maxit=1500):
     return x, its
 
 
-def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None):
+def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None, sa=None, sa_steps=1, sa_shifted=False):
     nv, npp = Ap.shape[0], J.shape[0]
     S = sps.bmat([[Ap, J.T], [J, None]], format="csr")
     blk, nb = agg(abs(Ap), bs)
@@ -85,6 +85,22 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None):
     pa, kp = agg(pp, ap)
     Yv = sps.csr_matrix((np.ones(nv), (np.arange(nv), va)), shape=(nv, kv))
     Yp = sps.csr_matrix((np.ones(npp), (np.arange(npp), pa)), shape=(npp, kp))
+    if sa is not None:
+        # smoothed aggregation of the velocity prolongation as the product builds it (ricadi_host.cpp:build_setup):
+        # P_v = (I - omega D^-1 sym(cal A)) Y_v, omega = 0.5 (scaled down where rho(D^-1 K0) > 2), shift independent
+        K0 = (0.5 * (sa + sa.T)).tocsr()
+        dinv = 1.0 / sa.diagonal()
+        x = np.random.default_rng(5).standard_normal(nv)
+        for _ in range(20):
+            y = dinv * (K0 @ x)
+            rho = np.linalg.norm(y) / np.linalg.norm(x)
+            x = y / np.linalg.norm(y)
+        om = 0.5 * (2.0 / rho if rho > 2.0 else 1.0)
+        if sa_shifted:             # smooth with the SHIFTED operator's symmetric part (per-shift prolongation)
+            K0 = (0.5 * (Ap + Ap.T)).tocsr()
+            dinv = 1.0 / Ap.diagonal()
+        for _ in range(sa_steps):
+            Yv = (Yv - om * (sps.diags(dinv) @ (K0 @ Yv))).tocsr()
     Y = sps.block_diag([Yv, Yp]).tocsr()
     Einv = np.linalg.inv((Y.T @ S @ Y).toarray())
     if variant.startswith("schur2"):
@@ -122,7 +138,15 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None):
     _m = _re.search(r"oma([0-9.]+)", variant)        # "oma0.7", "post2oma0.7": damped velocity predictor
     om_a = float(_m.group(1)) if _m else 1.0
 
+    _m2 = _re.search(r"bsa([0-9.]+)", variant)       # "bsa1.5": Braess-Sarazin scaling alpha of the block inverse
+    bs_a = float(_m2.group(1)) if _m2 else 1.0
+
     def simple(r):
+        if bs_a != 1.0:            # A^ -> alpha A^ in predictor, Schur complement and correction
+            zv = (Ainv @ r[:nv]) / bs_a
+            zp = bs_a * schur_solve(J @ zv - r[nv:])
+            zv = zv - (Ainv @ (J.T @ zp)) / bs_a
+            return np.r_[zv, zp]
         zv = om_a * (Ainv @ r[:nv])
         zp = schur_solve(J @ zv - r[nv:])
         zv = zv - om_v * (Ainv @ (J.T @ zp))
@@ -131,6 +155,9 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None):
     def P(r):
         if variant == "nocoarse":
             return simple(r)
+        if variant.startswith("pre"):               # sweep first, coarse correction on its residual
+            z = simple(r)
+            return z + Y @ (Einv @ (Y.T @ (r - S @ z)))
         if variant.startswith("v11"):               # pre-sweep, coarse correction, post-sweep
             z = simple(r)
             r1 = r - S @ z
@@ -159,7 +186,8 @@ if __name__ == "__main__":
     rng = np.random.default_rng(1)
     b = np.r_[rng.standard_normal(pr.NV), np.zeros(pr.NP)]
     print("N = %d, nu = %g%s, n = %d" % (N, nu, " (DRE operator)" if dre else "", pr.NV + pr.NP))
-    cases = [("mass only", 1.0, 0.0)] + [("p = %g" % p, -p, 1.0) for p in (1.0, 30.0, 300.0, 3000.0)]
+    plist = [float(t) for t in os.environ.get("SHIFTS", "1,30,300,3000").split(",")]
+    cases = [("mass only", 1.0, 0.0)] + [("p = %g" % p, -p, 1.0) for p in plist]
     sel = [a for a in sys.argv[3:] if a != "dre"] or ["base", "schur2", "schur2f"]
     for variant in sel:
         row = []
@@ -169,7 +197,7 @@ if __name__ == "__main__":
             kw = {}
             if variant.startswith("ap"):          # "ap8": base cycle with pressure aggregates of 8
                 kw = dict(ap=int(variant[2:]))
-            if variant.startswith("bs"):          # "bs64": base cycle with 64-row smoother blocks
+            if variant.startswith("bs") and variant[2:].isdigit():          # "bs64": base cycle with 64-row smoother blocks
                 kw = dict(bs=int(variant[2:]))
             if variant.startswith("pb"):          # "pb128": Schur blocks of 128 pressure rows, velocity blocks of 32
                 kw = dict(pbs=int(variant[2:]))
@@ -179,6 +207,17 @@ if __name__ == "__main__":
                 kw = dict(cc=(MT, -al if be else 0.0, nu if be else 0.0, 1.0 / N))
                 if not be:      # mass only: Ap = M, Schur inverse = [J Mb^-1 J^T]_b^-1 (as base)
                     kw = {}
+            if "+" in variant or variant in ("sa", "sa2", "sa3", "sas"):  # "sa+pb256": tokens sa (smoothed prolongation), pbN, bsN, avN, apN
+                kw = {}
+                for tok in variant.split("+"):
+                    if tok in ("sa", "sa2", "sa3", "sas"):
+                        kw["sa"] = calA
+                        if tok[2:].isdigit():
+                            kw["sa_steps"] = int(tok[2:])
+                        if tok == "sas":
+                            kw["sa_shifted"] = True
+                    elif tok[:2] in ("pb", "bs", "av", "ap"):
+                        kw[{"pb": "pbs", "bs": "bs", "av": "av", "ap": "ap"}[tok[:2]]] = int(tok[2:])
             S, P, kk = make_precond(Ap, pr.J, MT, "base" if (kw and "cc" not in kw) or (variant.startswith("cc") and not kw) else variant, **kw)
             x, its = gmres_right(S, P, b)
             row.append(its)
