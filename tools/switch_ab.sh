@@ -1,6 +1,7 @@
 #!/bin/bash
-# same-call A/B of one environment switch of the preconditioner cycle: stage timings at cfg2 / cfg5 sizes and the
-# default bench line.  Usage on the box: tools/mid32_ab.sh TAG SWITCH   (e.g. RICADI_MID32, RICADI_PS_TILED)
+# same-call A/B of ONE of the library's 0/1 environment switches: stage timings of the lockstep
+# iteration at cfg2 / cfg5 sizes (tools/kernel_classes.py) and the default bench line (tools/ab.sh), switch on and off.
+# Usage on the box: tools/switch_ab.sh TAG SWITCH   (e.g. RICADI_MID32, RICADI_W32, RICADI_BLOCKS16)
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
