@@ -310,8 +310,10 @@ void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblock
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrs& Einv,
                           const double* rc, double* ec);
 // FP32-stored inverses (leading dimension ldf = k rounded up to 4; bs x bs blocks)
+// f32_matrix_cores: the product on v_mfma_f32_16x16x4_f32 (coarse residual rounded to FP32, FP32 accumulation per K
+// slice) instead of v_mfma_f64_16x16x4_f64 -- experimental, see the kernel
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
-                          int ldf, const double* rc, double* ec);
+                          int ldf, const double* rc, double* ec, bool f32_matrix_cores = false);
 void launch_block_apply_b(hipStream_t st, const GroupTab& gt, int bs, int nblocks, const int* bptr,
                           const int* rows, const GroupPtrsF& inv, const double* in, int ldi,
                           size_t gsi, double* out, int ldo, size_t gso, int m, int subtract,

@@ -1219,6 +1219,78 @@ __global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int
     if (row < k && c0 + cc < m) ec[(size_t)row * m + c0 + cc] = sum;
   }
 }
+// The same product on the FP32 matrix cores (v_mfma_f32_16x16x4_f32: twice the rate of the FP64 form, no
+// conversion of the FP32-stored inverse): the launch above is bound twice -- 0.53 of HBM on the inverses and 0.41 of
+// the FP64 matrix peak on their FP64 products.  The coarse residual is rounded to FP32 on load, a wave accumulates its
+// K slice (k / 8 terms) in FP32, the eight slices are summed in FP64.  Mirrored on scipy first (tools/schur_lab.py
+// `sa+c32h`: iteration counts identical to the FP64 product at N = 30 / 58, NSE and DRE operators) -- it is the
+// arithmetic of a flexible preconditioner whose inverse is FP32-stored already.  WRITTEN IN THE LAST SESSION OF ROUND 4
+// WITHOUT GPU-MINUTES LEFT: never run on the device, off unless RICADI_COARSE32=1; DESIGN.md section 10a.
+// Operand maps (cdna_hip_programming.md section 3): A[l & 15][k = l >> 4], B[k = l >> 4][l & 15] as in the FP64 form;
+// C/D col = l & 15, row = 4 (l >> 4) + reg (the FP64 form: row = (l >> 4) + 4 reg).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void dense_apply_tiled_f32mfma_kernel(GroupTab gt, int k, int m, GroupPtrsF Einvs,
+                                                                        const double* __restrict__ rc,
+                                                                        double* __restrict__ ec) {
+  __shared__ float red[8][16][17];
+  const int grp = gt.gid[blockIdx.z];
+  const float* __restrict__ Einv = Einvs.p[grp];
+  rc += (size_t)grp * k * m;
+  ec += (size_t)grp * k * m;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int it = blockIdx.x, c0 = blockIdx.y * 16;
+  const int kp = (k + 15) / 16;
+  const int per = (kp + 7) / 8;
+  const int ch0 = w * per, ch1 = min(kp, ch0 + per);
+  const int col = c0 + r;
+  f4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // one per chunk of a pass: no dependent MFMA pairs
+  const size_t lane_off = (size_t)r * 16 + 4 * q;
+  for (int ch = ch0; ch < ch1; ch += 2) {
+    const bool two = ch + 1 < ch1;               // wave-uniform
+    // all ten loads of a pass are requested before anything waits: the rc loads are unconditional on clamped
+    // addresses (k >= 1, m >= 1) and zeroed by selects afterwards -- behind per-lane branches hipcc put a
+    // vmcnt(0) after every one of them
+    double d0[4], d1[4];
+    const int colc = min(col, m - 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j0 = ch * 16 + 4 * q + t, j1 = j0 + 16;
+      d0[t] = rc[(size_t)min(j0, k - 1) * m + colc];
+      d1[t] = rc[(size_t)min(j1, k - 1) * m + colc];
+    }
+    const float* __restrict__ trow = Einv + ((size_t)it * kp + ch) * 256 + lane_off;
+    const float4 a0 = *reinterpret_cast<const float4*>(trow);
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (two) a1 = *reinterpret_cast<const float4*>(trow + 256);
+    float b0[4], b1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j0 = ch * 16 + 4 * q + t, j1 = j0 + 16;
+      b0[t] = (j0 < k && col < m) ? (float)d0[t] : 0.f;
+      b1[t] = (two && j1 < k && col < m) ? (float)d1[t] : 0.f;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1[0], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0[1], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1[2], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0[3], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1[3], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[w][4 * q + e][r] = acc0[e] + acc1[e];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int rr = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) sum += (double)red[t][rr][cc];
+    const int row = it * 16 + rr;
+    if (row < k && c0 + cc < m) ec[(size_t)row * m + c0 + cc] = sum;
+  }
+}
 template <class T>
 static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, int m,
                                      const GroupPtrsT<T>& Einv, const double* rc, double* ec) {
@@ -1233,8 +1305,14 @@ static void dense_apply_tiled_launch(hipStream_t st, const GroupTab& gt, int k, 
   hipLaunchKernelGGL((dense_apply_tiled_kernel<T, 1>), grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
 }
 void launch_dense_apply_b(hipStream_t st, const GroupTab& gt, int k, int m, const GroupPtrsF& Einv,
-                          int ldf, const double* rc, double* ec) {
+                          int ldf, const double* rc, double* ec, bool f32_matrix_cores) {
   (void)ldf;   // tile-major storage (launch_to_f32_tiled)
+  if (f32_matrix_cores) {
+    if (k <= 0 || gt.ng <= 0) return;
+    dim3 grid((k + 15) / 16, (m + 15) / 16, gt.ng);
+    hipLaunchKernelGGL(dense_apply_tiled_f32mfma_kernel, grid, dim3(512), 0, st, gt, k, m, Einv, rc, ec);
+    return;
+  }
   dense_apply_tiled_launch(st, gt, k, m, Einv, rc, ec);
 }
 // dst = FP32 copy of the k x k row-major src in 16 x 16 tile-major layout, zero padded

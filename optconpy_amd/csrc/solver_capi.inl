@@ -465,6 +465,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   }
   if (const char* e = getenv("RICADI_MID32")) c->mid32 = e[0] != '0';
   if (const char* e = getenv("RICADI_ROWWAVE")) c->rowwave = e[0] != '0';
+  if (const char* e = getenv("RICADI_COARSE32")) c->coarse_mfma32 = e[0] == '1';
   if (const char* e = getenv("RICADI_BLOCKS16")) c->blocks16 = e[0] != '0';
   if (const char* e = getenv("RICADI_X32")) c->x32_always = e[0] != '0';
   if (const char* e = getenv("RICADI_W32")) c->w32 = e[0] != '0';
@@ -1063,7 +1064,7 @@ int ricadi_time_kernel_dev(ricadi_ctx* c, int which, int ng, const double* alpha
             lc = lc->child.get();
           }
           if (c->precond32)
-            launch_dense_apply_b(st, gt, lc->kc, m, lb.einvf, (lc->kc + 3) & ~3, lc->rc.p, lc->ec.p);
+            launch_dense_apply_b(st, gt, lc->kc, m, lb.einvf, (lc->kc + 3) & ~3, lc->rc.p, lc->ec.p, c->coarse_mfma32);
           else
             launch_dense_apply_b(st, gt, lc->kc, m, lb.einv, lc->rc.p, lc->ec.p);
         }

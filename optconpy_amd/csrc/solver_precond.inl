@@ -247,7 +247,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       cb.tab = gt;
       precond_apply(c->child.get(), cb, c->rc.p, bt.gsc, c->ec.p);
     } else if (c->precond32)
-      launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p);
+      launch_dense_apply_b(st, gt, c->kc, m, bt.einvf, (c->kc + 3) & ~3, c->rc.p, c->ec.p, c->coarse_mfma32);
     else
       launch_dense_apply_b(st, gt, c->kc, m, bt.einv, c->rc.p, c->ec.p);
     if (!on(2) || (fusedp && folded)) {

@@ -152,7 +152,29 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None, sa=
         zv = zv - om_v * (Ainv @ (J.T @ zp))
         return om_s * np.r_[zv, zp]
 
+    c32 = "c32" in variant.split("+")            # coarse apply in FP32 ARITHMETIC on the FP32-stored inverse
+    c32h = "c32h" in variant.split("+")          # ... head of the coarse residual only (no tail)
+    if c32 or c32h:
+        Einv32 = Einv.astype(np.float32)
+        Yt = Y.T.tocsr()
+
+        def coarse(r):
+            rc = Yt @ r
+            hd = rc.astype(np.float32)
+            e = (Einv32 @ hd).astype(np.float64)
+            if c32:
+                e = e + (Einv32 @ (rc - hd).astype(np.float32)).astype(np.float64)
+            return Y @ e
+    else:
+        E32 = Einv.astype(np.float32).astype(np.float64)     # the product stores the inverse in FP32
+
+        def coarse(r):
+            return Y @ (E32 @ (Y.T @ r))
+
     def P(r):
+        if "c32" in variant or "c64" in variant:
+            z = coarse(r)
+            return z + simple(r - S @ z)
         if variant == "nocoarse":
             return simple(r)
         if variant.startswith("pre"):               # sweep first, coarse correction on its residual
@@ -216,9 +238,13 @@ if __name__ == "__main__":
                             kw["sa_steps"] = int(tok[2:])
                         if tok == "sas":
                             kw["sa_shifted"] = True
+                    elif tok in ("c32", "c32h", "c64"):
+                        pass
                     elif tok[:2] in ("pb", "bs", "av", "ap"):
                         kw[{"pb": "pbs", "bs": "bs", "av": "av", "ap": "ap"}[tok[:2]]] = int(tok[2:])
-            S, P, kk = make_precond(Ap, pr.J, MT, "base" if (kw and "cc" not in kw) or (variant.startswith("cc") and not kw) else variant, **kw)
+            keepv = any(t in ("c32", "c32h", "c64") for t in variant.split("+"))
+            S, P, kk = make_precond(Ap, pr.J, MT, variant if keepv else
+                                    "base" if (kw and "cc" not in kw) or (variant.startswith("cc") and not kw) else variant, **kw)
             x, its = gmres_right(S, P, b)
             row.append(its)
         print("%-10s %s   coarse (kv, kp) = %s  (%.0f s)" % (variant, "  ".join("%s: %d" % (c[0], i) for c, i in zip(cases, row)), kk,
