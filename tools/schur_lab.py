@@ -141,7 +141,40 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None, sa=
     _m2 = _re.search(r"bsa([0-9.]+)", variant)       # "bsa1.5": Braess-Sarazin scaling alpha of the block inverse
     bs_a = float(_m2.group(1)) if _m2 else 1.0
 
+    toks = variant.split("+")
+    if "b16" in toks or "m32" in toks or "mb2" in toks:
+        # block operands as the device stores them (BF16: 8 mantissa bits, round to nearest even)
+        def bf16(a):
+            u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+            return u.view(np.float32)
+        Ainv = sps.csr_matrix((bf16(Ainv.data).astype(np.float64), Ainv.indices, Ainv.indptr), shape=Ainv.shape)
+        Sinv = sps.csr_matrix((bf16(Sinv.data).astype(np.float64), Sinv.indices, Sinv.indptr), shape=Sinv.shape)
+        AinvJT = (Ainv @ J.T).tocsr()      # the last sweep's per-block rectangles, BF16-stored too
+        AinvJT = sps.csr_matrix((bf16(AinvJT.data).astype(np.float64), AinvJT.indices, AinvJT.indptr), shape=AinvJT.shape)
+        A32, S32, R32 = Ainv.astype(np.float32), Sinv.astype(np.float32), AinvJT.astype(np.float32)
+
+        def mm(M64, M32, x):
+            """block product as the matrix cores would do it: m32 = FP32 operands and accumulation,
+            mb2 = panel side rounded to two BF16 pieces (16 mantissa bits), FP32 accumulation"""
+            if "m32" in toks:
+                return (M32 @ x.astype(np.float32)).astype(np.float64)
+            if "mb2" in toks:
+                hi = bf16(x)
+                lo = bf16(x - hi.astype(np.float64))
+                return (M32 @ hi).astype(np.float64) + (M32 @ lo).astype(np.float64)
+            return M64 @ x
+
+        def simple(r):        # noqa: F811 -- the cycle on the rounded operands
+            zv = mm(Ainv, A32, r[:nv])
+            zp = mm(Sinv, S32, J @ zv - r[nv:])
+            zv = zv - mm(AinvJT, R32, zp)
+            return np.r_[zv, zp]
+        _simple_rounded = simple
+
     def simple(r):
+        if "b16" in toks or "m32" in toks or "mb2" in toks:
+            return _simple_rounded(r)
         if bs_a != 1.0:            # A^ -> alpha A^ in predictor, Schur complement and correction
             zv = (Ainv @ r[:nv]) / bs_a
             zp = bs_a * schur_solve(J @ zv - r[nv:])
@@ -152,6 +185,7 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None, sa=
         zv = zv - om_v * (Ainv @ (J.T @ zp))
         return om_s * np.r_[zv, zp]
 
+    keep_coarse_form = any(t in ("b16", "m32", "mb2") for t in variant.split("+"))
     c32 = "c32" in variant.split("+")            # coarse apply in FP32 ARITHMETIC on the FP32-stored inverse
     c32h = "c32h" in variant.split("+")          # ... head of the coarse residual only (no tail)
     if c32 or c32h:
@@ -172,7 +206,7 @@ def make_precond(Ap, J, gv, variant, bs=32, av=16, ap=24, cc=None, pbs=None, sa=
             return Y @ (E32 @ (Y.T @ r))
 
     def P(r):
-        if "c32" in variant or "c64" in variant:
+        if "c32" in variant or "c64" in variant or keep_coarse_form:
             z = coarse(r)
             return z + simple(r - S @ z)
         if variant == "nocoarse":
@@ -238,11 +272,11 @@ if __name__ == "__main__":
                             kw["sa_steps"] = int(tok[2:])
                         if tok == "sas":
                             kw["sa_shifted"] = True
-                    elif tok in ("c32", "c32h", "c64"):
+                    elif tok in ("c32", "c32h", "c64", "b16", "m32", "mb2"):
                         pass
                     elif tok[:2] in ("pb", "bs", "av", "ap"):
                         kw[{"pb": "pbs", "bs": "bs", "av": "av", "ap": "ap"}[tok[:2]]] = int(tok[2:])
-            keepv = any(t in ("c32", "c32h", "c64") for t in variant.split("+"))
+            keepv = any(t in ("c32", "c32h", "c64", "b16", "m32", "mb2") for t in variant.split("+"))
             S, P, kk = make_precond(Ap, pr.J, MT, variant if keepv else
                                     "base" if (kw and "cc" not in kw) or (variant.startswith("cc") and not kw) else variant, **kw)
             x, its = gmres_right(S, P, b)
