@@ -127,6 +127,32 @@ def child_cycle(E, kv, kp, kind, om=0.7, pair=2, cbs=32):
             def sweep(r):
                 z = one(r)
                 return z + one(r - E @ z)
+        elif kind == "vankac":            # coloured: patches of one colour share no unknown and are applied together
+            sets = [set(idx.tolist()) for idx, _ in patches]
+            colour = [-1] * len(patches)
+            for i in range(len(patches)):
+                used = {colour[j] for j in range(i) if sets[i] & sets[j]}
+                c = 0
+                while c in used:
+                    c += 1
+                colour[i] = c
+            ncol = max(colour) + 1
+            groups = [[i for i in range(len(patches)) if colour[i] == c] for c in range(ncol)]
+            print("    coloured Vanka: %d colours, patches per colour %s" % (ncol, [len(g_) for g_ in groups]), flush=True)
+
+            def sweep(r):
+                z = np.zeros(k)
+                res = r.copy()
+                for g_ in groups:
+                    d = np.zeros(k)
+                    for i in g_:
+                        idx, inv = patches[i]
+                        d[idx] = om * (inv @ res[idx])
+                    z += d
+                    res -= E @ d
+                if len(lone):
+                    z[lone] += om * dl * res[lone]
+                return z
         elif kind == "vanka":
             def sweep(r):
                 z = np.zeros(k)
