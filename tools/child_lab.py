@@ -188,6 +188,9 @@ if __name__ == "__main__":
     pr = pb.ricc_problem(N, nu)
     MT = pr.M.T.tocsr()
     calA = (-pr.A - pr.Nc).T.tocsr()
+    if os.environ.get("DRE") == "1":      # operator of a DRE time step (schur_lab.py): -(M^T / 2 + tau (A + N)^T)
+        tau = float(np.diff(pb.get_tint(0.0, 1.0, 16, True)).max())
+        calA = (-(0.5 * MT + tau * (pr.A.T + pr.Nc.T))).tocsr()
     Ap = (calA - p * MT).tocsr()
     S, Y, E, kv, kp, simple = build(Ap, pr.J, MT, calA, av, ap)
     b = np.r_[np.random.default_rng(1).standard_normal(pr.NV), np.zeros(pr.NP)]
