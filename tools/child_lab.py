@@ -203,7 +203,7 @@ if __name__ == "__main__":
             capply = lambda r: Einv @ r  # noqa: E731
             extra = ""
         else:
-            capply, kv2 = child_cycle(E, kv, kp, kind, om=om)
+            capply, kv2 = child_cycle(E, kv, kp, kind, om=om, pair=int(os.environ.get("PAIR", "2")))
             extra = " child coarse %d" % (kv2 + kp)
 
         def P(r):
