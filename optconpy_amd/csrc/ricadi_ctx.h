@@ -305,6 +305,7 @@ struct ricadi_ctx {
   bool blocks16 = true;       // RICADI_BLOCKS16=0: the sweeps apply the FP32 copies of the per-shift blocks
   bool rowwave = true;        // RICADI_ROWWAVE=0: the restriction through the 16-lanes-per-row CSR kernel
   bool mid32 = true;          // RICADI_MID32=0: the velocity part between the sweeps of a cycle stays an FP64 panel
+  bool sweep_mfma32 = false;  // RICADI_SWEEP32=1: first velocity sweep on the FP32 matrix cores (experimental, unmeasured: DESIGN 10a)
   bool coarse_mfma32 = false; // RICADI_COARSE32=1: coarse apply on the FP32 matrix cores (experimental, unmeasured: DESIGN 10a)
   int w32_last = -1;          // the last operator launch of an iteration / timing class wrote the FP32 panel (1) or FP64 (0)
   int mid32_last = -1;        // what the last preconditioner application did (1 FP32 panel, 0 FP64; -1 none yet)

@@ -410,7 +410,8 @@ void launch_to_bf16(hipStream_t st, size_t n, const double* src, uint16_t* dst);
 // contracts as launch_block_apply2_b / launch_block_apply_rect_b / launch_pressure_step_b with the FP32 panel; return
 // false (nothing launched) when the shape is not the hot one.
 bool launch_block_two32_h(hipStream_t st, const GroupTab& gt, int nblocks, const GroupPtrsH& m1, const Seg2& s1,
-                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa);
+                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa,
+                          bool f32_matrix_cores = false);
 bool launch_block_rect32_h(hipStream_t st, const GroupTab& gt, int ks, int nblocks, const GroupPtrsH& mats,
                            const double* in, size_t gsi, double* out, size_t gso, int subtract, const ProlongArgs& pa);
 void launch_pressure_step_h(hipStream_t st, const GroupTab& gt, int nblocks, const int* meta,

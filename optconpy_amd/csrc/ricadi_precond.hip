@@ -36,6 +36,7 @@ __device__ __forceinline__ void load4(const float* p, double (&a)[4]) {
 
 // four consecutive stored entries as ONE raw load; converted to FP64 only when used (a conversion between
 // loads makes the compiler wait for each load in turn)
+typedef float f4v __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f32_16x16x4_f32
 template <class T>
 struct Raw4;
 template <>
@@ -455,6 +456,124 @@ __global__ __launch_bounds__(256) void block_two32_kernel(
         if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + at] = v;
         if (!(o32 && pa.only32)) out[at] = v;
         if (o32) o32[at] = (float)v;
+      }
+    }
+}
+
+// The first sweep on the FP32 matrix cores (v_mfma_f32_16x16x4_f32; BF16-stored blocks widened by a shift, the two
+// input panels rounded to FP32, FP32 accumulation over the block's <= 96 terms): block_two32_kernel above does 1.30
+// GFLOP per 16-group launch at cfg2 in 34 us = 0.49 of the FP64 matrix peak beside its 0.46 of HBM.  The arithmetic
+// was mirrored on scipy (tools/schur_lab.py `sa+b16+m32`: iteration counts identical).  As the coarse apply's FP32
+// form: WRITTEN IN THE LAST SESSION OF ROUND 4 WITHOUT GPU-MINUTES LEFT, never run on the device, off unless
+// RICADI_SWEEP32=1.  Differences from the kernel above: operand and accumulator types, and
+// the C/D map of the FP32 form -- row = 4 (l >> 4) + reg instead of (l >> 4) + 4 reg -- in the output rows.
+template <int K2, bool H1>
+__global__ __launch_bounds__(256) void block_two32_f32mfma_kernel(
+    GroupTab gt, int nblocks, const int* __restrict__ meta, int mstride, int in_off, GroupPtrsT<uint16_t> m1s, Seg2 s1,
+    GroupPtrsT<uint16_t> m2s, Seg2 s2, double* __restrict__ out, size_t gso, ProlongArgs pa) {
+  const int grp = gt.gid[blockIdx.z];
+  out += (size_t)grp * gso;
+  float* __restrict__ o32 = pa.out32 ? pa.out32 + (size_t)grp * pa.gs32 : nullptr;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wave >= nblocks) return;
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  constexpr int N2 = K2 / 16;
+  const uint16_t* __restrict__ M1 = m1s.p[grp] + (size_t)wave * 32 * 32;
+  const uint16_t* __restrict__ M2 = m2s.p[grp] + (size_t)wave * 32 * K2;
+  const double* __restrict__ in1 = s1.in ? s1.in + (size_t)grp * s1.gs : nullptr;
+  const _Float16* __restrict__ in1h = s1.in16 ? s1.in16 + (size_t)grp * s1.gs : nullptr;
+  const double* __restrict__ in2 = s2.in + (size_t)grp * s2.gs;
+  const int* __restrict__ mt = meta + (size_t)wave * mstride;
+  const int nb = mt[0], ni = mt[2];
+  int r1[2][4], r2[N2][4], orow[2][4];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) r1[kc][s4] = mt[4 + kc * 16 + 4 * q + s4];
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) r2[kc][s4] = mt[in_off + kc * 16 + 4 * q + s4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) orow[t][e] = mt[4 + 16 * t + 4 * q + e];      // FP32 C/D map
+  _Float16 h1[2][4];
+  double x1[2][4], x2[N2][4];
+  uint2 a1[2][2], a2[2][N2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if (H1) h1[kc][s4] = ld_off(in1h, (unsigned)(r1[kc][s4] * 16 + r) * 2u);
+      else x1[kc][s4] = ld_off(in1, (unsigned)(r1[kc][s4] * 16 + r) * 8u);
+    }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) x2[kc][s4] = ld_off(in2, (unsigned)(r2[kc][s4] * 16 + r) * 8u);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) a1[t][kc] = Raw4<uint16_t>::load(M1 + (16 * t + r) * 32 + kc * 16 + 4 * q);
+#pragma unroll
+    for (int kc = 0; kc < N2; ++kc) a2[t][kc] = Raw4<uint16_t>::load(M2 + (16 * t + r) * K2 + kc * 16 + 4 * q);
+  }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(x2[kc][s4]));
+  __builtin_amdgcn_sched_barrier(0);
+  auto widen = [](const uint2& u, float (&a)[4]) {
+    a[0] = __uint_as_float(u.x << 16);
+    a[1] = __uint_as_float(u.x & 0xffff0000u);
+    a[2] = __uint_as_float(u.y << 16);
+    a[3] = __uint_as_float(u.y & 0xffff0000u);
+  };
+  f4v acc[2];
+  acc[0] = acc[1] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    float xm[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float v = H1 ? (float)h1[kc][s4] : (float)x1[kc][s4];
+      xm[s4] = (kc * 16 + 4 * q + s4 < nb) ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float a4[4];
+      widen(a1[t][kc], a4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], xm[s4], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int kc = 0; kc < N2; ++kc) {
+    if (kc * 16 >= ni) break;                 // wave-uniform
+    float xm[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) xm[s4] = (kc * 16 + 4 * q + s4 < ni) ? -(float)x2[kc][s4] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float a4[4];
+      widen(a2[t][kc], a4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], xm[s4], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int il = 16 * t + 4 * q + e;
+      if (il < nb) {
+        const unsigned at = (unsigned)(orow[t][e] * 16 + r);
+        const double v = (double)acc[t][e];
+        if (pa.out2) pa.out2[(size_t)grp * pa.gs2 + at] = v;
+        if (!(o32 && pa.only32)) out[at] = v;
+        if (o32) o32[at] = acc[t][e];
       }
     }
 }
@@ -1228,7 +1347,6 @@ __global__ __launch_bounds__(512) void dense_apply_tiled_kernel(GroupTab gt, int
 // WITHOUT GPU-MINUTES LEFT: never run on the device, off unless RICADI_COARSE32=1; DESIGN.md section 10a.
 // Operand maps (cdna_hip_programming.md section 3): A[l & 15][k = l >> 4], B[k = l >> 4][l & 15] as in the FP64 form;
 // C/D col = l & 15, row = 4 (l >> 4) + reg (the FP64 form: row = (l >> 4) + 4 reg).
-typedef float f4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512) void dense_apply_tiled_f32mfma_kernel(GroupTab gt, int k, int m, GroupPtrsF Einvs,
                                                                         const double* __restrict__ rc,
                                                                         double* __restrict__ ec) {
@@ -1681,12 +1799,22 @@ void launch_to_bf16(hipStream_t st, size_t n, const double* src, uint16_t* dst) 
   hipLaunchKernelGGL(to_bf16_kernel, dim3(grid), dim3(256), 0, st, n, src, dst);
 }
 bool launch_block_two32_h(hipStream_t st, const GroupTab& gt, int nblocks, const GroupPtrsH& m1, const Seg2& s1,
-                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa) {
+                          const GroupPtrsH& m2, const Seg2& s2, double* out, size_t gso, const ProlongArgs& pa,
+                          bool f32_matrix_cores) {
   if (nblocks <= 0 || gt.ng <= 0) return true;
   if (!(pa.bmeta && !pa.aggof && (s2.kstride == 32 || s2.kstride == 64) &&
         std::max(std::max(gso, s1.gs), s2.gs) * 8 < ((size_t)1 << 32)))
     return false;
   dim3 grid((nblocks + 3) / 4, 1, gt.ng), block(256);
+  if (f32_matrix_cores) {          // experimental (RICADI_SWEEP32=1), see block_two32_f32mfma_kernel
+#define RICADI_TWO32F(K, H)                                                                                       \
+  hipLaunchKernelGGL((block_two32_f32mfma_kernel<K, H>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
+                     pa.bm_in, m1, s1, m2, s2, out, gso, pa)
+    if (s2.kstride == 32) { if (s1.in16) RICADI_TWO32F(32, true); else RICADI_TWO32F(32, false); }
+    else { if (s1.in16) RICADI_TWO32F(64, true); else RICADI_TWO32F(64, false); }
+#undef RICADI_TWO32F
+    return true;
+  }
 #define RICADI_TWO32(K, H)                                                                                         \
   hipLaunchKernelGGL((block_two32_kernel<K, uint16_t, H>), grid, block, 0, st, gt, nblocks, pa.bmeta, pa.bm_stride, \
                      pa.bm_in, m1, s1, m2, s2, out, gso, pa)

@@ -466,6 +466,7 @@ int ricadi_set_operator(ricadi_ctx* c, int nv, int np, const int32_t* a_rp, cons
   if (const char* e = getenv("RICADI_MID32")) c->mid32 = e[0] != '0';
   if (const char* e = getenv("RICADI_ROWWAVE")) c->rowwave = e[0] != '0';
   if (const char* e = getenv("RICADI_COARSE32")) c->coarse_mfma32 = e[0] == '1';
+  if (const char* e = getenv("RICADI_SWEEP32")) c->sweep_mfma32 = e[0] == '1';
   if (const char* e = getenv("RICADI_BLOCKS16")) c->blocks16 = e[0] != '0';
   if (const char* e = getenv("RICADI_X32")) c->x32_always = e[0] != '0';
   if (const char* e = getenv("RICADI_W32")) c->w32 = e[0] != '0';

@@ -331,7 +331,7 @@ static void precond_apply(ricadi_ctx* c, const Batch& bt, const double* r, size_
       fpa.bm_in = c->sw_in_two;
       fpa.bm_ni = 2;
     }
-    if (b16 && launch_block_two32_h(st, gt, c->nbv, bt.bvinvh, s1, bt.adymh, s2, z, bt.gs, fpa)) {
+    if (b16 && launch_block_two32_h(st, gt, c->nbv, bt.bvinvh, s1, bt.adymh, s2, z, bt.gs, fpa, c->sweep_mfma32)) {
     } else if (c->precond32)
       launch_block_apply2_b(st, gt, c->bs, c->nbv, c->bv_ptr.p, c->bv_rows.p, bt.bvinvf, s1, bt.adymf, s2, z, m,
                             bt.gs, m, fpa);

@@ -357,11 +357,13 @@ def test_cycle_forms_of_round4_against_sparse_lu(cfg1, monkeypatch):
 
 @pytest.mark.skipif(os.environ.get("RICADI_EXPERIMENTAL") != "1",
                     reason="kernel written without GPU-minutes left (round 4): run with RICADI_EXPERIMENTAL=1 first")
-def test_experimental_coarse_apply_on_fp32_matrix_cores(cfg1, monkeypatch):
-    """RICADI_COARSE32=1: the coarse apply on v_mfma_f32_16x16x4_f32 (coarse residual rounded to FP32, FP32
-    accumulation per K slice) instead of the FP64 matrix cores.  Mirrored on scipy (tools/schur_lab.py sa+c32h:
-    iteration counts unchanged); on the device it has to solve to the tolerance, agree with the sparse LU and keep
-    the default's iteration counts within a few before it may become the default."""
+@pytest.mark.parametrize("switch", ["RICADI_COARSE32", "RICADI_SWEEP32"])
+def test_experimental_fp32_matrix_core_forms(cfg1, monkeypatch, switch):
+    """RICADI_COARSE32=1: the coarse apply, RICADI_SWEEP32=1: the first velocity sweep on v_mfma_f32_16x16x4_f32
+    (operands rounded to FP32, FP32 accumulation) instead of the FP64 matrix cores.  Mirrored on scipy
+    (tools/schur_lab.py sa+c32h, sa+b16+m32: iteration counts unchanged); on the device each has to solve to the
+    tolerance, agree with the sparse LU and keep the default's iteration counts within a few before it may become
+    the default."""
     import torch
     pr = cfg1[0]
     calA = (-pr.A - pr.Nc).T.tocsr()
@@ -370,7 +372,7 @@ def test_experimental_coarse_apply_on_fp32_matrix_cores(cfg1, monkeypatch):
     ps = [-1.0, -40.0, -1500.0]
     refs = [olau.SaddleLU(calA + p * MT, pr.J).solve(R) for p in ps]
     iters = {}
-    for name, val in (("default", None), ("RICADI_COARSE32", "1")):
+    for name, val in (("default", None), (switch, "1")):
         if val is not None:
             monkeypatch.setenv(name, val)
         with _lib.Context(0) as ctx:
@@ -386,4 +388,4 @@ def test_experimental_coarse_apply_on_fp32_matrix_cores(cfg1, monkeypatch):
         for g in range(len(ps)):
             assert rel(X[g][:pr.NV], refs[g][:pr.NV]) < 1e-8, (name, g)
         iters[name] = np.asarray(its, dtype=float)
-    assert np.abs(iters["RICADI_COARSE32"] - iters["default"]).max() <= 3, iters
+    assert np.abs(iters[switch] - iters["default"]).max() <= 3, iters
